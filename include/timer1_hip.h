@@ -1,0 +1,109 @@
+/*
+ * timer1_hip.h - C ABI of libtimer1_hip.so: the MI355X (gfx950) kernels behind the Time-R1 GRPO rollout-and-update path.
+ *
+ * The reference (xiaomi-research/time-r1) has no native code of its own; its hot path reaches native kernels only through
+ * third-party wheels (torch/cuBLAS/flash-attn/DeepSpeed).  Every entry point below names the reference call site whose native
+ * work it replaces ("ref:" = path under the reference repo, "TF:" = transformers/models/qwen2_vl/modeling_qwen2_vl.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated; bf16 = raw uint16 bfloat16 bits;
+ *   - `stream` is a hipStream_t (pass 0 for the null stream); every call is asynchronous on that stream;
+ *   - return value 0 = success, otherwise a hipError_t or 1000 (argument check failed); tr1_last_error() returns the message;
+ *   - the library never allocates device memory: workspaces are caller-provided.
+ *
+ * This header is parsed by time-r1_amd/hip.py to build the ctypes signatures, so keep one declaration per statement and
+ * only the types: void*, const void*, char*, int64_t*, int64_t, uint64_t, int, float.
+ */
+#ifndef TIMER1_HIP_H
+#define TIMER1_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- plumbing ------------------------------------------------------------------------------------------------------ */
+int tr1_version(void);
+const char* tr1_last_error(void);
+int tr1_device_info(int device, char* arch, int64_t arch_len, int64_t* n_cu, int64_t* hbm_bytes);
+
+/* ---- GEMM: C[M,N] = A[M,K] * B[N,K]^T (+bias[N]) (+residual[M,N]); bf16 in, fp32 accumulate on MFMA ------------------- */
+/* ref: every nn.Linear on the path - TF:501-504 (q/k/v/o), TF:459-466 (MLP), TF:251-274 (patch embed), TF:277-290 (merger),
+ * TF:1323 (lm_head); called from src/time_r1/rl/timer1_trainer.py:452-457 (logprob forward) and :569-573 (generate).
+ * K % 64 == 0 (pad), N % 8 == 0.  out_f32: C is fp32; accumulate (fp32 only): C += result (weight-gradient accumulation).
+ * M <= 16 dispatches the HBM-streaming skinny kernel used by rollout decode. */
+int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream);
+/* out[c, r] = in[r, c]; columns [R, ld_out) of out are zero-filled (feeds the NT GEMM for dgrad / wgrad). */
+int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------------------------- */
+/* ref: Qwen2RMSNorm TF:96-110 (fp32 math, cast to bf16 BEFORE the weight multiply).  If residual != NULL the kernel first forms
+ * xsum = bf16(x + residual) (the decoder's residual add, TF:559-624), writes it, and normalises xsum.  rstd (fp32[rows]) optional. */
+int tr1_rmsnorm_fwd(const void* x, const void* residual, const void* w, void* y, void* xsum, void* rstd, int64_t rows, int64_t cols, float eps, void* stream);
+/* dx = rmsnorm'(dy) (+ dres if given);  dw_f32[c] += sum_r dy*xhat   (autograd of the above; ref: accelerator.backward, TF trainer.py:1952-1961) */
+int tr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* rstd, const void* dres, void* dx, void* dw_f32, int64_t rows, int64_t cols, void* stream);
+/* ref: nn.LayerNorm(eps=1e-6) in VisionBlock TF:425-449 and PatchMerger.ln_q TF:277-290 */
+int tr1_layernorm_fwd(const void* x, const void* w, const void* b, void* y, void* mean, void* rstd, int64_t rows, int64_t cols, float eps, void* stream);
+int tr1_layernorm_bwd(const void* dy, const void* x, const void* w, const void* mean, const void* rstd, void* dx, void* dw_f32, void* db_f32, int64_t rows, int64_t cols, void* stream);
+
+/* ---- activations / elementwise ---------------------------------------------------------------------------------------- */
+/* ref: Qwen2MLP TF:459-466: out = silu(gate) * up with gu = [gate | up] along the feature axis */
+int tr1_swiglu_fwd(const void* gu, void* out, int64_t rows, int64_t inter, void* stream);
+int tr1_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int64_t inter, void* stream);
+/* ref: PatchMerger GELU(erf) TF:277-290; VisionMlp quick_gelu TF:293-301 */
+int tr1_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int tr1_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+int tr1_quickgelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int tr1_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+int tr1_cast_f32_to_bf16(const void* x, void* y, int64_t n, void* stream);
+int tr1_cast_bf16_to_f32(const void* x, void* y, int64_t n, void* stream);
+int tr1_colsum_accum(const void* dy, void* dbias_f32, int64_t rows, int64_t cols, void* stream);
+
+/* ---- rotary embeddings ------------------------------------------------------------------------------------------------ */
+/* ref: Qwen2VLRotaryEmbedding TF:117-169 + apply_multimodal_rotary_pos_emb TF:180-222.  pos3: int32 [3, T] (t,h,w) from
+ * get_rope_index TF:914-1016; cos/sin: fp32 [T, head_dim/2]; sections (sec_t, sec_h, sec_w) = mrope_section. */
+int tr1_mrope_table(const void* pos3, void* cosb, void* sinb, int64_t T, int64_t head_dim, int64_t sec_t, int64_t sec_h, int64_t sec_w, float theta, int round_bf16, void* stream);
+/* ref: VisionRotaryEmbedding + apply_rotary_pos_emb_vision TF:225-248; hw: int32 [N, 2] patch (h, w) ids in merge-block order */
+int tr1_vision_rope_table(const void* hw, void* cosb, void* sinb, int64_t N, int64_t head_dim, float theta, void* stream);
+/* rotate-half RoPE on n_heads heads stored inside rows of `in` (row stride ld_in); backward != 0 applies the adjoint rotation */
+int tr1_rope_apply(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* cosb, const void* sinb, int64_t T, int64_t n_heads, int64_t head_dim, int backward, void* stream);
+
+/* ---- embedding / scatter ---------------------------------------------------------------------------------------------- */
+/* ref: embed_tokens TF:1160 and the masked_scatter of video embeddings TF:1170-1176 */
+int tr1_gather_rows(const void* table, const void* ids, void* out, int64_t T, int64_t cols, void* stream);
+int tr1_scatter_rows(const void* src, const void* idx, void* dst, int64_t T, int64_t cols, void* stream);
+int tr1_embed_bwd(const void* dout, const void* ids, void* dtable_f32, int64_t T, int64_t cols, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------------------------------- */
+/* Two-interval masked flash attention: key kv is visible to query token t iff kv < pre[t] or lo[t] <= kv <= hi[t].
+ * ref: flash_attn_varlen_func / SDPA via TF:379-396 (ViT, cu_seqlens segments) and TF:521-556 (LLM causal GQA); the shared-prefix
+ * form replaces the G-times replicated prompt of timer1_trainer.py:594-599.  Q/O: [T, n_heads*head_dim]; K: [slots, n_kv*head_dim];
+ * VT: [n_kv*head_dim, vt_ld] (slot-contiguous).  lse (optional): fp32 [n_heads, T].  nsplit > 1 = split-KV (decode) with a
+ * caller workspace of tr1_attn_fwd_workspace_floats() floats. */
+int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, void* stream);
+int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit);
+/* Backward of the above (recompute based): needs K, V row-major and the transposed copies KT, QT, dOT (tr1_pack_transpose).
+ * delta: fp32 [n_heads, T] scratch; qmeta_ws: int32 [3*ceil(T*group/64)] scratch.  Writes dQ [T, n_heads*hd], dK, dV [slots, n_kv*hd]. */
+int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT, int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld, const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld, void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
+/* out[(kvh*hd + d) * ld_out + col] = in[t*ld_in + (kvh*group + hq)*hd + d], col = t*group + hq (or slots[t] when slots != NULL, group 1) */
+int tr1_pack_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* slots, int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int zero_pad, void* stream);
+/* KV-cache append: dst[slots[t], :] = src[t, :] */
+int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const void* slots, int64_t T, int64_t cols, void* stream);
+
+/* ---- vocabulary side -------------------------------------------------------------------------------------------------- */
+/* ref: src/time_r1/rl/timer1_trainer.py:458-481 (_get_per_token_logps: log_softmax, gather, entropy) */
+int tr1_logp_entropy_fwd(const void* logits, int64_t ld, const void* targets, void* logp, void* entropy, void* lse, int64_t R, int64_t V, void* stream);
+int tr1_logp_bwd(const void* logits, int64_t ld, const void* targets, const void* lse, const void* dlogp, void* dlogits, int64_t ld_out, int64_t R, int64_t V, void* stream);
+/* ref: timer1_trainer.py:635-639 (k3 KL), :713-737 (both loss branches).  out3 = {loss, mean masked kl, sum mask}. */
+int tr1_grpo_loss(const void* logp, const void* ref_logp, const void* mask, const void* adv, void* dlogp, void* out3, void* row_len, void* row_kl, int64_t G, int64_t C, float beta, int use_grpo, float grad_scale, void* stream);
+/* ref: model.generate(do_sample=True, temperature, top_k) at timer1_trainer.py:568-573.  tokens[row*tok_ld + *step_ptr] = draw. */
+int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* stream);
+
+/* ---- optimizer -------------------------------------------------------------------------------------------------------- */
+/* ref: DeepSpeed FusedAdam / DeepSpeedCPUAdam selected by scripts/zero3.json:13-21 and zero3_offload.json:24-31 (AdamW, clip 1.0) */
+int tr1_sumsq_accum(const void* g, int64_t n, void* out_scalar, void* stream);
+int tr1_adamw_step(void* p_f32, void* m_f32, void* v_f32, void* g_f32, void* p_bf16, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const void* sumsq_scalar, float max_norm, float grad_mult, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

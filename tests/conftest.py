@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_ops():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import time_r1_amd  # noqa: F401
+    from time_r1_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def ref_ops():
+    from oracle.ref_ops import RefOps
+    return RefOps()

@@ -1,0 +1,355 @@
+"""GPU parity: every HIP kernel behind the C ABI vs the CPU oracle (oracle/ref_ops.py) on the same seeded inputs.
+
+Inputs are drawn in fp32, rounded to bf16 once, and handed to both sides; the oracle computes in fp32. Tolerances are bf16-scale
+(the HIP path stores bf16 activations, fp32 accumulate) and written next to each check.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF16)
+
+
+def close(hip_t, ref_t, atol, rtol=2e-2, what=""):
+    a = hip_t.detach().float().cpu()
+    b = ref_t.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what + ": non-finite values from the HIP path"
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d elements off, max err %.4g (ref %.4g) at %s" % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(b.flatten()[err.argmax()]), str(divmod(int(err.argmax()), b.shape[-1])))
+
+
+def both(hip_ops, ref_ops, fn, *tensors, **kw):
+    """Run ops.<fn> on GPU copies and on fp32 CPU copies."""
+    dev = [t.to("cuda:0") if isinstance(t, torch.Tensor) else t for t in tensors]
+    cpu = [t.float() if isinstance(t, torch.Tensor) and t.dtype == BF16 else t for t in tensors]
+    return getattr(hip_ops, fn)(*dev, **kw), getattr(ref_ops, fn)(*cpu, **kw)
+
+
+# ------------------------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 128, 256), (8, 512, 3584), (16, 72, 320), (130, 200, 64), (257, 384, 192), (300, 1152, 512),
+                                   (128, 128, 64), (513, 136, 1216)])
+def test_gemm_nt(hip_ops, ref_ops, M, N, K):
+    a, b, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    atol = 0.02 * math.sqrt(K) * 0.1 + 0.02
+    h, r = both(hip_ops, ref_ops, "gemm_nt", a, b)
+    close(h, r, atol, what="gemm plain")
+    h = hip_ops.gemm_nt(a.cuda(), b.cuda(), bias=bias.cuda(), residual=res.cuda())
+    r = ref_ops.gemm_nt(a.float(), b.float(), bias=bias.float(), residual=res.float())
+    close(h, r, atol, what="gemm bias+residual")
+    # fp32 output + accumulate (weight-gradient mode)
+    if M > 16:
+        out = torch.full((M, N), 0.5, device="cuda:0")
+        hip_ops.gemm_nt(a.cuda(), b.cuda(), out_f32=True, out=out, accumulate=True)
+        close(out, a.float() @ b.float().t() + 0.5, 1e-3 * math.sqrt(K), rtol=1e-3, what="gemm f32 accumulate")
+    out = hip_ops.gemm_nt(a.cuda(), b.cuda(), out_f32=True)
+    close(out, a.float() @ b.float().t(), 1e-3 * math.sqrt(K), rtol=1e-3, what="gemm f32")
+
+
+def test_gemm_strided_views(hip_ops, ref_ops):
+    big = rnd(200, 448, seed=5)
+    a = big[:, 64:192]  # lda = 448
+    b = rnd(96, 128, seed=6, scale=0.1)
+    h = hip_ops.gemm_nt(a.cuda(), b.cuda())
+    close(h, a.float() @ b.float().t(), 0.05, what="gemm strided A")
+
+
+@pytest.mark.parametrize("R,C", [(5, 64), (100, 136), (257, 64), (64, 4608)])
+def test_transpose(hip_ops, ref_ops, R, C):
+    x = rnd(R, C, seed=7)
+    h, r = both(hip_ops, ref_ops, "transpose", x)
+    assert torch.equal(h.float().cpu(), r.float()), "transpose must be bit exact (incl. zero padding)"
+
+
+# ----------------------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,cols", [(1, 64), (37, 1536), (130, 3584), (9, 4096), (300, 1280)])
+def test_rmsnorm(hip_ops, ref_ops, rows, cols):
+    x, w, res, dy = rnd(rows, cols, seed=1, scale=2.0), rnd(cols, seed=2), rnd(rows, cols, seed=3), rnd(rows, cols, seed=4)
+    (y, rstd, _), (yr, rstdr, _) = both(hip_ops, ref_ops, "rmsnorm_fwd", x, w, 1e-6)
+    close(y, yr, 0.02, what="rmsnorm y")
+    close(rstd, rstdr, 1e-5, rtol=1e-4, what="rmsnorm rstd")
+    (y, rstd, xs), (yr, rstdr, xsr) = hip_ops.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-6, residual=res.cuda()), \
+        RefBF().rmsnorm_fwd(x, w, 1e-6, residual=res)
+    assert torch.equal(xs.float().cpu(), xsr.float()), "fused residual sum must equal bf16(x+res) exactly"
+    close(y, yr, 0.02, what="rmsnorm(res) y")
+    # backward
+    dw_h = torch.zeros(cols, device="cuda:0")
+    dw_r = torch.zeros(cols)
+    dx_h = hip_ops.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstdr.cuda(), dres=res.cuda(), dw=dw_h)
+    dx_r = ref_ops.rmsnorm_bwd(dy.float(), x.float(), w.float(), rstdr, dres=res.float(), dw=dw_r)
+    close(dx_h, dx_r, 0.03, what="rmsnorm dx")
+    close(dw_h, dw_r, 0.02 * math.sqrt(rows) + 1e-3, rtol=1e-3, what="rmsnorm dw")
+
+
+def RefBF():
+    from oracle.ref_ops import RefOps
+    return RefOps(act_dtype=BF16)
+
+
+@pytest.mark.parametrize("rows,cols", [(3, 64), (130, 1280)])
+def test_layernorm(hip_ops, ref_ops, rows, cols):
+    x, w, b, dy = rnd(rows, cols, seed=1, scale=2.0), rnd(cols, seed=2), rnd(cols, seed=3), rnd(rows, cols, seed=4)
+    (y, mean, rstd), (yr, meanr, rstdr) = both(hip_ops, ref_ops, "layernorm_fwd", x, w, b, 1e-6)
+    close(y, yr, 0.02, what="layernorm y")
+    close(mean, meanr, 1e-5, rtol=1e-4, what="ln mean")
+    close(rstd, rstdr, 1e-5, rtol=1e-4, what="ln rstd")
+    dw_h, db_h = torch.zeros(cols, device="cuda:0"), torch.zeros(cols, device="cuda:0")
+    dw_r, db_r = torch.zeros(cols), torch.zeros(cols)
+    dx_h = hip_ops.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), meanr.cuda(), rstdr.cuda(), dw_h, db_h, need_dx=True)
+    dx_r = ref_ops.layernorm_bwd(dy.float(), x.float(), w.float(), meanr, rstdr, dw_r, db_r, need_dx=True)
+    close(dx_h, dx_r, 0.03, what="ln dx")
+    close(dw_h, dw_r, 0.02 * math.sqrt(rows) + 1e-3, rtol=1e-3, what="ln dw")
+    close(db_h, db_r, 0.02 * math.sqrt(rows) + 1e-3, rtol=1e-3, what="ln db")
+
+
+# ----------------------------------------------------------------------------------------------------------- elementwise
+def test_activations(hip_ops, ref_ops):
+    gu, dout = rnd(77, 2 * 136, seed=1, scale=2.0), rnd(77, 136, seed=2)
+    h, r = both(hip_ops, ref_ops, "swiglu_fwd", gu)
+    close(h, r, 0.02, what="swiglu fwd")
+    h, r = both(hip_ops, ref_ops, "swiglu_bwd", dout, gu)
+    close(h, r, 0.03, what="swiglu bwd")
+    x, dy = rnd(50, 128, seed=3, scale=2.0), rnd(50, 128, seed=4)
+    for fn in ("gelu_fwd", "quickgelu_fwd"):
+        h, r = both(hip_ops, ref_ops, fn, x)
+        close(h, r, 0.02, what=fn)
+    h, r = both(hip_ops, ref_ops, "gelu_bwd", x, dy)
+    close(h, r, 0.02, what="gelu bwd")
+    h, r = both(hip_ops, ref_ops, "add", x, dy)
+    close(h, r, 0.02, what="add")
+    acc_h, acc_r = torch.ones(128, device="cuda:0"), torch.ones(128)
+    hip_ops.colsum_accum(rnd(300, 128, seed=5).cuda(), acc_h)
+    ref_ops.colsum_accum(rnd(300, 128, seed=5).float(), acc_r)
+    close(acc_h, acc_r, 1e-3, rtol=1e-4, what="colsum")
+
+
+def test_rope(hip_ops, ref_ops):
+    T, nh, hd = 70, 6, 128
+    g = torch.Generator().manual_seed(0)
+    pos3 = torch.randint(0, 4000, (3, T), generator=g, dtype=torch.int32)
+    (c, s), (cr, sr) = hip_ops.mrope_table(pos3.cuda(), hd, (16, 24, 24), 1e6), ref_ops.mrope_table(pos3, hd, (16, 24, 24), 1e6)
+    # angles reach thousands of radians in fp32: allow one bf16 ulp of cos/sin (the table is bf16-rounded like the reference)
+    close(c, cr, 8e-3, rtol=0, what="mrope cos")
+    close(s, sr, 8e-3, rtol=0, what="mrope sin")
+    x = rnd(T, (nh + 2) * hd, seed=1)
+    for bwd in (False, True):
+        h = hip_ops.rope_apply(x.cuda(), nh, hd, cr.cuda(), sr.cuda(), backward=bwd)
+        r = ref_ops.rope_apply(x.float(), nh, hd, cr, sr, backward=bwd)
+        close(h, r, 0.02, what="mrope apply bwd=%s" % bwd)
+    # vision: head_dim 80
+    hw = torch.randint(0, 46, (90, 2), generator=g, dtype=torch.int32)
+    (c, s), (cr, sr) = hip_ops.vision_rope_table(hw.cuda(), 80), ref_ops.vision_rope_table(hw, 80)
+    close(c, cr, 1e-4, rtol=0, what="vision cos")
+    close(s, sr, 1e-4, rtol=0, what="vision sin")
+    x = rnd(90, 3 * 4 * 80, seed=2)
+    h = hip_ops.rope_apply(x.cuda(), 8, 80, cr.cuda(), sr.cuda())
+    r = ref_ops.rope_apply(x.float(), 8, 80, cr, sr)
+    close(h, r, 0.02, what="vision rope apply")
+
+
+def test_gather_scatter_embed(hip_ops, ref_ops):
+    table = rnd(50, 64, seed=1)
+    ids = torch.tensor([3, 49, 0, 3, 7, 7, 7], dtype=torch.int32)
+    h, r = hip_ops.gather_rows(table.cuda(), ids.cuda()), ref_ops.gather_rows(table.float(), ids)
+    assert torch.equal(h.float().cpu(), r)
+    dst_h, dst_r = torch.zeros(50, 64, dtype=BF16, device="cuda:0"), torch.zeros(50, 64)
+    src = rnd(3, 64, seed=2)
+    idx = torch.tensor([5, 1, 40], dtype=torch.int32)
+    hip_ops.scatter_rows(src.cuda(), idx.cuda(), dst_h)
+    ref_ops.scatter_rows(src.float(), idx, dst_r)
+    assert torch.equal(dst_h.float().cpu(), dst_r)
+    ids2 = torch.tensor([3, 49, -1, 3, 7, 7, 7], dtype=torch.int32)
+    dt_h, dt_r = torch.zeros(50, 64, device="cuda:0"), torch.zeros(50, 64)
+    dout = rnd(7, 64, seed=3)
+    hip_ops.embed_bwd(dout.cuda(), ids2.cuda(), dt_h)
+    ref_ops.embed_bwd(dout.float(), ids2, dt_r)
+    close(dt_h, dt_r, 1e-5, rtol=1e-5, what="embed bwd")
+
+
+# ------------------------------------------------------------------------------------------------------------- attention
+def masks_causal(T):
+    t = torch.arange(T, dtype=torch.int32)
+    return torch.zeros(T, dtype=torch.int32), torch.zeros(T, dtype=torch.int32), t
+
+
+def masks_prefix_shared(P, G, C):
+    """Packed sequence: P prompt tokens then G groups of C completion tokens; slot == token index."""
+    pre = torch.cat([torch.zeros(P), torch.full((G * C,), P)]).int()
+    lo = torch.cat([torch.zeros(P), (P + torch.arange(G).repeat_interleave(C) * C).float()]).int()
+    hi = torch.arange(P + G * C).int()
+    return pre, lo, hi
+
+
+def masks_segments(lengths):
+    lo, hi = [], []
+    a = 0
+    for n in lengths:
+        lo += [a] * n
+        hi += [a + n - 1] * n
+        a += n
+    return torch.zeros(a, dtype=torch.int32), torch.tensor(lo, dtype=torch.int32), torch.tensor(hi, dtype=torch.int32)
+
+
+ATT_CASES = [
+    ("causal", 4, 2, 128, masks_causal(200)),
+    ("causal-small-d", 4, 4, 32, masks_causal(77)),
+    ("prefix-shared", 6, 2, 64, masks_prefix_shared(70, 3, 37)),
+    ("prefix-shared-128", 14, 2, 128, masks_prefix_shared(150, 4, 21)),
+    ("vit-segments", 4, 4, 80, masks_segments([60, 60, 60, 45])),
+    ("windows", 2, 2, 80, masks_segments([16] * 9 + [4, 4, 7])),
+]
+
+
+@pytest.mark.parametrize("name,nh,nkv,hd,m", ATT_CASES, ids=[c[0] for c in ATT_CASES])
+def test_attention_fwd_bwd(hip_ops, ref_ops, name, nh, nkv, hd, m):
+    pre, lo, hi = m
+    T = pre.numel()
+    S = T
+    scale = hd ** -0.5
+    q, k, v, do = rnd(T, nh * hd, seed=1), rnd(S, nkv * hd, seed=2), rnd(S, nkv * hd, seed=3), rnd(T, nh * hd, seed=4)
+    vt_h = hip_ops.pack_transpose(v.cuda(), nkv, nkv, hd)
+    vt_r = ref_ops.pack_transpose(v.float(), nkv, nkv, hd)
+    assert torch.equal(vt_h.float().cpu(), vt_r), "pack_transpose must be exact"
+    o_h, lse_h = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, scale)
+    o_r, lse_r = ref_ops.attn_fwd(q.float(), k.float(), vt_r, pre, lo, hi, nh, nkv, S, hd, scale)
+    close(o_h, o_r, 0.02, what=name + " O")
+    close(lse_h, lse_r, 2e-3, rtol=1e-3, what=name + " lse")
+    # split-KV must agree with the single pass
+    o_s, lse_s = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, scale, nsplit=3)
+    close(o_s, o_r, 0.02, what=name + " O split")
+    close(lse_s, lse_r, 2e-3, rtol=1e-3, what=name + " lse split")
+    # backward (uses the oracle's O / lse so that only the backward kernels are under test)
+    dq_h, dk_h, dv_h = hip_ops.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o_r.to(BF16).cuda(), do.cuda(), lse_r.cuda(), pre.cuda(), lo.cuda(),
+                                        hi.cuda(), nh, nkv, S, hd, scale)
+    dq_r, dk_r, dv_r = ref_ops.attn_bwd(q.float(), k.float(), v.float(), o_r, do.float(), lse_r, pre, lo, hi, nh, nkv, S, hd, scale)
+    close(dq_h, dq_r, 0.03, rtol=3e-2, what=name + " dQ")
+    close(dk_h, dk_r, 0.03 * math.sqrt(nh // nkv) + 0.02, rtol=3e-2, what=name + " dK")
+    close(dv_h, dv_r, 0.03 * math.sqrt(nh // nkv) + 0.02, rtol=3e-2, what=name + " dV")
+
+
+def test_attention_decode_over_cache(hip_ops, ref_ops):
+    """G rollout rows, one new token each, over a KV cache = shared prompt prefix + per-row suffix slots (split-KV path)."""
+    P, G, C, step, nh, nkv, hd = 300, 8, 20, 11, 14, 2, 128
+    S = P + G * C
+    k, v, q = rnd(S, nkv * hd, seed=1), rnd(S, nkv * hd, seed=2), rnd(G, nh * hd, seed=3)
+    pre = torch.full((G,), P, dtype=torch.int32)
+    lo = (P + torch.arange(G) * C).int()
+    hi = (lo + step).int()
+    vt_h = hip_ops.pack_transpose(v.cuda(), nkv, nkv, hd)
+    vt_r = ref_ops.pack_transpose(v.float(), nkv, nkv, hd)
+    o_r, _ = ref_ops.attn_fwd(q.float(), k.float(), vt_r, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5)
+    for nsplit in (1, 4, 16):
+        o_h, _ = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, hd ** -0.5, nsplit=nsplit,
+                                  need_lse=False)
+        close(o_h, o_r, 0.02, what="decode attention nsplit=%d" % nsplit)
+
+
+def test_kv_cache_append(hip_ops, ref_ops):
+    nkv, hd, S = 2, 64, 256
+    newk = rnd(5, nkv * hd, seed=1)
+    slots = torch.tensor([7, 100, 101, 255, 0], dtype=torch.int32)
+    kc_h, kc_r = torch.zeros(S, nkv * hd, dtype=BF16, device="cuda:0"), torch.zeros(S, nkv * hd)
+    hip_ops.scatter_slots(newk.cuda(), kc_h, slots.cuda())
+    ref_ops.scatter_slots(newk.float(), kc_r, slots)
+    assert torch.equal(kc_h.float().cpu(), kc_r)
+    vt_h, vt_r = torch.zeros(nkv * hd, S, dtype=BF16, device="cuda:0"), torch.zeros(nkv * hd, S)
+    hip_ops.pack_transpose(newk.cuda(), nkv, nkv, hd, slots=slots.cuda(), out=vt_h)
+    ref_ops.pack_transpose(newk.float(), nkv, nkv, hd, slots=slots, out=vt_r)
+    assert torch.equal(vt_h.float().cpu(), vt_r)
+
+
+# ------------------------------------------------------------------------------------------------------- vocabulary side
+def test_logp_entropy(hip_ops, ref_ops):
+    R, V = 37, 5000 + 8
+    logits = rnd(R, V, seed=1, scale=3.0)
+    tg = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    (lp, en, ls), (lpr, enr, lsr) = hip_ops.logp_entropy_fwd(logits.cuda(), tg.cuda()), ref_ops.logp_entropy_fwd(logits.float(), tg)
+    close(lp, lpr, 1e-3, rtol=1e-4, what="logp")
+    close(en, enr, 1e-3, rtol=1e-4, what="entropy")
+    close(ls, lsr, 1e-3, rtol=1e-4, what="lse")
+    dlogp = torch.randn(R, generator=torch.Generator().manual_seed(3))
+    dh = hip_ops.logp_bwd(logits.cuda(), tg.cuda(), lsr.cuda(), dlogp.cuda(), inplace=False)
+    dr = ref_ops.logp_bwd(logits.float(), tg, lsr, dlogp, inplace=False)
+    close(dh, dr, 1e-3, rtol=1e-2, what="dlogits")
+
+
+@pytest.mark.parametrize("use_grpo,beta", [(True, 0.04), (False, 0.04), (True, 0.0), (False, 0.0)])
+def test_grpo_loss(hip_ops, ref_ops, use_grpo, beta):
+    G, C = 8, 50
+    g = torch.Generator().manual_seed(0)
+    logp = -torch.rand(G, C, generator=g) * 3
+    ref = (logp + 0.2 * torch.randn(G, C, generator=g)) if beta else None
+    lens = torch.randint(1, C + 1, (G,), generator=g)
+    mask = (torch.arange(C)[None, :] < lens[:, None]).int()
+    adv = torch.randn(G, generator=g)
+    outs_h = hip_ops.grpo_loss(logp.cuda(), ref.cuda() if ref is not None else None, mask.cuda(), adv.cuda(), beta, use_grpo, 0.5)
+    outs_r = ref_ops.grpo_loss(logp, ref, mask, adv, beta, use_grpo, 0.5)
+    for h, r, w in zip(outs_h, outs_r, ("dlogp", "out3", "row_len", "row_kl")):
+        close(h, r, 1e-5, rtol=1e-4, what="grpo " + w)
+
+
+def test_sampler(hip_ops, ref_ops):
+    rows, V, C = 8, 3000, 4
+    logits = rnd(rows, V, seed=1, scale=2.5)
+    for top_k in (0, 50):
+        tok_h = torch.zeros(rows, C, dtype=torch.int32, device="cuda:0")
+        tok_r = torch.zeros(rows, C, dtype=torch.int32)
+        u_h = torch.zeros(rows, device="cuda:0")
+        u_r = torch.zeros(rows)
+        step = torch.tensor([2], dtype=torch.int32)
+        hip_ops.sample_tokens(logits.cuda(), 0.9, top_k, 1234, step.cuda(), tok_h, None, 1, 0, False, u_out=u_h)
+        ref_ops.sample_tokens(logits.float(), 0.9, top_k, 1234, step, tok_r, None, 1, 0, False, u_out=u_r)
+        close(u_h, u_r, 1e-7, rtol=0, what="philox uniforms")  # integer RNG: must agree exactly
+        # the drawn token must be the inverse-CDF answer for that uniform (allowing fp slack at interval edges)
+        x = logits.float() / 0.9
+        for r in range(rows):
+            xr = x[r].double()
+            keep = xr >= (torch.topk(xr, top_k).values[-1] if top_k else -1e30)
+            p = torch.where(keep, (xr - xr.max()).exp(), torch.zeros_like(xr))
+            cdf = torch.cumsum(p, 0) / p.sum()
+            t = int(tok_h[r, 2])
+            assert keep[t], "sampled a filtered token"
+            lo_c = float(cdf[t - 1]) if t > 0 else 0.0
+            assert lo_c - 1e-4 <= float(u_r[r]) <= float(cdf[t]) + 1e-4, (r, t, lo_c, float(u_r[r]), float(cdf[t]))
+        assert (tok_h[:, [0, 1, 3]] == 0).all(), "only column *step is written"
+
+
+def test_adamw_and_clip(hip_ops, ref_ops):
+    n = 10007
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * 3 for _ in range(3)]
+    st_h = [p.clone().cuda(), torch.zeros(n, device="cuda:0"), torch.zeros(n, device="cuda:0"), None, torch.zeros(n, dtype=BF16, device="cuda:0")]
+    st_r = [p.clone(), torch.zeros(n), torch.zeros(n), None, torch.zeros(n, dtype=BF16)]
+    for step, gr in enumerate(grads, 1):
+        gh, grr = gr.clone().cuda(), gr.clone()
+        ss_h, ss_r = torch.zeros(1, device="cuda:0"), torch.zeros(1)
+        hip_ops.sumsq_accum(gh, ss_h)
+        ref_ops.sumsq_accum(grr, ss_r)
+        close(ss_h, ss_r, 0, rtol=1e-4, what="sumsq")
+        hip_ops.adamw_step(st_h[0], st_h[1], st_h[2], gh, st_h[4], 1e-3, 0.9, 0.999, 1e-8, 0.01, step, sumsq=ss_h, max_norm=1.0, grad_mult=0.5)
+        ref_ops.adamw_step(st_r[0], st_r[1], st_r[2], grr, st_r[4], 1e-3, 0.9, 0.999, 1e-8, 0.01, step, sumsq=ss_r, max_norm=1.0, grad_mult=0.5)
+        assert float(gh.abs().max()) == 0.0, "zero_grad"
+    close(st_h[0], st_r[0], 1e-6, rtol=1e-5, what="adamw master")
+    close(st_h[1], st_r[1], 1e-7, rtol=1e-4, what="adamw m")
+    close(st_h[2], st_r[2], 1e-9, rtol=1e-4, what="adamw v")
+    assert torch.equal(st_h[4].float().cpu(), st_h[0].to(BF16).float().cpu()), "bf16 copy = round(master)"
+    # and against torch.optim.AdamW itself (the DeepSpeed/HF default optimizer semantics)
+    pt = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for gr in grads:
+        pt.grad = gr.clone() * 0.5
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+    close(st_h[0], pt.detach(), 1e-6, rtol=1e-5, what="adamw vs torch.optim.AdamW")

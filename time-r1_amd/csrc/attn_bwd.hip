@@ -1,0 +1,334 @@
+// Attention backward: delta, dQ kernel (per query block, loops key tiles) and dK/dV kernel (per key block, loops query tiles).
+// Recompute-based (FlashAttention-2 style), no atomics. See attn_common.h for the mask model and MFMA orientation.
+//
+//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - delta),  dQ = scale * dS K,  dK = scale * dS^T Q,   delta = rowsum(dO o O)
+//
+// Gradient flow through the shared prompt prefix falls out of the mask: every completion row of every group sees the prefix
+// keys, so the dK/dV kernel accumulates all G suffixes' contributions into the single prefix K/V (hard part 1).
+#include "attn_common.h"
+
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, int64_t do_ld, const bf16_t* __restrict__ O, int64_t o_ld,
+                                  float* __restrict__ delta, int T, int n_heads, int d) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * n_heads) return;
+    const int t = (int)(i / n_heads), h = (int)(i - (int64_t)t * n_heads);
+    const bf16_t* a = dO + (int64_t)t * do_ld + (int64_t)h * d;
+    const bf16_t* b = O + (int64_t)t * o_ld + (int64_t)h * d;
+    float s = 0.f;
+    for (int c = 0; c < d; c += 8) {
+        const u32x4_t x = *reinterpret_cast<const u32x4_t*>(a + c), y = *reinterpret_cast<const u32x4_t*>(b + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += bflo(x[j]) * bflo(y[j]) + bfhi(x[j]) * bfhi(y[j]);
+    }
+    delta[(int64_t)h * T + t] = s;
+}
+
+// per 64 packed rows: (max pre, min lo, max hi) over rows with a non-empty [lo,hi]
+__global__ void attn_qmeta_kernel(const int* __restrict__ pre, const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta,
+                                  int T, int group) {
+    const int64_t R = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    int mp = 0, ml = 0x7fffffff, mh = -1;
+    if (R < (int64_t)T * group) {
+        const int t = (int)(R / group);
+        mp = pre[t];
+        if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { mp = max(mp, __shfl_xor(mp, o, 64)); ml = min(ml, __shfl_xor(ml, o, 64)); mh = max(mh, __shfl_xor(mh, o, 64)); }
+    if (threadIdx.x == 0) { qmeta[blockIdx.x * 3 + 0] = mp; qmeta[blockIdx.x * 3 + 1] = ml; qmeta[blockIdx.x * 3 + 2] = mh; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    constexpr int KSTR = 2 * D + 16;
+    __shared__ __attribute__((aligned(16))) char lds_k[ATT_KV * KSTR];
+    __shared__ __attribute__((aligned(16))) char lds_v[ATT_KV * KSTR];
+    __shared__ __attribute__((aligned(16))) char lds_kt[D * 144];
+    __shared__ int lds_meta[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    const int kvh = blockIdx.y;
+    const int64_t nR = (int64_t)p.T * p.group;
+    const int64_t R0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+    int tq[2], hq[2], pre[2], lo[2], hi[2]; bool valid[2];
+    float lse2[2], dlt[2];
+    int wmaxpre = 0, wminlo = 0x7fffffff, wmaxhi = -1;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int64_t R = R0 + cb * 16 + u;
+        valid[cb] = R < nR;
+        const int64_t Rc = valid[cb] ? R : nR - 1;
+        tq[cb] = (int)(Rc / p.group); hq[cb] = (int)(Rc - (int64_t)tq[cb] * p.group);
+        pre[cb] = valid[cb] ? p.pre[tq[cb]] : 0;
+        lo[cb] = valid[cb] ? p.lo[tq[cb]] : 1;
+        hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
+        if (valid[cb]) { wmaxpre = max(wmaxpre, pre[cb]); if (hi[cb] >= lo[cb]) { wminlo = min(wminlo, lo[cb]); wmaxhi = max(wmaxhi, hi[cb]); } }
+        const int64_t si = (int64_t)(kvh * p.group + hq[cb]) * p.T + tq[cb];
+        const float ls = valid[cb] ? p.lse[si] : NEG_INF;
+        lse2[cb] = (ls == NEG_INF) ? INFINITY : ls * 1.4426950408889634f;
+        dlt[cb] = valid[cb] ? p.delta[si] : 0.f;
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
+    }
+    if (lane == 0) { lds_meta[wave][0] = wmaxpre; lds_meta[wave][1] = wminlo; lds_meta[wave][2] = wmaxhi; }
+    __syncthreads();
+    int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w][0]); bminlo = min(bminlo, lds_meta[w][1]); bmaxhi = max(bmaxhi, lds_meta[w][2]); }
+    const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
+
+    bf16x8_t qf[2][D / 32], dof[2][D / 32];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int64_t hoff = (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
+        const bf16_t* qrow = p.Q + (int64_t)tq[cb] * p.q_ld + hoff;
+        const bf16_t* drow = p.dO + (int64_t)tq[cb] * p.do_ld + hoff;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+            qf[cb][ks] = load_row_frag(qrow, ks * 32 + g * 8, p.d_real, valid[cb]);
+            dof[cb][ks] = load_row_frag(drow, ks * 32 + g * 8, p.d_real, valid[cb]);
+        }
+    }
+    f32x4_t dq[D / 16][2];
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) { dq[dt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dq[dt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int i = 0; i < tr.n_rel; ++i) {
+        const int kv0 = att_tile_at(tr, i) * ATT_KV;
+        __syncthreads();
+        stage_rows<D, ATT_KV>(lds_k, p.K, p.k_ld, (int64_t)kvh * p.d_real, kv0, p.n_slots, p.d_real);
+        stage_rows<D, ATT_KV>(lds_v, p.V, p.v_ld, (int64_t)kvh * p.d_real, kv0, p.n_slots, p.d_real);
+        stage_T<D>(lds_kt, p.KT, p.kt_ld, kvh, kv0, p.n_slots, p.d_real);
+        __syncthreads();
+        f32x4_t s[4][2], dp[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) { s[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(lds_v + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    s[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[cb][ks], s[kt][cb], 0, 0, 0);
+                    dp[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[cb][ks], dp[kt][cb], 0, 0, 0);
+                }
+            }
+        }
+        bf16x8_t dsf[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kv = kv0 + kt * 16 + g * 4 + r;
+                    const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
+                    const float pr = ok ? exp2f(s[kt][cb][r] * p.scale_log2 - lse2[cb]) : 0.f;
+                    s[kt][cb][r] = pr * (dp[kt][cb][r] - dlt[cb]);
+                }
+            dsf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
+            dsf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const char* base = lds_kt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
+                const bf16x8_t ktf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
+                dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][0], dq[dt][0], 0, 0, 0);
+                dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][1], dq[dt][1], 0, 0, 0);
+            }
+        }
+    }
+    const float scale = p.scale_log2 * 0.6931471805599453f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (!valid[cb]) continue;
+        bf16_t* row = p.dQ + (int64_t)tq[cb] * p.dq_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d < p.d_real) {
+                u32x2_t w = {pack2bf(dq[dt][cb][0] * scale, dq[dt][cb][1] * scale), pack2bf(dq[dt][cb][2] * scale, dq[dt][cb][3] * scale)};
+                *reinterpret_cast<u32x2_t*>(row + d) = w;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------- dK/dV
+// Block = 64 keys of one kv head; wave owns 16 of them (K/V fragments stay in registers), loops over 64-row query tiles.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles) {
+    constexpr int KSTR = 2 * D + 16;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    char* lds_q = dyn_lds;                       // [64][KSTR]   Q rows (packed)
+    char* lds_do = lds_q + 64 * KSTR;            // [64][KSTR]   dO rows
+    char* lds_qt = lds_do + 64 * KSTR;           // [D][144]     Q^T
+    char* lds_dot = lds_qt + D * 144;            // [D][144]     dO^T
+    float* lds_lse = reinterpret_cast<float*>(lds_dot + D * 144);   // [64]
+    float* lds_dlt = lds_lse + 64;                                   // [64]
+    int* lds_pre = reinterpret_cast<int*>(lds_dlt + 64);            // [64] x3
+    int* lds_lo = lds_pre + 64;
+    int* lds_hi = lds_lo + 64;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    const int kvh = blockIdx.y;
+    const int kvb0 = blockIdx.x * ATT_KV;
+    const int kv = kvb0 + wave * 16 + u;
+    const bool kv_ok = kv < p.n_slots;
+    const int64_t nR = (int64_t)p.T * p.group;
+
+    bf16x8_t kf[D / 32], vf[D / 32];
+    {
+        const bf16_t* krow = p.K + (int64_t)(kv_ok ? kv : 0) * p.k_ld + (int64_t)kvh * p.d_real;
+        const bf16_t* vrow = p.V + (int64_t)(kv_ok ? kv : 0) * p.v_ld + (int64_t)kvh * p.d_real;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+            kf[ks] = load_row_frag(krow, ks * 32 + g * 8, p.d_real, kv_ok);
+            vf[ks] = load_row_frag(vrow, ks * 32 + g * 8, p.d_real, kv_ok);
+        }
+    }
+    f32x4_t dk[D / 16], dv[D / 16];
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int qi = 0; qi < n_qtiles; ++qi) {
+        const int mp = p.qmeta[qi * 3], ml = p.qmeta[qi * 3 + 1], mh = p.qmeta[qi * 3 + 2];
+        const bool rel = (kvb0 < mp) || (kvb0 + ATT_KV - 1 >= ml && kvb0 <= mh);
+        if (!rel) continue;  // block-uniform
+        const int64_t Rq0 = (int64_t)qi * 64;
+        __syncthreads();
+        stage_packed_rows<D, 64>(lds_q, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
+        stage_packed_rows<D, 64>(lds_do, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
+        stage_T<D>(lds_qt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
+        stage_T<D>(lds_dot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
+        if (threadIdx.x < 64) {
+            const int64_t R = Rq0 + threadIdx.x;
+            float ls = INFINITY, dl = 0.f; int a = 0, b = 1, c = 0;
+            if (R < nR) {
+                const int t = (int)(R / p.group), hq = (int)(R - (int64_t)t * p.group);
+                const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + t;
+                const float l0 = p.lse[si];
+                ls = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
+                dl = p.delta[si]; a = p.pre[t]; b = p.lo[t]; c = p.hi[t];
+            }
+            lds_lse[threadIdx.x] = ls; lds_dlt[threadIdx.x] = dl; lds_pre[threadIdx.x] = a; lds_lo[threadIdx.x] = b; lds_hi[threadIdx.x] = c;
+        }
+        __syncthreads();
+
+        f32x4_t s[4], dp[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) { s[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(lds_q + (qt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(lds_do + (qt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], s[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp[qt], 0, 0, 0);
+            }
+        }
+        // lane holds S[q = qt*16 + g*4 + r][kv = u-th key of this wave]
+        f32x4_t pr[4], ds[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = qt * 16 + g * 4 + r;
+                const bool ok = kv_ok && att_visible(kv, lds_pre[ql], lds_lo[ql], lds_hi[ql]);
+                const float pv = ok ? exp2f(s[qt][r] * p.scale_log2 - lds_lse[ql]) : 0.f;
+                pr[qt][r] = pv; ds[qt][r] = pv * (dp[qt][r] - lds_dlt[ql]);
+            }
+        const bf16x8_t pf0 = pack_frag(pr[0], pr[1]), pf1 = pack_frag(pr[2], pr[3]);
+        const bf16x8_t df0 = pack_frag(ds[0], ds[1]), df1 = pack_frag(ds[2], ds[3]);
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            const char* bq = lds_qt + (dt * 16 + u) * 144 + g * 8;
+            const char* bo = lds_dot + (dt * 16 + u) * 144 + g * 8;
+            const bf16x8_t q0 = make_frag(*reinterpret_cast<const u32x2_t*>(bq), *reinterpret_cast<const u32x2_t*>(bq + 32));
+            const bf16x8_t q1 = make_frag(*reinterpret_cast<const u32x2_t*>(bq + 64), *reinterpret_cast<const u32x2_t*>(bq + 96));
+            const bf16x8_t o0 = make_frag(*reinterpret_cast<const u32x2_t*>(bo), *reinterpret_cast<const u32x2_t*>(bo + 32));
+            const bf16x8_t o1 = make_frag(*reinterpret_cast<const u32x2_t*>(bo + 64), *reinterpret_cast<const u32x2_t*>(bo + 96));
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[dt], 0, 0, 0);
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0, dk[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
+        }
+    }
+    // lane holds dK^T/dV^T[d = dt*16 + g*4 + r][kv]
+    if (kv_ok) {
+        const float scale = p.scale_log2 * 0.6931471805599453f;
+        bf16_t* kr = p.dK + (int64_t)kv * p.dk_ld + (int64_t)kvh * p.d_real;
+        bf16_t* vr = p.dV + (int64_t)kv * p.dv_ld + (int64_t)kvh * p.d_real;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d < p.d_real) {
+                u32x2_t wk = {pack2bf(dk[dt][0] * scale, dk[dt][1] * scale), pack2bf(dk[dt][2] * scale, dk[dt][3] * scale)};
+                u32x2_t wv = {pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
+                *reinterpret_cast<u32x2_t*>(kr + d) = wk;
+                *reinterpret_cast<u32x2_t*>(vr + d) = wv;
+            }
+        }
+    }
+}
+
+template <int D>
+static int launch_bwd(const AttnParams& p, hipStream_t s) {
+    const int64_t nR = (int64_t)p.T * p.group;
+    const int n_qtiles = (int)((nR + 63) / 64);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), 0, s, p);
+    const size_t dyn = 2 * 64 * (2 * D + 16) + 2 * D * 144 + 64 * 5 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<D>, dim3((unsigned)((p.n_slots + ATT_KV - 1) / ATT_KV), p.n_kv), dim3(256), dyn, s, p, n_qtiles);
+    return 0;
+}
+
+// Workspace (ints): qmeta needs 3*ceil(T*group/64). delta is caller-provided fp32 [n_heads*T].
+extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
+                            int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
+                            const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,
+                            void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, int64_t T,
+                            int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream) {
+    AttnParams p; memset(&p, 0, sizeof(p));
+    TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention bwd: n_heads must be a multiple of n_kv");
+    p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.V = (const bf16_t*)V; p.v_ld = v_ld;
+    p.KT = (const bf16_t*)KT; p.kt_ld = kt_ld; p.QT = (const bf16_t*)QT; p.qt_ld = qt_ld; p.dOT = (const bf16_t*)dOT; p.dot_ld = dot_ld;
+    p.dO = (const bf16_t*)dO; p.do_ld = do_ld; p.dQ = (bf16_t*)dQ; p.dq_ld = dq_ld; p.dK = (bf16_t*)dK; p.dk_ld = dk_ld;
+    p.dV = (bf16_t*)dV; p.dv_ld = dv_ld; p.lse = (float*)lse; p.delta = (float*)delta; p.pre = (const int*)pre; p.lo = (const int*)lo;
+    p.hi = (const int*)hi; p.qmeta = (const int*)qmeta_ws;
+    p.T = (int)T; p.group = (int)(n_heads / n_kv); p.n_kv = (int)n_kv; p.n_slots = (int)n_slots; p.d_real = (int)head_dim; p.nsplit = 1;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    const int d_pad = (int)((head_dim + 31) / 32 * 32);
+    TR1_CHECK_ARG(d_pad == 32 || d_pad == 64 || d_pad == 96 || d_pad == 128, "attention bwd: padded head dim must be 32/64/96/128");
+    TR1_CHECK_ARG(head_dim % 8 == 0 && q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && do_ld % 8 == 0 && o_ld % 8 == 0,
+                  "attention bwd: dims must be multiples of 8");
+    TR1_CHECK_ARG(kt_ld % 8 == 0 && kt_ld >= n_slots && qt_ld % 8 == 0 && qt_ld >= T * p.group && dot_ld % 8 == 0 && dot_ld >= T * p.group,
+                  "attention bwd: transposed leading dims too small");
+    if (T == 0 || n_slots == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T * n_heads + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dO, do_ld,
+                       (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim);
+    const int n_qtiles = (int)((T * p.group + 63) / 64);
+    hipLaunchKernelGGL(attn_qmeta_kernel, dim3(n_qtiles), dim3(64), 0, s, p.pre, p.lo, p.hi, (int*)qmeta_ws, (int)T, p.group);
+    switch (d_pad) {
+        case 32: launch_bwd<32>(p, s); break;
+        case 64: launch_bwd<64>(p, s); break;
+        case 96: launch_bwd<96>(p, s); break;
+        default: launch_bwd<128>(p, s); break;
+    }
+    TR1_LAUNCH_CHECK();
+}

@@ -1,0 +1,132 @@
+// Shared pieces of the attention kernels (gfx950).
+//
+// One kernel family serves every attention in the GRPO path:
+//   * LLM causal GQA attention with ONE shared prompt prefix and G completion suffixes (training forward/backward,
+//     rollout prefill, and - through split-KV - single-token decode over the KV cache);
+//   * ViT varlen non-causal attention over cu_seqlens segments (Qwen2-VL frames, Qwen2.5-VL windows).
+// The mask is "two intervals per query token":   key kv is visible to token t  iff
+//        kv < pre[t]   or   lo[t] <= kv <= hi[t]
+// (prompt token: pre=0, lo=0, hi=t;  completion token of group g at step s: pre=P, lo=P+g*C, hi=P+g*C+s;
+//  ViT token in segment [a,b): pre=0, lo=a, hi=b-1).  Reference semantics: flash_attn_varlen_func / SDPA as called from
+//  transformers/models/qwen2_vl/modeling_qwen2_vl.py:379-396 (vision) and :521-556 (LLM, softmax in fp32, GQA by repeat).
+//
+// Query rows are "GQA packed": row R = t*group + hq enumerates the `group` query heads that share kv head `kvh`, so a
+// K/V tile staged in LDS is reused by all of them and decode (T = G rollout rows) still fills MFMA columns.
+//
+// MFMA orientation trick used throughout: scores are computed TRANSPOSED, S^T[kv][q] = K * Q^T, so that after
+// v_mfma_f32_16x16x32_bf16 a lane holds, for ITS query column q = lane&15, the four keys kv = (lane>>4)*4 + r.
+// Row statistics (max, sum, lse, delta) are then lane-local, and two S^T tiles concatenate into a legal B operand
+// (k-slot (g,j): j<4 -> tile0 key g*4+j, j>=4 -> tile1 key g*4+j-4) for O^T = V^T * P^T with V^T read as 8-byte pairs.
+#pragma once
+#include "tr1_common.h"
+
+struct AttnParams {
+    const bf16_t* Q;  int64_t q_ld;    // [T, n_heads*d]   (row = token)
+    const bf16_t* K;  int64_t k_ld;    // [slots, n_kv*d]  (row = kv slot)
+    const bf16_t* V;  int64_t v_ld;    // [slots, n_kv*d]
+    const bf16_t* KT; int64_t kt_ld;   // [n_kv*d, slots_pad]  (transposed copies, slot-contiguous)
+    const bf16_t* VT; int64_t vt_ld;
+    const bf16_t* QT; int64_t qt_ld;   // [n_kv*d, T*group padded]  (packed-row-contiguous)
+    const bf16_t* dOT; int64_t dot_ld;
+    bf16_t* O;        int64_t o_ld;    // [T, n_heads*d]
+    const bf16_t* dO; int64_t do_ld;
+    bf16_t* dQ;       int64_t dq_ld;
+    bf16_t* dK;       int64_t dk_ld;   // [slots, n_kv*d]
+    bf16_t* dV;       int64_t dv_ld;
+    float* lse;                        // [n_heads, T] natural-log LSE of the scaled scores
+    float* delta;                      // [n_heads, T] rowsum(dO*O)
+    const int* pre; const int* lo; const int* hi;   // [T]
+    const int* qmeta;                  // [n_qtiles64, 3] (max pre, min lo, max hi) per 64 packed rows (backward only)
+    float* Opart; float* mpart; float* lpart;       // split-KV workspaces
+    int T, group, n_kv, n_slots, d_real, nsplit;
+    float scale_log2;                  // softmax scale * log2(e)
+};
+
+#define ATT_KV 64          // keys per tile
+#define NEG_INF (-INFINITY)
+
+TR1_DEV bf16x8_t make_frag(u32x2_t a, u32x2_t b) {
+    u32x4_t w = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+TR1_DEV bf16x8_t pack_frag(f32x4_t a, f32x4_t b) {
+    u32x4_t w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+TR1_DEV bf16x8_t zero_frag() { u32x4_t w = {0, 0, 0, 0}; return __builtin_bit_cast(bf16x8_t, w); }
+
+// 16-byte global load of 8 bf16 at column d0 of a row, zero beyond d_real / invalid row
+TR1_DEV bf16x8_t load_row_frag(const bf16_t* row_ptr, int d0, int d_real, bool valid) {
+    if (valid && d0 < d_real) return *reinterpret_cast<const bf16x8_t*>(row_ptr + d0);
+    return zero_frag();
+}
+
+// Stage `NROWS` rows x D columns (row-major source) into LDS with a (2*D+16)-byte row stride (conflict-free b128 column reads).
+// Row r of the tile is source row (row0 + r); rows >= nvalid and columns >= d_real are zero-filled.
+template <int D, int NROWS>
+TR1_DEV void stage_rows(char* lds, const bf16_t* src, int64_t ld, int64_t col0, int64_t row0, int64_t nvalid, int d_real) {
+    constexpr int CH = D / 8;
+    constexpr int STRIDE = 2 * D + 16;
+    for (int idx = threadIdx.x; idx < NROWS * CH; idx += 256) {
+        const int r = idx / CH, c = idx - r * CH;
+        u32x4_t v = {0, 0, 0, 0};
+        const int64_t row = row0 + r;
+        if (row < nvalid && c * 8 < d_real) v = *reinterpret_cast<const u32x4_t*>(src + row * ld + col0 + c * 8);
+        *reinterpret_cast<u32x4_t*>(lds + r * STRIDE + c * 16) = v;
+    }
+}
+// Same, but the tile rows are GQA-packed query rows R = R0 + r  ->  token R/group, head R%group.
+template <int D, int NROWS>
+TR1_DEV void stage_packed_rows(char* lds, const bf16_t* src, int64_t ld, int kvh, int group, int64_t R0, int64_t nR, int d_real) {
+    constexpr int CH = D / 8;
+    constexpr int STRIDE = 2 * D + 16;
+    for (int idx = threadIdx.x; idx < NROWS * CH; idx += 256) {
+        const int r = idx / CH, c = idx - r * CH;
+        u32x4_t v = {0, 0, 0, 0};
+        const int64_t R = R0 + r;
+        if (R < nR && c * 8 < d_real) {
+            const int64_t t = R / group; const int hq = (int)(R - t * group);
+            v = *reinterpret_cast<const u32x4_t*>(src + t * ld + (int64_t)(kvh * group + hq) * d_real + c * 8);
+        }
+        *reinterpret_cast<u32x4_t*>(lds + r * STRIDE + c * 16) = v;
+    }
+}
+// Stage a transposed tile: D rows (feature d) x 64 columns (slot / packed row), source is [n_kv*d_real, ldT] with the
+// column index contiguous. LDS row stride 144 bytes. Columns >= nvalid and rows >= d_real are zero-filled.
+template <int D>
+TR1_DEV void stage_T(char* lds, const bf16_t* srcT, int64_t ldT, int kvh, int64_t col0, int64_t nvalid, int d_real) {
+    for (int idx = threadIdx.x; idx < D * 8; idx += 256) {
+        const int d = idx >> 3, c = idx & 7;
+        u32x4_t v = {0, 0, 0, 0};
+        const int64_t col = col0 + c * 8;
+        if (d < d_real && col < nvalid) {
+            v = *reinterpret_cast<const u32x4_t*>(srcT + ((int64_t)kvh * d_real + d) * ldT + col);
+            if (col + 8 > nvalid) {  // ragged tail: keep only the valid columns (stale cache slots must not leak)
+                const int keep = (int)(nvalid - col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (2 * e >= keep) v[e] = 0;
+                    else if (2 * e + 1 >= keep) v[e] &= 0xffffu;
+                }
+            }
+        }
+        *reinterpret_cast<u32x4_t*>(lds + d * 144 + c * 16) = v;
+    }
+}
+
+TR1_DEV bool att_visible(int kv, int pre, int lo, int hi) { return (kv < pre) || (kv >= lo && kv <= hi); }
+
+// Which 64-key tiles can a set of rows with (max_pre, min_lo, max_hi) see?  [0, pre_tiles) U [start2, end2]
+struct TileRange { int pre_tiles, start2, n_rel; };
+TR1_DEV TileRange att_tile_range(int max_pre, int min_lo, int max_hi, int n_slots) {
+    TileRange tr;
+    if (max_pre > n_slots) max_pre = n_slots;
+    if (max_hi >= n_slots) max_hi = n_slots - 1;
+    tr.pre_tiles = (max_pre + ATT_KV - 1) / ATT_KV;
+    int s2 = min_lo / ATT_KV; if (s2 < tr.pre_tiles) s2 = tr.pre_tiles;
+    const int e2 = (max_hi >= 0) ? max_hi / ATT_KV : -1;
+    tr.start2 = s2;
+    tr.n_rel = tr.pre_tiles + ((max_hi >= min_lo && e2 >= s2) ? (e2 - s2 + 1) : 0);
+    return tr;
+}
+TR1_DEV int att_tile_at(const TileRange& tr, int i) { return i < tr.pre_tiles ? i : tr.start2 + (i - tr.pre_tiles); }

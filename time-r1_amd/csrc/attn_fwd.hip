@@ -1,0 +1,293 @@
+// Attention forward (flash style, online softmax) + split-KV combine + layout helpers. See attn_common.h for the design.
+#include "attn_common.h"
+
+// Block: 256 threads = 4 waves; wave owns 32 packed query rows (two 16-column blocks); block = 128 packed rows.
+// grid = (ceil(T*group/128), n_kv, nsplit)
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    constexpr int KSTR = 2 * D + 16;
+    __shared__ __attribute__((aligned(16))) char lds_k[ATT_KV * KSTR];
+    __shared__ __attribute__((aligned(16))) char lds_vt[D * 144];
+    __shared__ int lds_meta[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    const int kvh = blockIdx.y, split = blockIdx.z;
+    const int64_t nR = (int64_t)p.T * p.group;
+    const int64_t R0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+    int tq[2], hq[2], pre[2], lo[2], hi[2]; bool valid[2];
+    int wmaxpre = 0, wminlo = 0x7fffffff, wmaxhi = -1;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int64_t R = R0 + cb * 16 + u;
+        valid[cb] = R < nR;
+        const int64_t Rc = valid[cb] ? R : nR - 1;
+        tq[cb] = (int)(Rc / p.group); hq[cb] = (int)(Rc - (int64_t)tq[cb] * p.group);
+        pre[cb] = valid[cb] ? p.pre[tq[cb]] : 0;
+        lo[cb] = valid[cb] ? p.lo[tq[cb]] : 1;
+        hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
+        if (valid[cb]) { wmaxpre = max(wmaxpre, pre[cb]); if (hi[cb] >= lo[cb]) { wminlo = min(wminlo, lo[cb]); wmaxhi = max(wmaxhi, hi[cb]); } }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
+    }
+    if (lane == 0) { lds_meta[wave][0] = wmaxpre; lds_meta[wave][1] = wminlo; lds_meta[wave][2] = wmaxhi; }
+    __syncthreads();
+    int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w][0]); bminlo = min(bminlo, lds_meta[w][1]); bmaxhi = max(bmaxhi, lds_meta[w][2]); }
+    const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
+
+    // Q fragments (B operand): Q[q = u][d = ks*32 + g*8 .. +8]
+    bf16x8_t qf[2][D / 32];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const bf16_t* qrow = p.Q + (int64_t)tq[cb] * p.q_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) qf[cb][ks] = load_row_frag(qrow, ks * 32 + g * 8, p.d_real, valid[cb]);
+    }
+
+    f32x4_t o[D / 16][2];
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) { o[dt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; o[dt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    float m[2] = {NEG_INF, NEG_INF}, l[2] = {0.f, 0.f};
+
+    for (int i = split; i < tr.n_rel; i += p.nsplit) {
+        const int kv0 = att_tile_at(tr, i) * ATT_KV;
+        __syncthreads();
+        stage_rows<D, ATT_KV>(lds_k, p.K, p.k_ld, (int64_t)kvh * p.d_real, kv0, p.n_slots, p.d_real);
+        stage_T<D>(lds_vt, p.VT, p.vt_ld, kvh, kv0, p.n_slots, p.d_real);
+        __syncthreads();
+
+        f32x4_t s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; s[kt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+                s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+                s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+            }
+        }
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float mx = NEG_INF;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kv = kv0 + kt * 16 + g * 4 + r;
+                    const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
+                    const float v = ok ? s[kt][cb][r] * p.scale_log2 : NEG_INF;
+                    s[kt][cb][r] = v; mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[cb], mx);
+            const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+            const float alpha = exp2f(m[cb] - m_safe);
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][cb][r] - m_safe); s[kt][cb][r] = e; rs += e; }
+            rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
+            l[cb] = l[cb] * alpha + rs; m[cb] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) o[dt][cb] *= alpha;
+            pf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
+            pf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const char* base = lds_vt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
+                const bf16x8_t vf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
+                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][0], o[dt][0], 0, 0, 0);
+                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][1], o[dt][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue. Lane holds O^T[d = dt*16 + g*4 + r][q = u].
+    if (p.nsplit == 1) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (!valid[cb]) continue;
+            const float inv = l[cb] > 0.f ? 1.f / l[cb] : 0.f;
+            bf16_t* orow = p.O + (int64_t)tq[cb] * p.o_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < p.d_real) {
+                    u32x2_t w = {pack2bf(o[dt][cb][0] * inv, o[dt][cb][1] * inv), pack2bf(o[dt][cb][2] * inv, o[dt][cb][3] * inv)};
+                    *reinterpret_cast<u32x2_t*>(orow + d) = w;
+                }
+            }
+            if (g == 0 && p.lse)
+                p.lse[(int64_t)(kvh * p.group + hq[cb]) * p.T + tq[cb]] = l[cb] > 0.f ? (m[cb] + log2f(l[cb])) * 0.6931471805599453f : NEG_INF;
+        }
+    } else {
+        const int64_t nRpad = (int64_t)gridDim.x * 128;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int64_t R = R0 + cb * 16 + u;
+            const int64_t slot = ((int64_t)split * p.n_kv + kvh) * nRpad + R;
+            float* op = p.Opart + slot * D;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4_t*>(op + dt * 16 + g * 4) = o[dt][cb];
+            if (g == 0) { p.mpart[slot] = m[cb]; p.lpart[slot] = l[cb]; }
+        }
+    }
+}
+
+// Merge split-KV partials: one thread per (packed row, 4 features).
+template <int D>
+__global__ void attn_combine_kernel(AttnParams p, int64_t nRpad) {
+    const int64_t nR = (int64_t)p.T * p.group;
+    const int kvh = blockIdx.y;
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t R = idx / (D / 4); const int d = (int)(idx - R * (D / 4)) * 4;
+    if (R >= nR) return;
+    float M = NEG_INF;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.mpart[((int64_t)s * p.n_kv + kvh) * nRpad + R]);
+    const float Ms = (M == NEG_INF) ? 0.f : M;
+    float L = 0.f; f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.nsplit; ++s) {
+        const int64_t slot = ((int64_t)s * p.n_kv + kvh) * nRpad + R;
+        const float w = exp2f(p.mpart[slot] - Ms);
+        L += w * p.lpart[slot];
+        acc += w * *reinterpret_cast<const f32x4_t*>(p.Opart + slot * D + d);
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    const int64_t t = R / p.group; const int hq = (int)(R - t * p.group);
+    if (d < p.d_real) {
+        u32x2_t w = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
+        *reinterpret_cast<u32x2_t*>(p.O + t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real + d) = w;
+    }
+    if (d == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
+}
+
+// out[(kvh*d + dd) * ld_out + t*group + hq] = in[t*ld_in + (kvh*group + hq)*d + dd] ; columns [T*group, ld_out) zero-filled
+// when zero_pad != 0. With group = 1 this is the K^T / V^T builder (optionally through a slot map: column = slots[t]).
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
+                                                             int64_t ld_out, const int* __restrict__ slots, int64_t T, int n_kv, int group,
+                                                             int d, int zero_pad) {
+    __shared__ bf16_t tile[64][66];
+    const int kvh = blockIdx.z;
+    const int64_t nR = T * group;
+    const int64_t R0 = (int64_t)blockIdx.y * 64; const int d0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t R = R0 + ty + i * 4; const int dd = d0 + tx;
+        bf16_t v = 0;
+        if (R < nR && dd < d) { const int64_t t = R / group; const int hq = (int)(R - t * group); v = in[t * ld_in + (int64_t)(kvh * group + hq) * d + dd]; }
+        tile[ty + i * 4][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int dd = d0 + ty + i * 4; const int64_t R = R0 + tx;
+        if (dd >= d) continue;
+        if (R < nR) {
+            const int64_t col = slots ? (int64_t)slots[R] : R;
+            out[((int64_t)kvh * d + dd) * ld_out + col] = tile[tx][ty + i * 4];
+        } else if (zero_pad && R < ld_out && !slots) {
+            out[((int64_t)kvh * d + dd) * ld_out + R] = 0;
+        }
+    }
+}
+
+// rows of `src` [T, cols] -> dst[slots[t], :]   (KV-cache append; 16 bytes per lane)
+__global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_src, bf16_t* __restrict__ dst, int64_t ld_dst,
+                                     const int* __restrict__ slots, int64_t T, int cols) {
+    const int nch = cols >> 3;
+    const int64_t total = T * nch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / nch; const int c = (int)(i - t * nch);
+        *reinterpret_cast<u32x4_t*>(dst + (int64_t)slots[t] * ld_dst + c * 8) = *reinterpret_cast<const u32x4_t*>(src + t * ld_src + c * 8);
+    }
+}
+
+static int attn_check(const AttnParams& p, int d_pad) {
+    TR1_CHECK_ARG(d_pad == 32 || d_pad == 64 || d_pad == 96 || d_pad == 128, "attention: padded head dim must be 32/64/96/128");
+    TR1_CHECK_ARG(p.d_real % 8 == 0 && p.d_real <= d_pad && p.d_real > d_pad - 32, "attention: head dim must be a multiple of 8");
+    TR1_CHECK_ARG(p.q_ld % 8 == 0 && p.k_ld % 8 == 0 && p.o_ld % 4 == 0, "attention: leading dims must be multiples of 8");
+    TR1_CHECK_ARG(p.group >= 1 && p.n_kv >= 1 && p.nsplit >= 1, "attention: bad group/n_kv/nsplit");
+    return 0;
+}
+
+extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
+                            void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
+                            int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, void* stream) {
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.VT = (const bf16_t*)VT; p.vt_ld = vt_ld;
+    p.O = (bf16_t*)O; p.o_ld = o_ld; p.lse = (float*)lse; p.pre = (const int*)pre; p.lo = (const int*)lo; p.hi = (const int*)hi;
+    TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention: n_heads must be a multiple of n_kv");
+    p.T = (int)T; p.group = (int)(n_heads / n_kv); p.n_kv = (int)n_kv; p.n_slots = (int)n_slots; p.d_real = (int)head_dim; p.nsplit = (int)nsplit;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    const int d_pad = (int)((head_dim + 31) / 32 * 32);
+    if (int e = attn_check(p, d_pad)) return e;
+    TR1_CHECK_ARG(vt_ld % 8 == 0 && vt_ld >= n_slots, "attention: vt_ld must be a multiple of 8 and >= n_slots");
+    if (T == 0) return 0;
+    const int64_t nR = T * p.group;
+    const int qtiles = (int)((nR + 127) / 128);
+    const int64_t nRpad = (int64_t)qtiles * 128;
+    if (nsplit > 1) {
+        const int64_t need = nsplit * n_kv * nRpad * (d_pad + 2);
+        TR1_CHECK_ARG(ws_f32 && ws_floats >= need, "attention: split-KV workspace too small");
+        p.Opart = (float*)ws_f32; p.mpart = p.Opart + nsplit * n_kv * nRpad * d_pad; p.lpart = p.mpart + nsplit * n_kv * nRpad;
+    }
+    dim3 grid(qtiles, (unsigned)n_kv, (unsigned)nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    switch (d_pad) {
+        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, s, p); break;
+        case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, s, p); break;
+        case 96: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, s, p); break;
+    }
+    if (nsplit > 1) {
+        dim3 cg((unsigned)((nR * (d_pad / 4) + 255) / 256), (unsigned)n_kv);
+        switch (d_pad) {
+            case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;
+            case 64: hipLaunchKernelGGL(attn_combine_kernel<64>, cg, dim3(256), 0, s, p, nRpad); break;
+            case 96: hipLaunchKernelGGL(attn_combine_kernel<96>, cg, dim3(256), 0, s, p, nRpad); break;
+            default: hipLaunchKernelGGL(attn_combine_kernel<128>, cg, dim3(256), 0, s, p, nRpad); break;
+        }
+    }
+    TR1_LAUNCH_CHECK();
+}
+
+extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit) {
+    if (nsplit <= 1 || n_kv <= 0) return 0;
+    const int64_t nR = T * (n_heads / n_kv);
+    const int64_t nRpad = (nR + 127) / 128 * 128;
+    const int64_t d_pad = (head_dim + 31) / 32 * 32;
+    return nsplit * n_kv * nRpad * (d_pad + 2);
+}
+
+extern "C" int tr1_pack_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* slots, int64_t T, int64_t n_heads,
+                                  int64_t n_kv, int64_t head_dim, int zero_pad, void* stream) {
+    TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "pack_transpose: n_heads must be a multiple of n_kv");
+    const int group = (int)(n_heads / n_kv);
+    TR1_CHECK_ARG(slots || ld_out >= T * group, "pack_transpose: ld_out too small");
+    if (T == 0) return 0;
+    const int64_t span = (zero_pad && !slots) ? ld_out : T * group;
+    dim3 grid((unsigned)((head_dim + 63) / 64), (unsigned)((span + 63) / 64), (unsigned)n_kv);
+    hipLaunchKernelGGL(pack_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out,
+                       (const int*)slots, T, (int)n_kv, group, (int)head_dim, zero_pad);
+    TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const void* slots, int64_t T, int64_t cols,
+                                 void* stream) {
+    TR1_CHECK_ARG(cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "scatter_slots: cols/ld must be multiples of 8");
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(scatter_slots_kernel, dim3(tr1_grid_1d(T * cols / 8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       ld_src, (bf16_t*)dst, ld_dst, (const int*)slots, T, (int)cols);
+    TR1_LAUNCH_CHECK();
+}

@@ -1,0 +1,248 @@
+// bf16 GEMM for gfx950 (CDNA4): C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (+ residual[M,N]), fp32 accumulate on MFMA.
+//
+// This is the projection workhorse behind every Linear in the GRPO path (reference call sites: the cuBLAS GEMMs under
+// transformers/models/qwen2_vl/modeling_qwen2_vl.py:501-504 (q/k/v/o), :459-466 (MLP), :251-274 (patch embed as GEMM),
+// :277-290 (patch merger), :1323 (lm_head)).  Both operands are K-contiguous ("NT"), which is what nn.Linear stores.
+//
+// Design (MI355X-first, see /opt/skills/guides/cdna_hip_programming.md section 5):
+//   * 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave owns 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+//   * operands go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip), two LDS buffers,
+//     one __syncthreads per K-tile (the barrier's vmcnt(0) retires the DMA issued one iteration earlier).
+//   * the LDS image is lane-linear per DMA instruction, so the bank-conflict swizzle is applied on the SOURCE
+//     address (which 16-byte chunk of the 128-byte row a lane fetches) and mirrored on the ds_read_b128 side.
+//   * the MFMA is issued with the weight tile as the A operand and the activation tile as the B operand, with the
+//     16 weight rows of tile j permuted so that every lane ends up owning 16 CONTIGUOUS output columns of one output
+//     row: the epilogue is two 16-byte bf16 stores (or four fp32 ones) per row, no LDS transpose.
+//   * 1-D grid with an XCD-aware, M-grouped tile order so the 32 blocks resident on one XCD share B panels in its L2.
+#include "tr1_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand per buffer
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+TR1_DEV int keyA(int row) { return (row >> 1) & 7; }
+TR1_DEV int keyB(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
+
+// Stage one 128x64 bf16 tile: 16 wave-instructions of 1 KiB, 4 per wave. Rows beyond `rows_valid` are clamped
+// (their products land in rows/cols that are never stored).
+template <bool IS_B>
+TR1_DEV void stage_tile(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
+                        int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = wave * 4 + i;
+        const int row = inst * 8 + (lane >> 3);
+        const int phys = lane & 7;
+        const int logical = phys ^ (IS_B ? keyB(row) : keyA(row));
+        int64_t grow = row0 + row;
+        if (grow >= rows_valid) grow = rows_valid - 1;
+        const bf16_t* src = g + grow * ld + k0 + logical * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+    }
+}
+
+template <bool OUT_F32, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
+                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                                         int64_t ldr, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of the grouped order.
+    const int nwg = tiles_m * tiles_n;
+    int wgid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int GROUP_M = 8;
+    const int group = wgid / (GROUP_M * tiles_n);
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = wgid - group * GROUP_M * tiles_n;
+    const int tm = first_m + in_group % gsz;
+    const int tn = in_group / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(K / BK);
+    stage_tile<false>(A, lda, m0, M, 0, smem, wave, lane);
+    stage_tile<true>(B, ldb, n0, N, 0, smem + TILE_BYTES, wave, lane);
+
+    const int u = lane & 15, g = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // retires this wave's DMA for tile kt (vmcnt(0)) and orders it against every reader
+        char* curA = smem + (kt & 1) * 2 * TILE_BYTES;
+        char* curB = curA + TILE_BYTES;
+        if (kt + 1 < nk) {
+            char* nxtA = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile<false>(A, lda, m0, M, (int64_t)(kt + 1) * BK, nxtA, wave, lane);
+            stage_tile<true>(B, ldb, n0, N, (int64_t)(kt + 1) * BK, nxtA + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t xa[4], wb[4];
+            const int chunk = ks * 4 + g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + u;
+                xa[i] = *reinterpret_cast<const bf16x8_t*>(curA + row * 128 + ((chunk ^ keyA(row)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + (u >> 2) * 16 + j * 4 + (u & 3);
+                wb[j] = *reinterpret_cast<const bf16x8_t*>(curB + row * 128 + ((chunk ^ keyB(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns, for each i, row m = m0 + wm*64 + i*16 + u and columns n0 + wn*64 + g*16 + [0,16)
+    const int64_t nbase = n0 + wn * 64 + g * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + u;
+        if (m >= M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // two 8-column halves
+            const int64_t n = nbase + h * 8;
+            if (n + 8 > N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][h * 2 + (e >> 2)][e & 3];
+            if (bias) {
+                const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(bv[e]); v[2 * e + 1] += bfhi(bv[e]); }
+            }
+            if (residual) {
+                const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
+            }
+            if (OUT_F32) {
+                float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
+                f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                if (ACCUM) {
+                    const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(cp), p1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
+                    o0 += p0; o1 += p1;
+                }
+                *reinterpret_cast<f32x4_t*>(cp) = o0;
+                *reinterpret_cast<f32x4_t*>(cp + 4) = o1;
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(Cv) + m * ldc + n;
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<u32x4_t*>(cp) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Skinny GEMM for the decode regime (M <= 16 rows, one new token per rollout row): out[M,N] = x[M,K] * W[N,K]^T.
+// HBM-bound weight streaming: every W element is read exactly once, straight from global memory into the MFMA A
+// fragment (no LDS: the operand is not shared between waves).  A block owns 16 output columns; its 4 waves split K
+// and the partial 16x16 tiles are reduced through LDS.  Each lane fetches 32 contiguous bytes of one W row per
+// step, so a 16-lane group covers one full 128-byte line per row; the k-order inside the MFMA is permuted the same
+// way for x (any k permutation is legal as long as A and B agree).
+// ------------------------------------------------------------------------------------------------------------------
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
+                                                          float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
+                                                          const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
+                                                          int64_t ldw, int64_t ldc, int64_t ldr) {
+    __shared__ __attribute__((aligned(16))) float red[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    int64_t wrow = n0 + u; if (wrow >= N) wrow = N - 1;
+    const int xrow = (u < M) ? u : (M - 1);
+    const bf16_t* wp = W + wrow * ldw;
+    const bf16_t* xp = X + (int64_t)xrow * ldx;
+    // this wave's K range, in steps of 64 elements (two MFMA k-steps)
+    const int64_t nsteps = K / 64;
+    const int64_t s_per = (nsteps + 3) / 4;
+    const int64_t s0 = wave * s_per;
+    int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int64_t s = s0;
+    for (; s + UNROLL <= s1; s += UNROLL) {
+        bf16x8_t wa[UNROLL][2], xa[UNROLL][2];
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            const int64_t k = (s + q) * 64 + g * 16;
+            wa[q][0] = *reinterpret_cast<const bf16x8_t*>(wp + k);
+            wa[q][1] = *reinterpret_cast<const bf16x8_t*>(wp + k + 8);
+            xa[q][0] = *reinterpret_cast<const bf16x8_t*>(xp + k);
+            xa[q][1] = *reinterpret_cast<const bf16x8_t*>(xp + k + 8);
+        }
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][0], xa[q][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][1], xa[q][1], acc1, 0, 0, 0);
+        }
+    }
+    for (; s < s1; ++s) {
+        const int64_t k = s * 64 + g * 16;
+        const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp + k), w1 = *reinterpret_cast<const bf16x8_t*>(wp + k + 8);
+        const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xp + k), x1 = *reinterpret_cast<const bf16x8_t*>(xp + k + 8);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc1, 0, 0, 0);
+    }
+    // D[row = n index (g*4+r)][col = m (u)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][u][g * 4 + r] = acc0[r] + acc1[r];
+    __syncthreads();
+    // 256 threads -> 16 (m) x 16 (n)
+    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+    const int64_t n = n0 + nn;
+    if (m < M && n < N) {
+        float v = red[0][m][nn] + red[1][m][nn] + red[2][m][nn] + red[3][m][nn];
+        if (bias) v += bf2f(bias[n]);
+        if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
+        if (Cf32) Cf32[(int64_t)m * ldc + n] = v;
+        else C[(int64_t)m * ldc + n] = f2bf(v);
+    }
+}
+
+extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
+                                int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0, "gemm_nt: K must be a multiple of 64 (pad the operands)");
+    TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: N%8, lda%8, ldb%8, ldc%4 required");
+    TR1_CHECK_ARG(!accumulate || out_f32, "gemm_nt: accumulate requires fp32 output");
+    TR1_CHECK_ARG(!residual || ldr % 8 == 0, "gemm_nt: ldr%8 required");
+    TR1_CHECK_ARG(out_f32 || ldc % 8 == 0, "gemm_nt: ldc%8 required for bf16 output");
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 16 && !accumulate && K >= 256) {
+        dim3 grid((unsigned)((N + 15) / 16));
+        hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C,
+                           out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr);
+        TR1_LAUNCH_CHECK();
+    }
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    dim3 grid((unsigned)(tiles_m * tiles_n));
+#define LAUNCH(OF, AC)                                                                                                              \
+    hipLaunchKernelGGL((gemm_nt_kernel<OF, AC>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
+                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n)
+    if (out_f32) { if (accumulate) LAUNCH(true, true); else LAUNCH(true, false); }
+    else LAUNCH(false, false);
+#undef LAUNCH
+    TR1_LAUNCH_CHECK();
+}

@@ -1,0 +1,89 @@
+// Shared device/host helpers for the timer1 HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16, 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define TR1_DEV __device__ __forceinline__
+
+TR1_DEV float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
+TR1_DEV bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+TR1_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+TR1_DEV float bflo(unsigned w) { return __uint_as_float(w << 16); }
+TR1_DEV float bfhi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+TR1_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+TR1_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); red must hold >= 16 floats
+TR1_DEV float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : 0.f;
+    t = wave_sum(t);
+    return t;
+}
+TR1_DEV float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : -INFINITY;
+    t = wave_max(t);
+    return t;
+}
+
+// ---- host side error plumbing (C ABI returns int; message via tr1_last_error) ----
+extern "C" void tr1_set_error_(const char* msg);
+
+#define TR1_CHECK_ARG(cond, msg)                                  \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            tr1_set_error_(msg);                                  \
+            return 1000;                                          \
+        }                                                         \
+    } while (0)
+
+#define TR1_LAUNCH_CHECK()                                        \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) {                                  \
+            tr1_set_error_(hipGetErrorString(e__));               \
+            return (int)e__;                                      \
+        }                                                         \
+        return 0;                                                 \
+    } while (0)
+
+static inline int tr1_grid_1d(int64_t work_items, int per_block, int cap = 8192) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}

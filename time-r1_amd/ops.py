@@ -1,0 +1,333 @@
+"""Tensor-level wrappers over the C ABI (include/timer1_hip.h). PyTorch is used for device memory and streams only.
+
+`HipOps` is the product backend. The engine (model.py / rollout.py / grpo.py) is written against this small interface so that
+tests can drive the same host logic with `oracle.ref_ops.RefOps` on CPU - the product never imports oracle/.
+"""
+import torch
+
+from . import hip
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+I32 = torch.int32
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor/view, got strides %s" % (t.stride(),)
+    return t.stride(0)
+
+
+class HipOps:
+    """All compute goes through libtimer1_hip.so on the current torch HIP stream. No fallbacks."""
+
+    name = "hip"
+    act_dtype = BF16
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise hip.HipError("HipOps needs a HIP device (got %s); there is no CPU fallback" % device)
+        self.L = hip.lib()
+        self._ws = {}
+
+    # ---- memory helpers -------------------------------------------------------------------------------------------
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.act_dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.act_dtype, device=self.device)
+
+    def tensor(self, data, dtype):
+        return torch.as_tensor(data, dtype=dtype).to(self.device)
+
+    def _s(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _workspace(self, key, numel, dtype):
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _chk(self, *ts, dtype=BF16):
+        for t in ts:
+            if t is not None:
+                assert t.device.type == "cuda" and t.dtype == dtype, (t.device, t.dtype, dtype)
+
+    # ---- GEMM -----------------------------------------------------------------------------------------------------
+    def gemm_nt(self, a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
+        """C[M,N] = a[M,K] @ b[N,K]^T (+bias) (+residual); bf16 in, fp32 accumulate. K must be a multiple of 64."""
+        self._chk(a, b, bias, residual)
+        M, K = a.shape
+        N, K2 = b.shape
+        assert K == K2, (a.shape, b.shape)
+        if out is None:
+            assert not accumulate
+            out = self.empty(M, N, dtype=F32 if out_f32 else BF16)
+        assert out.shape == (M, N) and out.dtype == (F32 if out_f32 else BF16)
+        self.L.call("tr1_gemm_nt_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, _ld(a), _ld(b), _ld(out),
+                    _ld(residual) if residual is not None else 0, int(out_f32), int(accumulate), self._s())
+        return out
+
+    def transpose(self, x, pad_to=64, out=None):
+        """x[R,C] -> [C, Rpad] with zero-filled padding columns (Rpad = R rounded up to pad_to)."""
+        self._chk(x)
+        R, C = x.shape
+        Rp = (R + pad_to - 1) // pad_to * pad_to
+        if out is None:
+            out = self.empty(C, Rp)
+        assert out.shape[0] == C and out.shape[1] >= R
+        self.L.call("tr1_transpose_bf16", _p(x), _ld(x), _p(out), _ld(out), R, C, self._s())
+        return out
+
+    # ---- norms ----------------------------------------------------------------------------------------------------
+    def rmsnorm_fwd(self, x, w, eps, residual=None, need_rstd=True):
+        self._chk(x, w, residual)
+        rows, cols = x.shape
+        assert x.is_contiguous() and (residual is None or residual.is_contiguous())
+        y = self.empty(rows, cols)
+        rstd = self.empty(rows, dtype=F32) if need_rstd else None
+        xsum = self.empty(rows, cols) if residual is not None else None
+        self.L.call("tr1_rmsnorm_fwd", _p(x), _p(residual), _p(w), _p(y), _p(xsum), _p(rstd), rows, cols, float(eps), self._s())
+        return y, rstd, xsum
+
+    def rmsnorm_bwd(self, dy, x, w, rstd, dres=None, dw=None):
+        self._chk(dy, x, w, dres)
+        rows, cols = x.shape
+        assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
+        dx = self.empty(rows, cols)
+        if dw is not None:
+            assert dw.dtype == F32 and dw.numel() == cols
+        self.L.call("tr1_rmsnorm_bwd", _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), rows, cols, self._s())
+        return dx
+
+    def layernorm_fwd(self, x, w, b, eps, need_stats=True):
+        self._chk(x, w, b)
+        rows, cols = x.shape
+        assert x.is_contiguous()
+        y = self.empty(rows, cols)
+        mean = self.empty(rows, dtype=F32) if need_stats else None
+        rstd = self.empty(rows, dtype=F32) if need_stats else None
+        self.L.call("tr1_layernorm_fwd", _p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, cols, float(eps), self._s())
+        return y, mean, rstd
+
+    def layernorm_bwd(self, dy, x, w, mean, rstd, dw, db, need_dx=False):
+        self._chk(dy, x, w)
+        rows, cols = x.shape
+        assert dy.is_contiguous() and x.is_contiguous() and dw.dtype == F32 and db.dtype == F32
+        dx = self.empty(rows, cols) if need_dx else None
+        self.L.call("tr1_layernorm_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db), rows, cols, self._s())
+        return dx
+
+    # ---- activations ----------------------------------------------------------------------------------------------
+    def swiglu_fwd(self, gu):
+        self._chk(gu)
+        rows, two_i = gu.shape
+        assert gu.is_contiguous()
+        out = self.empty(rows, two_i // 2)
+        self.L.call("tr1_swiglu_fwd", _p(gu), _p(out), rows, two_i // 2, self._s())
+        return out
+
+    def swiglu_bwd(self, dout, gu):
+        self._chk(dout, gu)
+        rows, two_i = gu.shape
+        assert gu.is_contiguous() and dout.is_contiguous()
+        dgu = self.empty(rows, two_i)
+        self.L.call("tr1_swiglu_bwd", _p(dout), _p(gu), _p(dgu), rows, two_i // 2, self._s())
+        return dgu
+
+    def gelu_fwd(self, x):
+        self._chk(x)
+        assert x.is_contiguous()
+        y = torch.empty_like(x)
+        self.L.call("tr1_gelu_fwd", _p(x), _p(y), x.numel(), self._s())
+        return y
+
+    def gelu_bwd(self, x, dy):
+        self._chk(x, dy)
+        assert x.is_contiguous() and dy.is_contiguous()
+        dx = torch.empty_like(x)
+        self.L.call("tr1_gelu_bwd", _p(x), _p(dy), _p(dx), x.numel(), self._s())
+        return dx
+
+    def quickgelu_fwd(self, x):
+        self._chk(x)
+        assert x.is_contiguous()
+        y = torch.empty_like(x)
+        self.L.call("tr1_quickgelu_fwd", _p(x), _p(y), x.numel(), self._s())
+        return y
+
+    def add(self, a, b):
+        self._chk(a, b)
+        assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+        y = torch.empty_like(a)
+        self.L.call("tr1_add_bf16", _p(a), _p(b), _p(y), a.numel(), self._s())
+        return y
+
+    def colsum_accum(self, dy, dbias):
+        self._chk(dy)
+        assert dy.is_contiguous() and dbias.dtype == F32 and dbias.numel() == dy.shape[1]
+        self.L.call("tr1_colsum_accum", _p(dy), _p(dbias), dy.shape[0], dy.shape[1], self._s())
+
+    def cast_to_act(self, x_f32):
+        assert x_f32.dtype == F32 and x_f32.is_contiguous()
+        y = torch.empty(x_f32.shape, dtype=BF16, device=self.device)
+        self.L.call("tr1_cast_f32_to_bf16", _p(x_f32), _p(y), x_f32.numel(), self._s())
+        return y
+
+    def cast_to_f32(self, x):
+        self._chk(x)
+        assert x.is_contiguous()
+        y = torch.empty(x.shape, dtype=F32, device=self.device)
+        self.L.call("tr1_cast_bf16_to_f32", _p(x), _p(y), x.numel(), self._s())
+        return y
+
+    # ---- rotary ---------------------------------------------------------------------------------------------------
+    def mrope_table(self, pos3, head_dim, sections, theta):
+        assert pos3.dtype == I32 and pos3.is_contiguous() and pos3.shape[0] == 3
+        T = pos3.shape[1]
+        cos = self.empty(T, head_dim // 2, dtype=F32)
+        sin = self.empty(T, head_dim // 2, dtype=F32)
+        self.L.call("tr1_mrope_table", _p(pos3), _p(cos), _p(sin), T, head_dim, sections[0], sections[1], sections[2], float(theta), 1,
+                    self._s())
+        return cos, sin
+
+    def vision_rope_table(self, hw, head_dim, theta=10000.0):
+        assert hw.dtype == I32 and hw.is_contiguous() and hw.shape[1] == 2
+        N = hw.shape[0]
+        cos = self.empty(N, head_dim // 2, dtype=F32)
+        sin = self.empty(N, head_dim // 2, dtype=F32)
+        self.L.call("tr1_vision_rope_table", _p(hw), _p(cos), _p(sin), N, head_dim, float(theta), self._s())
+        return cos, sin
+
+    def rope_apply(self, x, n_heads, head_dim, cos, sin, backward=False, out=None):
+        """x: [T, >= n_heads*head_dim] row-major view; rotates the first n_heads heads of every row."""
+        self._chk(x)
+        T = x.shape[0]
+        if out is None:
+            out = self.empty(T, n_heads * head_dim)
+        self.L.call("tr1_rope_apply", _p(x), _ld(x), _p(out), _ld(out), _p(cos), _p(sin), T, n_heads, head_dim, int(backward), self._s())
+        return out
+
+    # ---- gathers --------------------------------------------------------------------------------------------------
+    def gather_rows(self, table, ids):
+        self._chk(table)
+        assert ids.dtype == I32 and table.is_contiguous()
+        out = self.empty(ids.numel(), table.shape[1])
+        self.L.call("tr1_gather_rows", _p(table), _p(ids), _p(out), ids.numel(), table.shape[1], self._s())
+        return out
+
+    def scatter_rows(self, src, idx, dst):
+        self._chk(src, dst)
+        assert idx.dtype == I32 and src.is_contiguous() and dst.is_contiguous() and src.shape[1] == dst.shape[1]
+        self.L.call("tr1_scatter_rows", _p(src), _p(idx), _p(dst), idx.numel(), src.shape[1], self._s())
+
+    def embed_bwd(self, dout, ids, dtable):
+        self._chk(dout)
+        assert ids.dtype == I32 and dout.is_contiguous() and dtable.dtype == F32
+        self.L.call("tr1_embed_bwd", _p(dout), _p(ids), _p(dtable), ids.numel(), dout.shape[1], self._s())
+
+    # ---- attention ------------------------------------------------------------------------------------------------
+    def pack_transpose(self, x, n_heads, n_kv, head_dim, ld_out=None, slots=None, out=None, zero_pad=True):
+        self._chk(x)
+        T = x.shape[0]
+        group = n_heads // n_kv
+        if out is None:
+            if ld_out is None:
+                ld_out = (T * group + 63) // 64 * 64
+            out = self.empty(n_kv * head_dim, ld_out)
+        self.L.call("tr1_pack_transpose", _p(x), _ld(x), _p(out), _ld(out), _p(slots), T, n_heads, n_kv, head_dim,
+                    int(zero_pad and slots is None), self._s())
+        return out
+
+    def scatter_slots(self, src, dst, slots):
+        self._chk(src, dst)
+        assert slots.dtype == I32
+        self.L.call("tr1_scatter_slots", _p(src), _ld(src), _p(dst), _ld(dst), _p(slots), src.shape[0], src.shape[1], self._s())
+
+    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True):
+        self._chk(q, k, vt)
+        assert pre.dtype == I32 and lo.dtype == I32 and hi.dtype == I32
+        T = q.shape[0]
+        o = self.empty(T, n_heads * head_dim)
+        lse = self.empty(n_heads, T, dtype=F32) if need_lse else None
+        ws, nws = None, 0
+        if nsplit > 1:
+            nws = self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
+            ws = self._workspace("attn_split", nws, F32)
+        self.L.call("tr1_attn_fwd", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
+                    n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, self._s())
+        return o, lse
+
+    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale):
+        """-> dq [T, n_heads*hd], dk, dv [n_slots, n_kv*hd]. Builds the transposed operand copies it needs."""
+        self._chk(q, k, v, o, do)
+        T = q.shape[0]
+        group = n_heads // n_kv
+        kt = self.pack_transpose(k[:n_slots], n_kv, n_kv, head_dim)
+        qt = self.pack_transpose(q, n_heads, n_kv, head_dim)
+        dot = self.pack_transpose(do, n_heads, n_kv, head_dim)
+        dq = self.empty(T, n_heads * head_dim)
+        dk = self.empty(n_slots, n_kv * head_dim)
+        dv = self.empty(n_slots, n_kv * head_dim)
+        delta = self.empty(n_heads, T, dtype=F32)
+        qmeta = self._workspace("attn_qmeta", 3 * ((T * group + 63) // 64), I32)
+        self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kt), _ld(kt), _p(qt), _ld(qt), _p(dot), _ld(dot),
+                    _p(o), _ld(o), _p(do), _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(pre), _p(lo),
+                    _p(hi), _p(qmeta), T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
+        return dq, dk, dv
+
+    # ---- vocabulary side ------------------------------------------------------------------------------------------
+    def logp_entropy_fwd(self, logits, targets):
+        self._chk(logits)
+        assert targets.dtype == I32
+        R, V = logits.shape
+        logp = self.empty(R, dtype=F32)
+        ent = self.empty(R, dtype=F32)
+        lse = self.empty(R, dtype=F32)
+        self.L.call("tr1_logp_entropy_fwd", _p(logits), _ld(logits), _p(targets), _p(logp), _p(ent), _p(lse), R, V, self._s())
+        return logp, ent, lse
+
+    def logp_bwd(self, logits, targets, lse, dlogp, inplace=True):
+        self._chk(logits)
+        R, V = logits.shape
+        out = logits if inplace else torch.empty_like(logits)
+        self.L.call("tr1_logp_bwd", _p(logits), _ld(logits), _p(targets), _p(lse), _p(dlogp), _p(out), _ld(out), R, V, self._s())
+        return out
+
+    def grpo_loss(self, logp, ref_logp, mask, adv, beta, use_grpo, grad_scale=1.0):
+        G, C = logp.shape
+        assert logp.dtype == F32 and mask.dtype == I32 and adv.dtype == F32 and logp.is_contiguous() and mask.is_contiguous()
+        dlogp = self.empty(G, C, dtype=F32)
+        out3 = self.empty(3, dtype=F32)
+        row_len = self.empty(G, dtype=F32)
+        row_kl = self.empty(G, dtype=F32)
+        self.L.call("tr1_grpo_loss", _p(logp), _p(ref_logp), _p(mask), _p(adv), _p(dlogp), _p(out3), _p(row_len), _p(row_kl), G, C,
+                    float(beta), int(bool(use_grpo)), float(grad_scale), self._s())
+        return dlogp, out3, row_len, row_kl
+
+    def sample_tokens(self, logits, temperature, top_k, seed, step_dev, tokens, finished, eos_id, pad_id, stop_at_eos, u_out=None):
+        self._chk(logits)
+        assert tokens.dtype == I32 and (step_dev is None or step_dev.dtype == I32)
+        rows, V = logits.shape
+        self.L.call("tr1_sample_tokens", _p(logits), _ld(logits), rows, V, float(temperature), int(top_k or 0), int(seed) & (2**64 - 1),
+                    _p(step_dev), _p(tokens), tokens.stride(0), _p(finished), int(eos_id), int(pad_id), int(bool(stop_at_eos)), _p(u_out),
+                    self._s())
+
+    # ---- optimizer ------------------------------------------------------------------------------------------------
+    def sumsq_accum(self, g, out_scalar):
+        assert g.dtype == F32 and out_scalar.dtype == F32
+        self.L.call("tr1_sumsq_accum", _p(g), g.numel(), _p(out_scalar), self._s())
+
+    def adamw_step(self, p32, m, v, g, p16, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0, grad_mult=1.0,
+                   zero_grad=True):
+        assert p32.dtype == F32 and m.dtype == F32 and v.dtype == F32 and g.dtype == F32 and p16.dtype == BF16
+        n = p32.numel()
+        assert m.numel() == n and v.numel() == n and g.numel() == n and p16.numel() == n
+        self.L.call("tr1_adamw_step", _p(p32), _p(m), _p(v), _p(g), _p(p16), n, float(lr), float(beta1), float(beta2), float(eps),
+                    float(weight_decay), int(step), _p(sumsq), float(max_norm), float(grad_mult), int(zero_grad), self._s())
