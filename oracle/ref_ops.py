@@ -178,7 +178,7 @@ class RefOps:
         ang = pos * inv_freq[None, :]
         cos, sin = ang.cos(), ang.sin()
         # the reference casts cos/sin to the activation dtype (bf16 on GPU)
-        return cos.to(torch.bfloat16).float(), sin.to(torch.bfloat16).float()
+        return cos.to(torch.bfloat16).float().contiguous(), sin.to(torch.bfloat16).float().contiguous()
 
     def vision_rope_table(self, hw, head_dim, theta=10000.0):
         half = head_dim // 2
@@ -186,7 +186,7 @@ class RefOps:
         inv_freq = 1.0 / (theta ** (torch.arange(0, half, 2, dtype=torch.float32) / half))  # [q]
         ang = torch.cat([hw[:, 0:1].float() * inv_freq[None, :], hw[:, 1:2].float() * inv_freq[None, :]], 1)  # [N, half]
         assert ang.shape[1] == half and q * 2 == half
-        return ang.cos(), ang.sin()
+        return ang.cos().contiguous(), ang.sin().contiguous()
 
     def rope_apply(self, x, n_heads, head_dim, cos, sin, backward=False, out=None):
         T = x.shape[0]

@@ -209,6 +209,7 @@ class HipOps:
         """x: [T, >= n_heads*head_dim] row-major view; rotates the first n_heads heads of every row."""
         self._chk(x)
         T = x.shape[0]
+        assert cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (T, head_dim // 2)
         if out is None:
             out = self.empty(T, n_heads * head_dim)
         self.L.call("tr1_rope_apply", _p(x), _ld(x), _p(out), _ld(out), _p(cos), _p(sin), T, n_heads, head_dim, int(backward), self._s())
