@@ -250,13 +250,16 @@ class RefOps:
         o, lse = self._dense_attn(q.float(), k.float(), v, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale)
         return self._a(o), (lse if need_lse else None)
 
-    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale):
+    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):
         with torch.enable_grad():
             qf = q.float().detach().requires_grad_(True)
             kf = k[:n_slots].float().detach().requires_grad_(True)
             vf = v[:n_slots].float().detach().requires_grad_(True)
             of, _ = self._dense_attn(qf, kf, vf, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale)
             dq, dk, dv = torch.autograd.grad(of, (qf, kf, vf), do.float())
+        if dv_out is not None:
+            dv_out.copy_(self._a(dv))
+            return self._a(dq), self._a(dk), dv_out
         return self._a(dq), self._a(dk), self._a(dv)
 
     # ---- vocabulary side (ref: timer1_trainer.py:458-481, :635-639, :713-737)

@@ -1,0 +1,147 @@
+"""One GRPO micro-step on device: vision tower once -> shared-prefix rollout -> policy / reference log-probs on the packed
+sequence -> loss gradient -> hand-written backward.  Restates the tensor algebra of TimeR1_Trainer.compute_loss
+(reference src/time_r1/rl/timer1_trainer.py:512-782) without the G-fold replication.
+
+Host-side pieces that the reference also runs on the host (text decode, reward callbacks, group statistics on G floats)
+stay in trainer.py; everything with a FLOP count lives here and goes through ops (HIP kernels).
+"""
+import numpy as np
+import torch
+
+from .model import Engine
+from .positions import PackedLayout, rope_index
+from .rollout import Rollout
+
+I32 = torch.int32
+F32 = torch.float32
+
+
+class StepState:
+    """Per-prompt device state handed between the phases of a micro-step."""
+    pass
+
+
+class GRPOCore:
+    def __init__(self, engine: Engine, ref_arena=None, num_generations=8, max_completion_length=200, beta=0.04, use_grpo=False,
+                 temperature=1.0, top_k=50, seed=1234, rope_index_mode="hf4", stop_at_eos=False):
+        self.eng = engine
+        self.ops = engine.ops
+        self.cfg = engine.cfg
+        self.ref_arena = ref_arena
+        self.G, self.C = int(num_generations), int(max_completion_length)
+        self.beta, self.use_grpo = float(beta), bool(use_grpo)
+        self.rope_index_mode = rope_index_mode
+        self.roll = Rollout(engine, self.G, self.C, temperature, top_k, seed, stop_at_eos)
+        if self.beta != 0.0 and ref_arena is None:
+            raise ValueError("beta != 0 needs a reference-policy arena (reference timer1_trainer.py:295-307)")
+
+    # ------------------------------------------------------------------------------------------------------- phase 1
+    def prepare(self, input_ids, pixel_values_videos, video_grid_thw):
+        """input_ids: 1-D ints (prompt with <|video_pad|> expanded); pixel_values_videos: float [N_v, patch_dim] as produced by
+        the HF video processor (reference timer1_trainer.py:547-565); video_grid_thw: [(t, h, w)]."""
+        ops, cfg, eng = self.ops, self.cfg, self.eng
+        st = StepState()
+        ids = np.asarray(input_ids, dtype=np.int64).reshape(-1)
+        grid = [tuple(int(x) for x in g) for g in np.asarray(video_grid_thw).reshape(-1, 3)]
+        st.P = int(ids.shape[0])
+        st.grid = grid
+        st.prompt_ids_host = ids
+        st.prompt_ids = ops.tensor(ids.astype(np.int32), I32)
+        vid_rows = np.nonzero(ids == cfg.video_token_id)[0].astype(np.int32)
+        st.vid_rows = ops.tensor(vid_rows, I32)
+        st.pos3_prompt, st.delta = rope_index(ids, grid, cfg.video_token_id, cfg.image_token_id, cfg.vision.spatial_merge_size,
+                                              mode=self.rope_index_mode)
+        v = cfg.vision
+        pix = torch.as_tensor(pixel_values_videos)
+        assert pix.dim() == 2 and pix.shape[1] == v.patch_dim, pix.shape
+        n_vid_tokens = sum(t * h * w for t, h, w in grid) // v.merge_unit
+        assert n_vid_tokens == vid_rows.shape[0], "video pad tokens (%d) != merged patches (%d)" % (vid_rows.shape[0], n_vid_tokens)
+        pp = ops.zeros(pix.shape[0], v.patch_dim_padded)
+        pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)
+        st.feats = eng.vit_features(pp, grid)                     # frozen blocks: once per prompt (reference: 3 x G times)
+        st.vid_embeds, st.merger_ctx = eng.merger_fwd(eng.params.train, st.feats, save=True)
+        return st
+
+    # ------------------------------------------------------------------------------------------------------- phase 2
+    def rollout(self, st):
+        tokens, lay = self.roll.generate(self.eng.params.train, st.prompt_ids, st.vid_embeds, st.vid_rows, st.pos3_prompt, st.delta)
+        st.layout = lay
+        st.completion_ids = tokens        # int32 [G, C] on device
+        return tokens
+
+    # ------------------------------------------------------------------------------------------------------- phase 3
+    def _packed_inputs(self, st):
+        ops, lay = self.ops, st.layout
+        comp = st.completion_ids
+        st.ids_packed = torch.cat([st.prompt_ids, comp.reshape(-1)])
+        st.pos3 = ops.tensor(lay.positions(st.pos3_prompt, st.delta), I32)
+        t = self.cfg.text
+        st.cos, st.sin = ops.mrope_table(st.pos3, t.head_dim, t.mrope_section, t.rope_theta)
+        st.masks = [ops.tensor(a, I32) for a in lay.masks()]
+        st.pred_rows = ops.tensor(lay.pred_rows(), I32)
+        G, C = lay.G, lay.C
+        st.targets = torch.cat([comp[:, 0], comp[:, 1:].reshape(-1)]).contiguous()
+        # permutation between [G, C] order and pred_rows order
+        perm = np.concatenate([np.arange(G) * C, (np.arange(G)[:, None] * C + 1 + np.arange(C - 1)[None, :]).reshape(-1)])
+        st.perm = torch.as_tensor(perm, dtype=torch.long, device=comp.device)          # pred order -> flat (g, s) index
+        st.inv_perm = torch.empty_like(st.perm)
+        st.inv_perm[st.perm] = torch.arange(G * C, device=comp.device)
+
+    def _to_gc(self, st, x_pred_order):
+        return x_pred_order[st.inv_perm].view(st.layout.G, st.layout.C)
+
+    def forward_logps(self, st):
+        """Policy log-probs / entropy (activations saved for backward) and reference log-probs (no grad)."""
+        eng, ops = self.eng, self.ops
+        self._packed_inputs(st)
+        tr = eng.params.train
+        h0 = eng.embed(tr, st.ids_packed, st.vid_embeds, st.vid_rows)
+        hL, st.llm_ctx = eng.llm_fwd(tr, h0, st.cos, st.sin, st.masks, save=True)
+        logp, ent, st.head_ctx = eng.head_fwd(tr, hL, st.pred_rows, st.targets, save=True)
+        st.logp = self._to_gc(st, logp).contiguous()
+        st.entropy = self._to_gc(st, ent).contiguous()
+        st.ref_logp = None
+        if self.beta != 0.0:
+            ra = self.ref_arena
+            ref_vid, _ = eng.merger_fwd(ra, st.feats, save=False)
+            h0r = eng.embed(ra, st.ids_packed, ref_vid, st.vid_rows)
+            hLr, _ = eng.llm_fwd(ra, h0r, st.cos, st.sin, st.masks, save=False)
+            rlogp, _, _ = eng.head_fwd(ra, hLr, st.pred_rows, st.targets, save=False)
+            st.ref_logp = self._to_gc(st, rlogp).contiguous()
+
+    # ------------------------------------------------------------------------------------------------------- phase 4
+    def loss_backward(self, st, completion_mask, advantages, grad_scale=1.0):
+        """completion_mask int32 [G, C], advantages fp32 [G] (device). Accumulates grads into the trainable arena.
+        Returns (out3 = [loss, mean kl, sum mask], row_len [G]) as device tensors."""
+        eng, ops = self.eng, self.ops
+        dlogp, out3, row_len, _ = ops.grpo_loss(st.logp, st.ref_logp, completion_mask, advantages, self.beta, self.use_grpo, grad_scale)
+        dl_pred = dlogp.reshape(-1)[st.perm].contiguous()
+        dh = eng.head_bwd(st.head_ctx, dl_pred, st.layout.G)
+        dh0 = eng.llm_bwd(st.llm_ctx, dh)
+        ids_g = st.ids_packed.clone()
+        ids_g[st.vid_rows.long()] = -1
+        dvid = eng.embed_bwd(dh0, ids_g, st.vid_rows)
+        eng.merger_bwd(st.merger_ctx, dvid)
+        st.llm_ctx = st.head_ctx = st.merger_ctx = None
+        return out3, row_len
+
+
+def eos_mask(completion_ids, eos_token_id):
+    """completion_mask[g, t] = 1 for t <= first EOS (EOS kept), all ones when there is none (reference timer1_trainer.py:580-590).
+    completion_ids: numpy int [G, C] -> numpy int32 [G, C]."""
+    G, C = completion_ids.shape
+    is_eos = completion_ids == eos_token_id
+    eos_idx = np.full(G, C, dtype=np.int64)
+    has = is_eos.any(1)
+    eos_idx[has] = is_eos.argmax(1)[has]
+    return (np.arange(C)[None, :] <= eos_idx[:, None]).astype(np.int32)
+
+
+def group_advantages(rewards_per_func, num_generations):
+    """rewards_per_func: torch fp32 [B*G, n_funcs] -> (rewards, advantages, std) exactly as reference timer1_trainer.py:700-712
+    (sum over funcs, per-group mean, UNBIASED std, eps 1e-4)."""
+    rewards = rewards_per_func.sum(dim=1)
+    mean = rewards.view(-1, num_generations).mean(dim=1).repeat_interleave(num_generations, dim=0)
+    std = rewards.view(-1, num_generations).std(dim=1).repeat_interleave(num_generations, dim=0)
+    adv = (rewards - mean) / (std + 1e-4)
+    return rewards, adv, std

@@ -1,0 +1,206 @@
+"""Qwen2-VL forward and hand-written backward, expressed on the op interface of ops.py (HipOps in production).
+
+No autograd: the GRPO update needs exactly one backward through a fixed architecture, so the engine saves what the HIP backward
+kernels need (288 GB of HBM holds every activation of a 7B step - no recomputation, unlike the reference's gradient
+checkpointing, scripts/posttrain/train_rl.sh:32) and walks the layers in reverse.
+
+Reference call sites restated here (transformers/models/qwen2_vl/modeling_qwen2_vl.py, v5.15.0):
+  vision tower   :251-274 PatchEmbed, :425-449 VisionBlock, :277-290 PatchMerger, :1021-1033 get_video_features
+  decoder layer  :559-624; attention :501-556; MLP :459-466; final norm :839; lm_head :1323; video scatter :1170-1176
+and the logprob stage of src/time_r1/rl/timer1_trainer.py:449-481.
+"""
+import numpy as np
+import torch
+
+from .config import ModelConfig
+from .params import ModelParams, Arena
+from .positions import vision_hw_ids, vision_segments
+
+I32 = torch.int32
+F32 = torch.float32
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, ops, params: ModelParams):
+        self.cfg, self.ops, self.params = cfg, ops, params
+        assert cfg.vision.variant == "qwen2_vl", "this round implements the Qwen2-VL vision tower (Qwen2.5-VL windows: next)"
+
+    # ================================================================================================= gradient helpers
+    def _wgrad(self, dy, x, gw):
+        """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K]"""
+        ops = self.ops
+        dyt = ops.transpose(dy)          # [N, Mp]
+        xt = ops.transpose(x)            # [K, Mp]
+        ops.gemm_nt(dyt, xt, out_f32=True, out=gw, accumulate=True)
+
+    def _dgrad(self, dy, w):
+        """dx[M,K] = dy[M,N] @ w[N,K]"""
+        assert dy.shape[1] % 64 == 0, "dgrad: N must be a multiple of 64"
+        wt = self.ops.transpose(w)       # [K, N]
+        return self.ops.gemm_nt(dy, wt)
+
+    # ============================================================================================================ ViT
+    def vit_features(self, pixels, grid_thw):
+        """Frozen Qwen2-VL vision blocks. pixels: [N_v, patch_dim_padded] act dtype; grid_thw: list of (t,h,w). -> [N_v, embed]"""
+        ops, v, fz = self.ops, self.cfg.vision, self.params.frozen
+        E, H, hd = v.embed_dim, v.num_heads, v.head_dim
+        hw = ops.tensor(vision_hw_ids(grid_thw, v.spatial_merge_size), I32)
+        pre, lo, hi = [ops.tensor(a, I32) for a in vision_segments(grid_thw)]
+        N = pixels.shape[0]
+        assert hw.shape[0] == N, (hw.shape, N)
+        cos, sin = ops.vision_rope_table(hw, hd)
+        x = ops.gemm_nt(pixels, fz.w("patch.w"))
+        scale = hd ** -0.5
+        for i in range(v.depth):
+            p = "v%d." % i
+            y, _, _ = ops.layernorm_fwd(x, fz.w(p + "n1.w"), fz.w(p + "n1.b"), v.ln_eps, need_stats=False)
+            qkv = ops.gemm_nt(y, fz.w(p + "qkv.w"), bias=fz.w(p + "qkv.b"))
+            q = ops.rope_apply(qkv[:, :E], H, hd, cos, sin)
+            k = ops.rope_apply(qkv[:, E:2 * E], H, hd, cos, sin)
+            vt = ops.pack_transpose(qkv[:, 2 * E:], H, H, hd)
+            o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
+            x = ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
+            y, _, _ = ops.layernorm_fwd(x, fz.w(p + "n2.w"), fz.w(p + "n2.b"), v.ln_eps, need_stats=False)
+            z = ops.quickgelu_fwd(ops.gemm_nt(y, fz.w(p + "fc1.w"), bias=fz.w(p + "fc1.b")))
+            x = ops.gemm_nt(z, fz.w(p + "fc2.w"), bias=fz.w(p + "fc2.b"), residual=x)
+        return x
+
+    def merger_fwd(self, arena: Arena, feats, save):
+        """PatchMerger (trainable even with fix_vit, reference timer1_trainer.py:277-280). feats [N_v, E] -> [N_v/4, out_hidden]"""
+        ops, v = self.ops, self.cfg.vision
+        N, E = feats.shape
+        xn, mean, rstd = ops.layernorm_fwd(feats, arena.w("merger.ln.w"), arena.w("merger.ln.b"), v.ln_eps, need_stats=save)
+        xv = xn.view(N // v.merge_unit, E * v.merge_unit)
+        z1 = ops.gemm_nt(xv, arena.w("merger.fc1.w"), bias=arena.w("merger.fc1.b"))
+        g1 = ops.gelu_fwd(z1)
+        out = ops.gemm_nt(g1, arena.w("merger.fc2.w"), bias=arena.w("merger.fc2.b"))
+        ctx = dict(feats=feats, mean=mean, rstd=rstd, xv=xv, z1=z1, g1=g1) if save else None
+        return out, ctx
+
+    def merger_bwd(self, ctx, dout):
+        ops, tr = self.ops, self.params.train
+        self._wgrad(dout, ctx["g1"], tr.g("merger.fc2.w"))
+        ops.colsum_accum(dout, tr.g("merger.fc2.b"))
+        dg1 = self._dgrad(dout, tr.w("merger.fc2.w"))
+        dz1 = ops.gelu_bwd(ctx["z1"], dg1)
+        self._wgrad(dz1, ctx["xv"], tr.g("merger.fc1.w"))
+        ops.colsum_accum(dz1, tr.g("merger.fc1.b"))
+        dxv = self._dgrad(dz1, tr.w("merger.fc1.w"))
+        dxn = dxv.view(ctx["feats"].shape)
+        ops.layernorm_bwd(dxn, ctx["feats"], tr.w("merger.ln.w"), ctx["mean"], ctx["rstd"], tr.g("merger.ln.w"), tr.g("merger.ln.b"),
+                          need_dx=False)  # the blocks below are frozen: no dx
+
+    # ============================================================================================================ LLM
+    def embed(self, arena: Arena, ids, vid_embeds=None, vid_rows=None):
+        h = self.ops.gather_rows(arena.w("embed"), ids)
+        if vid_embeds is not None:
+            self.ops.scatter_rows(vid_embeds, vid_rows, h)
+        return h
+
+    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None):
+        """Decoder stack over a packed sequence of M rows. masks = (pre, lo, hi) int32 [M] over slots == rows.
+        kv_cache: optional list of (K [S_cap, kv_dim], VT [kv_dim, S_cap]) to be filled (rollout prefill).
+        Returns (h_out, ctx) where ctx holds the saved activations when save=True."""
+        ops, t = self.ops, self.cfg.text
+        M = h.shape[0]
+        pre, lo, hi = masks
+        qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
+        scale = hd ** -0.5
+        layers = []
+        for i in range(t.n_layers):
+            p = "l%d." % i
+            xn, rstd1, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=save)
+            qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
+            q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cos, sin)
+            if kv_cache is not None:
+                kc, vtc = kv_cache[i]
+                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin, out=kc[:M])
+                vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc)
+                k_all = kc
+            else:
+                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin)
+                vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd)
+                k_all = k
+            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, M, hd, scale, need_lse=save)
+            h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
+            xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save)
+            gu = ops.gemm_nt(xn2, arena.w(p + "gu.w"))
+            a = ops.swiglu_fwd(gu)
+            h_out = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
+            if save:
+                layers.append(dict(h=h, rstd1=rstd1, xn=xn, qkv=qkv, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
+            h = h_out
+        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin) if save else None
+        return h, ctx
+
+    def llm_bwd(self, ctx, dh):
+        """dh: gradient wrt the decoder stack output [M, d]. Accumulates parameter grads; returns the gradient wrt the input embeddings."""
+        ops, t, tr = self.ops, self.cfg.text, self.params.train
+        pre, lo, hi = ctx["masks"]
+        cos, sin = ctx["cos"], ctx["sin"]
+        qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
+        scale = hd ** -0.5
+        for i in reversed(range(t.n_layers)):
+            p = "l%d." % i
+            L = ctx["layers"][i]
+            M = dh.shape[0]
+            # h_out = a @ Wd^T + h2
+            self._wgrad(dh, L["a"], tr.g(p + "down.w"))
+            da = self._dgrad(dh, tr.w(p + "down.w"))
+            dgu = ops.swiglu_bwd(da, L["gu"])
+            self._wgrad(dgu, L["xn2"], tr.g(p + "gu.w"))
+            dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"))
+            dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))
+            # h2 = o @ Wo^T + h
+            self._wgrad(dh2, L["o"], tr.g(p + "o.w"))
+            do = self._dgrad(dh2, tr.w(p + "o.w"))
+            dqkv = ops.empty(M, t.qkv_dim)
+            v = L["qkv"][:, qd + kvd:]
+            dq, dk, _ = ops.attn_bwd(L["q"], L["k"], v, L["o"], do, L["lse"], pre, lo, hi, t.n_heads, t.n_kv_heads, M, hd, scale,
+                                     dv_out=dqkv[:, qd + kvd:])
+            ops.rope_apply(dq, t.n_heads, hd, cos, sin, backward=True, out=dqkv[:, :qd])
+            ops.rope_apply(dk, t.n_kv_heads, hd, cos, sin, backward=True, out=dqkv[:, qd:qd + kvd])
+            ops.colsum_accum(dqkv, tr.g(p + "qkv.b"))
+            self._wgrad(dqkv, L["xn"], tr.g(p + "qkv.w"))
+            dxn = self._dgrad(dqkv, tr.w(p + "qkv.w"))
+            dh = ops.rmsnorm_bwd(dxn, L["h"], tr.w(p + "ln1"), L["rstd1"], dres=dh2, dw=tr.g(p + "ln1"))
+            ctx["layers"][i] = None  # release this layer's activations
+        return dh
+
+    def embed_bwd(self, dh0, ids_for_grad, vid_rows=None):
+        """ids_for_grad: token ids with -1 on rows whose embedding was replaced by a video feature."""
+        self.ops.embed_bwd(dh0, ids_for_grad, self.params.train.g("embed"))
+        if vid_rows is not None:
+            return self.ops.gather_rows(dh0, vid_rows)
+        return None
+
+    # ====================================================================================================== logprob head
+    def head_fwd(self, arena: Arena, h_last, pred_rows, targets, save):
+        """Final norm + lm_head on the rows that predict completion tokens only, then per-token log-prob and entropy
+        (reference _get_per_token_logps materialises logits for all (G, L, V) - SURVEY 0.6)."""
+        ops, t = self.ops, self.cfg.text
+        hp = ops.gather_rows(h_last, pred_rows)
+        hn, rstd, _ = ops.rmsnorm_fwd(hp, arena.w("norm"), t.rms_eps, need_rstd=save)
+        w = self.params.lm_head_w(arena)
+        logits = ops.gemm_nt(hn, w)
+        logp, ent, lse = ops.logp_entropy_fwd(logits, targets)
+        ctx = dict(hp=hp, hn=hn, rstd=rstd, logits=logits, lse=lse, targets=targets, pred_rows=pred_rows, M=h_last.shape[0]) if save else None
+        return logp, ent, ctx
+
+    def head_bwd(self, ctx, dlogp, n_dup):
+        """dlogp: [R] fp32 in pred_rows order. The first n_dup pred rows all alias one hidden row (the last prompt token)."""
+        ops, t, tr = self.ops, self.cfg.text, self.params.train
+        dlogits = ops.logp_bwd(ctx["logits"], ctx["targets"], ctx["lse"], dlogp, inplace=True)
+        self._wgrad(dlogits, ctx["hn"], self.params.lm_head_g())
+        dhn = self._dgrad(dlogits, self.params.lm_head_w())
+        ctx["logits"] = None
+        dhp = ops.rmsnorm_bwd(dhn, ctx["hp"], tr.w("norm"), ctx["rstd"], dw=tr.g("norm"))
+        d = dhp.shape[1]
+        dh = ops.zeros(ctx["M"], d)
+        acc = ops.zeros(d, dtype=F32)
+        ops.colsum_accum(dhp[:n_dup], acc)
+        first = ops.cast_to_act(acc).view(1, d)
+        ops.scatter_rows(first, ctx["pred_rows"][:1], dh)
+        if dhp.shape[0] > n_dup:
+            ops.scatter_rows(dhp[n_dup:], ctx["pred_rows"][n_dup:], dh)
+        return dh

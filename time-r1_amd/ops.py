@@ -265,7 +265,7 @@ class HipOps:
                     n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, self._s())
         return o, lse
 
-    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale):
+    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):
         """-> dq [T, n_heads*hd], dk, dv [n_slots, n_kv*hd]. Builds the transposed operand copies it needs."""
         self._chk(q, k, v, o, do)
         T = q.shape[0]
@@ -275,7 +275,7 @@ class HipOps:
         dot = self.pack_transpose(do, n_heads, n_kv, head_dim)
         dq = self.empty(T, n_heads * head_dim)
         dk = self.empty(n_slots, n_kv * head_dim)
-        dv = self.empty(n_slots, n_kv * head_dim)
+        dv = dv_out if dv_out is not None else self.empty(n_slots, n_kv * head_dim)
         delta = self.empty(n_heads, T, dtype=F32)
         qmeta = self._workspace("attn_qmeta", 3 * ((T * group + 63) // 64), I32)
         self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kt), _ld(kt), _p(qt), _ld(qt), _p(dot), _ld(dot),

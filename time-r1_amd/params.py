@@ -1,0 +1,216 @@
+"""Parameter arenas: every weight is a view into ONE flat buffer per role, so the optimizer, the gradient all-reduce and the
+reference-model snapshot are single large operations (MI355X: few, large HBM/xGMI transfers instead of thousands of small ones).
+
+  trainable arena : bf16 working weights + fp32 master / m / v / grad   (LLM + patch-merger; reference timer1_trainer.py:272-280)
+  frozen arena    : bf16 only (ViT patch-embed + blocks when fix_vit=True)
+"""
+import math
+import re
+
+import torch
+
+from .config import ModelConfig
+
+ALIGN = 64  # elements; keeps every view 128-byte aligned in bf16
+
+
+def _specs_llm(cfg: ModelConfig):
+    t = cfg.text
+    s = [("embed", (t.vocab_size, t.hidden))]
+    for i in range(t.n_layers):
+        p = "l%d." % i
+        s += [(p + "ln1", (t.hidden,)), (p + "qkv.w", (t.qkv_dim, t.hidden)), (p + "qkv.b", (t.qkv_dim,)), (p + "o.w", (t.hidden, t.q_dim)),
+              (p + "ln2", (t.hidden,)), (p + "gu.w", (2 * t.intermediate, t.hidden)), (p + "down.w", (t.hidden, t.intermediate))]
+    s += [("norm", (t.hidden,))]
+    if not t.tie_word_embeddings:
+        s += [("lm_head", (t.vocab_size, t.hidden))]
+    return s
+
+
+def _specs_merger(cfg: ModelConfig):
+    v = cfg.vision
+    m = v.embed_dim * v.merge_unit
+    s = [("merger.ln.w", (v.embed_dim,))]
+    if v.variant == "qwen2_vl":
+        s += [("merger.ln.b", (v.embed_dim,))]
+    s += [("merger.fc1.w", (m, m)), ("merger.fc1.b", (m,)), ("merger.fc2.w", (v.out_hidden, m)), ("merger.fc2.b", (v.out_hidden,))]
+    return s
+
+
+def _specs_vit(cfg: ModelConfig):
+    v = cfg.vision
+    s = [("patch.w", (v.embed_dim, v.patch_dim_padded))]
+    for i in range(v.depth):
+        p = "v%d." % i
+        s += [(p + "n1.w", (v.embed_dim,)), (p + "n1.b", (v.embed_dim,)), (p + "qkv.w", (3 * v.embed_dim, v.embed_dim)),
+              (p + "qkv.b", (3 * v.embed_dim,)), (p + "proj.w", (v.embed_dim, v.embed_dim)), (p + "proj.b", (v.embed_dim,)),
+              (p + "n2.w", (v.embed_dim,)), (p + "n2.b", (v.embed_dim,)), (p + "fc1.w", (v.mlp_dim, v.embed_dim)), (p + "fc1.b", (v.mlp_dim,)),
+              (p + "fc2.w", (v.embed_dim, v.mlp_dim)), (p + "fc2.b", (v.embed_dim,))]
+    return s
+
+
+class Arena:
+    def __init__(self, ops, specs, with_optimizer_state):
+        self.ops = ops
+        self.specs = specs
+        self.offsets = {}
+        off = 0
+        for name, shape in specs:
+            self.offsets[name] = (off, shape)
+            off += (int(math.prod(shape)) + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.w16 = ops.zeros(off, dtype=ops.act_dtype)
+        self.grad = self.master = self.m = self.v = None
+        if with_optimizer_state:
+            self.grad = ops.zeros(off, dtype=torch.float32)
+            self.master = ops.zeros(off, dtype=torch.float32)
+            self.m = ops.zeros(off, dtype=torch.float32)
+            self.v = ops.zeros(off, dtype=torch.float32)
+
+    def view(self, flat, name):
+        off, shape = self.offsets[name]
+        return flat[off: off + int(math.prod(shape))].view(*shape)
+
+    def w(self, name):
+        return self.view(self.w16, name)
+
+    def g(self, name):
+        return self.view(self.grad, name)
+
+    def names(self):
+        return [n for n, _ in self.specs]
+
+    def sync_master_from_w16(self):
+        if self.master is not None:
+            self.master.copy_(self.w16.float())
+
+    def clone_weights_only(self):
+        """bf16-only snapshot (the frozen reference policy, reference timer1_trainer.py:295-307)."""
+        a = Arena.__new__(Arena)
+        a.ops, a.specs, a.offsets, a.numel = self.ops, self.specs, self.offsets, self.numel
+        a.w16 = self.w16.clone()
+        a.grad = a.master = a.m = a.v = None
+        return a
+
+
+class ModelParams:
+    """Qwen2-VL parameters: `train` arena (LLM + merger) and `frozen` arena (ViT)."""
+
+    def __init__(self, cfg: ModelConfig, ops, seed=0, init="random"):
+        self.cfg = cfg
+        self.ops = ops
+        self.train = Arena(ops, _specs_llm(cfg) + _specs_merger(cfg), with_optimizer_state=True)
+        self.frozen = Arena(ops, _specs_vit(cfg), with_optimizer_state=False)
+        if init == "random":
+            self.init_random(seed)
+
+    # lm_head is tied to the embedding for the 2B model (shared storage -> shared gradient view)
+    def lm_head_w(self, arena=None):
+        a = arena or self.train
+        return a.w("embed") if self.cfg.text.tie_word_embeddings else a.w("lm_head")
+
+    def lm_head_g(self):
+        return self.train.g("embed") if self.cfg.text.tie_word_embeddings else self.train.g("lm_head")
+
+    def init_random(self, seed=0, std=0.02):
+        """SURVEY 8d synthetic weights: normal(0, 0.02), norm weights 1, biases small-random. Generated on host per tensor."""
+        g = torch.Generator().manual_seed(seed)
+        for arena in (self.train, self.frozen):
+            for name, shape in arena.specs:
+                if name.endswith("ln1") or name.endswith("ln2") or name == "norm" or name.endswith("ln.w") or name.endswith("n1.w") or name.endswith("n2.w"):
+                    t = torch.ones(shape)
+                elif name.endswith(".b"):
+                    t = torch.randn(shape, generator=g) * std
+                else:
+                    t = torch.randn(shape, generator=g) * std
+                    if name == "patch.w":
+                        t[:, self.cfg.vision.patch_dim:] = 0
+                arena.w(name).copy_(t.to(arena.w16.dtype))
+        self.train.sync_master_from_w16()
+
+    # ---- HF checkpoint <-> arena ----------------------------------------------------------------------------------
+    def load_hf_state_dict(self, sd):
+        """Accepts transformers 4.51 (`model.layers.*`, `visual.*`) and 5.x (`model.language_model.*`, `model.visual.*`) key layouts."""
+        cfg = self.cfg
+
+        def get(*cands):
+            for c in cands:
+                for k in sd:
+                    if k.endswith(c):
+                        return sd[k]
+            raise KeyError(cands)
+
+        tr, fz = self.train, self.frozen
+
+        def put(arena, name, t):
+            dst = arena.w(name)
+            assert tuple(dst.shape) == tuple(t.shape), (name, dst.shape, t.shape)
+            dst.copy_(t.to(dst.dtype))
+
+        put(tr, "embed", get("embed_tokens.weight"))
+        for i in range(cfg.text.n_layers):
+            p, h = "l%d." % i, "layers.%d." % i
+            put(tr, p + "ln1", get(h + "input_layernorm.weight"))
+            put(tr, p + "qkv.w", torch.cat([get(h + "self_attn.q_proj.weight"), get(h + "self_attn.k_proj.weight"), get(h + "self_attn.v_proj.weight")], 0))
+            put(tr, p + "qkv.b", torch.cat([get(h + "self_attn.q_proj.bias"), get(h + "self_attn.k_proj.bias"), get(h + "self_attn.v_proj.bias")], 0))
+            put(tr, p + "o.w", get(h + "self_attn.o_proj.weight"))
+            put(tr, p + "ln2", get(h + "post_attention_layernorm.weight"))
+            put(tr, p + "gu.w", torch.cat([get(h + "mlp.gate_proj.weight"), get(h + "mlp.up_proj.weight")], 0))
+            put(tr, p + "down.w", get(h + "mlp.down_proj.weight"))
+        put(tr, "norm", get("language_model.norm.weight", "model.norm.weight"))
+        if not cfg.text.tie_word_embeddings:
+            put(tr, "lm_head", get("lm_head.weight"))
+        put(tr, "merger.ln.w", get("merger.ln_q.weight"))
+        if cfg.vision.variant == "qwen2_vl":
+            put(tr, "merger.ln.b", get("merger.ln_q.bias"))
+        put(tr, "merger.fc1.w", get("merger.mlp.0.weight"))
+        put(tr, "merger.fc1.b", get("merger.mlp.0.bias"))
+        put(tr, "merger.fc2.w", get("merger.mlp.2.weight"))
+        put(tr, "merger.fc2.b", get("merger.mlp.2.bias"))
+        v = cfg.vision
+        pw = get("patch_embed.proj.weight").reshape(v.embed_dim, v.patch_dim)
+        pwp = torch.zeros(v.embed_dim, v.patch_dim_padded, dtype=pw.dtype)
+        pwp[:, : v.patch_dim] = pw
+        put(fz, "patch.w", pwp)
+        for i in range(v.depth):
+            p, h = "v%d." % i, "blocks.%d." % i
+            for a, b in (("n1", "norm1"), ("n2", "norm2"), ("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                put(fz, p + a + ".w", get(h + b + ".weight"))
+                put(fz, p + a + ".b", get(h + b + ".bias"))
+        self.train.sync_master_from_w16()
+
+    def export_hf_state_dict(self):
+        """Trainable + frozen weights under transformers-5.x key names (16-bit, like `stage3_gather_16bit_weights_on_model_save`)."""
+        cfg, tr, fz = self.cfg, self.train, self.frozen
+        t = cfg.text
+        sd = {"model.language_model.embed_tokens.weight": tr.w("embed")}
+        for i in range(t.n_layers):
+            p, h = "l%d." % i, "model.language_model.layers.%d." % i
+            qkvw, qkvb = tr.w(p + "qkv.w"), tr.w(p + "qkv.b")
+            gu = tr.w(p + "gu.w")
+            sd[h + "input_layernorm.weight"] = tr.w(p + "ln1")
+            for nm, a, b in (("q_proj", 0, t.q_dim), ("k_proj", t.q_dim, t.q_dim + t.kv_dim), ("v_proj", t.q_dim + t.kv_dim, t.qkv_dim)):
+                sd[h + "self_attn.%s.weight" % nm] = qkvw[a:b]
+                sd[h + "self_attn.%s.bias" % nm] = qkvb[a:b]
+            sd[h + "self_attn.o_proj.weight"] = tr.w(p + "o.w")
+            sd[h + "post_attention_layernorm.weight"] = tr.w(p + "ln2")
+            sd[h + "mlp.gate_proj.weight"] = gu[: t.intermediate]
+            sd[h + "mlp.up_proj.weight"] = gu[t.intermediate:]
+            sd[h + "mlp.down_proj.weight"] = tr.w(p + "down.w")
+        sd["model.language_model.norm.weight"] = tr.w("norm")
+        sd["lm_head.weight"] = self.lm_head_w()
+        sd["model.visual.merger.ln_q.weight"] = tr.w("merger.ln.w")
+        if cfg.vision.variant == "qwen2_vl":
+            sd["model.visual.merger.ln_q.bias"] = tr.w("merger.ln.b")
+        sd["model.visual.merger.mlp.0.weight"] = tr.w("merger.fc1.w")
+        sd["model.visual.merger.mlp.0.bias"] = tr.w("merger.fc1.b")
+        sd["model.visual.merger.mlp.2.weight"] = tr.w("merger.fc2.w")
+        sd["model.visual.merger.mlp.2.bias"] = tr.w("merger.fc2.b")
+        v = cfg.vision
+        sd["model.visual.patch_embed.proj.weight"] = fz.w("patch.w")[:, : v.patch_dim].reshape(v.embed_dim, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size)
+        for i in range(v.depth):
+            p, h = "v%d." % i, "model.visual.blocks.%d." % i
+            for a, b in (("n1", "norm1"), ("n2", "norm2"), ("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+                sd[h + b + ".weight"] = fz.w(p + a + ".w")
+                sd[h + b + ".bias"] = fz.w(p + a + ".b")
+        return {k: v_.detach().clone().contiguous().cpu() for k, v_ in sd.items()}

@@ -1,0 +1,99 @@
+"""Rollout: G sampled completions of one prompt, replacing `unwrapped_model.generate(..., num_return_sequences=G)`
+(reference src/time_r1/rl/timer1_trainer.py:568-578, GenerationConfig at :371-377).
+
+MI355X-first structure: the vision tower and the ~3.4k-token prompt are processed ONCE (the reference replicates
+them G times), the prompt's K/V live once in the cache and are shared by all G rows through the two-interval attention mask, and
+each decode step is a batch of G single-token rows whose GEMMs take the HBM-streaming skinny kernel.
+"""
+import numpy as np
+import torch
+
+from .positions import PackedLayout
+
+I32 = torch.int32
+
+
+class KVCache:
+    def __init__(self, ops, n_layers, kv_dim, s_cap):
+        self.s_cap = s_cap
+        self.layers = [(ops.zeros(s_cap, kv_dim), ops.zeros(kv_dim, s_cap)) for _ in range(n_layers)]
+
+
+class Rollout:
+    def __init__(self, engine, num_generations, max_completion_length, temperature=1.0, top_k=50, seed=1234, stop_at_eos=False):
+        self.eng = engine
+        self.G, self.C = int(num_generations), int(max_completion_length)
+        self.temperature, self.top_k, self.seed, self.stop_at_eos = float(temperature), int(top_k or 0), int(seed), bool(stop_at_eos)
+        self._cache = None
+        self.calls = 0
+
+    def _kv(self, layout):
+        t = self.eng.cfg.text
+        if self._cache is None or self._cache.s_cap != layout.S_cap:
+            self._cache = KVCache(self.eng.ops, t.n_layers, t.kv_dim, layout.S_cap)
+        return self._cache
+
+    def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta):
+        """prompt_ids: int32 device tensor [P]; prompt_pos3: numpy [3, P]; returns (tokens int32 [G, C] on device, layout)."""
+        eng, ops, cfg = self.eng, self.eng.ops, self.eng.cfg
+        t = cfg.text
+        G, C = self.G, self.C
+        P = int(prompt_ids.shape[0])
+        lay = PackedLayout(P, G, C)
+        kv = self._kv(lay)
+        seed = self.seed + 7919 * self.calls
+        self.calls += 1
+
+        # ---- prefill (prompt once, K/V written straight into the cache)
+        pos_p = ops.tensor(np.ascontiguousarray(prompt_pos3.astype(np.int32)), I32)
+        cos, sin = ops.mrope_table(pos_p, t.head_dim, t.mrope_section, t.rope_theta)
+        masks = [ops.tensor(a, I32) for a in lay.prompt_masks()]
+        h = eng.embed(arena, prompt_ids, vid_embeds, vid_rows)
+        hL, _ = eng.llm_fwd(arena, h, cos, sin, masks, save=False, kv_cache=kv.layers)
+        w_lm = eng.params.lm_head_w(arena)
+        hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
+        logits = ops.gemm_nt(hn, w_lm)  # [1, V]
+
+        tokens = ops.zeros(G, C, dtype=I32)
+        finished = ops.zeros(G, dtype=I32)
+        steps = ops.tensor(np.arange(C, dtype=np.int32), I32)
+        ops.sample_tokens(logits.expand(G, logits.shape[1]), self.temperature, self.top_k, seed, steps[0:1], tokens, finished,
+                          cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+
+        # ---- per-step tables (positions, slots, masks) built once
+        comp_pos = (P + delta + np.arange(C, dtype=np.int64))
+        pos_c = ops.tensor(np.repeat(comp_pos[None, :], 3, 0).astype(np.int32), I32)            # [3, C]
+        cos_c, sin_c = ops.mrope_table(pos_c, t.head_dim, t.mrope_section, t.rope_theta)          # [C, hd/2]
+        half = t.head_dim // 2
+        cos_all = cos_c.view(C, 1, half).expand(C, G, half).contiguous()
+        sin_all = sin_c.view(C, 1, half).expand(C, G, half).contiguous()
+        slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
+        pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
+        nsplit = max(1, min(64, (P + 63) // 64 + 2))
+        qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
+        scale = hd ** -0.5
+
+        for s in range(C - 1):
+            ids_s = tokens[:, s].contiguous()
+            slots = slots_all[s]
+            cs, sn = cos_all[s], sin_all[s]
+            h = ops.gather_rows(arena.w("embed"), ids_s)
+            for i in range(t.n_layers):
+                p = "l%d." % i
+                kc, vtc = kv.layers[i]
+                xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
+                qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
+                q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cs, sn)
+                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cs, sn)
+                ops.scatter_slots(k, kc, slots)
+                ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, slots=slots, out=vtc)
+                o, _ = ops.attn_fwd(q, kc, vtc, pre_d, lo_d, slots, t.n_heads, t.n_kv_heads, lay.M, hd, scale, nsplit=nsplit, need_lse=False)
+                h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
+                xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
+                a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
+                h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
+            hn, _, _ = ops.rmsnorm_fwd(h, arena.w("norm"), t.rms_eps, need_rstd=False)
+            logits = ops.gemm_nt(hn, w_lm)
+            ops.sample_tokens(logits, self.temperature, self.top_k, seed, steps[s + 1:s + 2], tokens, finished, cfg.eos_token_id,
+                              cfg.pad_token_id, self.stop_at_eos)
+        return tokens, lay
