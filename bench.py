@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""GRPO throughput benchmark (BASELINE.json metric): video-query samples/s and rollout tokens/s for Qwen2-VL GRPO post-training.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one GRPO micro-step on one synthetic prompt per GPU: vision tower -> G sampled completions (shared-prefix rollout)
+-> policy + reference log-probs -> rewards / group advantages -> loss gradient -> backward; the AdamW step (with the RCCL gradient
+average for N > 1) runs every `--ga` steps inside the timed region, exactly like the reference's gradient_accumulation_steps=2
+(scripts/posttrain/train_rl.sh:27).  Inputs (token ids, normalised patches) are resident in HBM before the timed region.
+Weights are random-init of the exact architecture; data is synthetic (no checkpoints / videos exist offline).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import time_r1_amd  # noqa: E402,F401
+from time_r1_amd.config import PRESETS  # noqa: E402
+from time_r1_amd.params import ModelParams  # noqa: E402
+from time_r1_amd.model import Engine  # noqa: E402
+from time_r1_amd.grpo import GRPOCore, eos_mask, group_advantages  # noqa: E402
+from time_r1_amd.synthetic import synthetic_prompt  # noqa: E402
+from time_r1_amd import rewards as R  # noqa: E402
+from time_r1_amd.dist import init_from_env, DataParallel  # noqa: E402
+
+# (frames -> video_grid_thw) for a 360x640 source under the reference's pixel budget
+GRIDS = {8: (4, 26, 46), 16: (8, 26, 46), 32: (16, 22, 38), 64: (32, 14, 28)}
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+_PIECES = ["<think>", "</think>", "<answer>", "</answer>", " to ", " and ", "1", "2", "3", "4", "5", "6", "7", "8", "9", "0", ".", " ", "the", "person",
+           "because", "\n", "step", "observe", "<timestep>", "</timestep>"]
+
+
+def fake_decode(ids_row):
+    """No tokenizer files exist offline: a fixed id -> text piece map so that the real reward callbacks run on real strings."""
+    return "".join(_PIECES[int(i) % len(_PIECES)] for i in ids_row)
+
+
+class Workload:
+    def __init__(self, args, ops, device, rank):
+        self.cfg = PRESETS[args.model]()
+        self.args, self.ops, self.rank = args, ops, rank
+        self.params = ModelParams(self.cfg, ops, init="none")
+        if hasattr(self.params, "init_random_device"):
+            self.params.init_random_device(seed=0)
+        self.eng = Engine(self.cfg, ops, self.params)
+        self.ref = self.params.train.clone_weights_only() if args.beta != 0.0 else None
+        self.core = GRPOCore(self.eng, self.ref, args.G, args.C, beta=args.beta, use_grpo=not args.clip_loss, temperature=1.0, top_k=50,
+                             seed=1234 + rank, rope_index_mode="hf4")
+        from time_r1_amd.optim import AdamWFlat
+        self.opt = AdamWFlat(self.params, ops, lr=1e-6, dp=DataParallel())
+        grid = GRIDS[args.frames] if args.model != "tiny" else (2, 4, 6)
+        self.grid = grid
+        self.prompts = []
+        v = self.cfg.vision
+        for i in range(args.n_prompts):
+            ids, pix, g = synthetic_prompt(self.cfg, grid, 64, 64, seed=100 * rank + i)
+            pp = ops.zeros(pix.shape[0], v.patch_dim_padded)
+            pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)   # staged in HBM before the timed region
+            self.prompts.append((ids, pp, g))
+        self.P = len(self.prompts[0][0])
+        self.reward_funcs = [R.iou_timestamp_reward_v2, R.format_reward]
+        self.micro = 0
+        self.ev = []
+
+    def step(self, timing=None):
+        a, core = self.args, self.core
+        ids, pix, grid = self.prompts[self.micro % len(self.prompts)]
+
+        def mark(name):
+            if timing is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                timing.append((name, e))
+        mark("start")
+        st = core.prepare(ids, pix, grid)
+        mark("vision")
+        toks = core.rollout(st)
+        mark("rollout")
+        core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
+        toks_host = toks.cpu().numpy()
+        completions = [fake_decode(r) for r in toks_host]
+        mask = eos_mask(toks_host, self.cfg.eos_token_id)
+        rew = torch.zeros(a.G, len(self.reward_funcs))
+        kw = dict(solution=[(2.0, 12.0)] * a.G, durations=[30.0] * a.G)
+        for j, fn in enumerate(self.reward_funcs):
+            rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
+        _, adv, _ = group_advantages(rew, a.G)
+        mark("logps")
+        out3, _ = core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga)
+        mark("backward")
+        self.micro += 1
+        if self.micro % a.ga == 0:
+            self.opt.step()
+        mark("optimizer")
+        self.last_tokens = int(mask.sum())
+        return out3
+
+
+def instrument_gemms(ops):
+    """Wrap ops.gemm_nt with HIP events (torch events on the current stream = the stream the kernels are launched on)."""
+    rec = []
+    orig = ops.gemm_nt
+
+    def timed(a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
+        M, K = a.shape
+        N = b.shape[0]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(a, b, bias=bias, residual=residual, out_f32=out_f32, out=out, accumulate=accumulate)
+        e1.record()
+        skinny = M <= 16 and not accumulate and K >= 256
+        rec.append((skinny, M, N, K, e0, e1))
+        return r
+    ops.gemm_nt = timed
+    return rec, orig
+
+
+def cpu_baseline(args, budget_note=True):
+    """Reference CPU path: the same engine driven by the CPU oracle ops (oracle/ref_ops.py, proven equal to the imported
+    reference on the golden fixtures) on the host cores. Bounded sample: the full-width architecture at depth 1 and depth 2
+    (LLM layers and ViT blocks), C_cpu decode steps; per-layer and fixed costs are separated by differencing and scaled to the
+    full depth / completion length. kind = "port"."""
+    from oracle.ref_ops import RefOps  # noqa: checker/baseline only
+    import copy
+    full = PRESETS[args.model]()
+    ops = RefOps(act_dtype=torch.float32)
+    C_cpu = min(args.C, 3)
+    grid = GRIDS[args.frames] if args.model != "tiny" else (2, 4, 6)
+    times = {}
+    t_all0 = time.time()
+    for depth in (1, 2):
+        cfg = copy.deepcopy(full)
+        cfg.text.n_layers = depth
+        cfg.vision.depth = depth
+        params = ModelParams(cfg, ops, init="none", optimizer_state=False)
+        params.init_random_device(seed=0)
+        eng = Engine(cfg, ops, params)
+        ref = params.train if args.beta != 0.0 else None   # same weights: timing only
+        core = GRPOCore(eng, ref, args.G, C_cpu, beta=args.beta, use_grpo=not args.clip_loss, seed=1, rope_index_mode="hf4")
+        ids, pix, g = synthetic_prompt(cfg, grid, 64, 64, seed=0)
+        t = {}
+        t0 = time.time(); st = core.prepare(ids, pix, g); t["vision"] = time.time() - t0
+        t0 = time.time(); toks = core.rollout(st); t["rollout"] = time.time() - t0
+        t0 = time.time(); core.forward_logps(st); t["logps"] = time.time() - t0
+        mask = torch.ones(args.G, C_cpu, dtype=torch.int32)
+        adv = torch.randn(args.G)
+        t0 = time.time(); core.loss_backward(st, mask, adv, 1.0); t["backward"] = time.time() - t0
+        times[depth] = t
+        del core, eng, params
+    per = {k: times[2][k] - times[1][k] for k in times[1]}
+    fix = {k: max(0.0, times[1][k] - per[k]) for k in times[1]}
+    nl, nv = full.text.n_layers, full.vision.depth
+    # rollout at depth d = prefill(d) + (C_cpu - 1) decode steps(d); decode cost is taken proportional to generated tokens
+    est = fix["vision"] + nv * per["vision"]
+    roll_scale = 1.0  # prefill dominates the measured rollout at C_cpu; decode tail extrapolated by the GEMV byte model below
+    est_roll = fix["rollout"] + nl * per["rollout"]
+    est += est_roll * roll_scale + fix["logps"] + nl * per["logps"] + fix["backward"] + nl * per["backward"]
+    # decode steps not covered by the sample: each streams all weights once on the host (fp32): measured copy bandwidth model
+    w_bytes = 4.0 * (nl * (full.text.hidden * (full.text.qkv_dim + full.text.q_dim) + 3 * full.text.hidden * full.text.intermediate)
+                     + full.text.vocab_size * full.text.hidden)
+    x = torch.empty(64 * 1024 * 1024)
+    t0 = time.time(); y = x * 2.0; bw = 2 * x.numel() * 4 / (time.time() - t0)
+    est += max(0, args.C - C_cpu) * w_bytes / bw
+    return {"value": 1.0 / est, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "CPU oracle ops fp32, %s width at depth 1 and 2 (LLM layers / ViT blocks), grid %s, G=%d, %d of %d decode steps; per-layer and "
+                      "fixed costs differenced and scaled to depth %d/%d, remaining decode steps priced at measured host stream bandwidth (%.1f GB/s); "
+                      "%.0f s of CPU work" % (full.name, str(grid), args.G, C_cpu, args.C, nl, nv, bw / 1e9, time.time() - t_all0),
+            "seconds_per_sample_est": est}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="qwen2-vl-7b", choices=list(PRESETS))
+    ap.add_argument("--frames", type=int, default=32, choices=list(GRIDS))
+    ap.add_argument("--G", type=int, default=8)
+    ap.add_argument("--C", type=int, default=200)
+    ap.add_argument("--beta", type=float, default=0.04)
+    ap.add_argument("--ga", type=int, default=2)
+    ap.add_argument("--clip-loss", action="store_true", help="PPO-clip branch (use_grpo=False) instead of the sequence-mean GRPO loss")
+    ap.add_argument("--n-prompts", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local, world = init_from_env("cuda")
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    from time_r1_amd.ops import HipOps
+    ops = HipOps(device)
+    wl = Workload(args, ops, device, rank)
+    dp = DataParallel()
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
+    timing = []
+    gen_tokens = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(timing)
+        gen_tokens += wl.last_tokens
+    torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dp.enabled:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+        gt = torch.tensor([gen_tokens], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(gt)
+        gen_tokens = int(gt.item())
+
+    phases = {}
+    for (n0, e0), (n1, e1) in zip(timing[:-1], timing[1:]):
+        if n1 != "start":
+            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1)
+    phases = {k: v / args.steps for k, v in phases.items()}
+
+    out = None
+    if rank == 0:
+        cfg = wl.cfg
+        value = args.steps * world / dt
+        out = {
+            "metric": "grpo_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "rollout_tokens_per_sec": (gen_tokens / world / args.steps) / (phases.get("rollout", 1e-9) / 1000.0) * world,
+            "generated_tokens_per_sec_end_to_end": gen_tokens / dt,
+            "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
+            "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
+                                   "loss=%s, grad-accum %d, 1 prompt/GPU/step" % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta,
+                                                                                    "ppo-clip" if args.clip_loss else "grpo", args.ga),
+                       "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1},
+        }
+    # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step
+    if rank == 0 and not args.no_roofline:
+        rec, orig = instrument_gemms(ops)
+        wl.step()
+        torch.cuda.synchronize()
+        ops.gemm_nt = orig
+        big_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if not s)
+        big_fl = sum(2.0 * M * N * K for s, M, N, K, e0, e1 in rec if not s)
+        big_n = sum(1 for r in rec if not r[0])
+        sk_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if s)
+        sk_by = sum(2.0 * (N * K + M * K + M * N) for s, M, N, K, e0, e1 in rec if s)
+        sk_n = sum(1 for r in rec if r[0])
+        mfma = {"kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms, "traffic": None}
+        mfma["frac"] = mfma["achieved"] / PEAK_BF16_TFLOPS
+        hbm = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
+               "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms, "traffic": None}
+        hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
+        dominant, other = (mfma, hbm) if big_ms >= sk_ms else (hbm, mfma)
+        out["roofline"] = dominant
+        out["roofline_secondary"] = other
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args)
+        except Exception as e:  # the GPU numbers above stay valid; say why the baseline is missing
+            out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(out))
+    dp.barrier()
+
+
+if __name__ == "__main__":
+    main()

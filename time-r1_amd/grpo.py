@@ -53,11 +53,14 @@ class GRPOCore:
                                               mode=self.rope_index_mode)
         v = cfg.vision
         pix = torch.as_tensor(pixel_values_videos)
-        assert pix.dim() == 2 and pix.shape[1] == v.patch_dim, pix.shape
         n_vid_tokens = sum(t * h * w for t, h, w in grid) // v.merge_unit
         assert n_vid_tokens == vid_rows.shape[0], "video pad tokens (%d) != merged patches (%d)" % (vid_rows.shape[0], n_vid_tokens)
-        pp = ops.zeros(pix.shape[0], v.patch_dim_padded)
-        pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)
+        if pix.dim() == 2 and pix.shape[1] == v.patch_dim_padded and pix.dtype == ops.act_dtype and pix.device == ops.device:
+            pp = pix        # already staged on the device in the kernels' layout (K padded to a multiple of 64)
+        else:
+            assert pix.dim() == 2 and pix.shape[1] == v.patch_dim, pix.shape
+            pp = ops.zeros(pix.shape[0], v.patch_dim_padded)
+            pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)
         st.feats = eng.vit_features(pp, grid)                     # frozen blocks: once per prompt (reference: 3 x G times)
         st.vid_embeds, st.merger_ctx = eng.merger_fwd(eng.params.train, st.feats, save=True)
         return st

@@ -50,7 +50,7 @@ def _specs_vit(cfg: ModelConfig):
 
 
 class Arena:
-    def __init__(self, ops, specs, with_optimizer_state):
+    def __init__(self, ops, specs, with_optimizer_state, with_grad=None):
         self.ops = ops
         self.specs = specs
         self.offsets = {}
@@ -61,8 +61,11 @@ class Arena:
         self.numel = off
         self.w16 = ops.zeros(off, dtype=ops.act_dtype)
         self.grad = self.master = self.m = self.v = None
-        if with_optimizer_state:
+        if with_grad is None:
+            with_grad = with_optimizer_state
+        if with_grad:
             self.grad = ops.zeros(off, dtype=torch.float32)
+        if with_optimizer_state:
             self.master = ops.zeros(off, dtype=torch.float32)
             self.m = ops.zeros(off, dtype=torch.float32)
             self.v = ops.zeros(off, dtype=torch.float32)
@@ -82,7 +85,7 @@ class Arena:
 
     def sync_master_from_w16(self):
         if self.master is not None:
-            self.master.copy_(self.w16.float())
+            self.master.copy_(self.w16)
 
     def clone_weights_only(self):
         """bf16-only snapshot (the frozen reference policy, reference timer1_trainer.py:295-307)."""
@@ -96,10 +99,10 @@ class Arena:
 class ModelParams:
     """Qwen2-VL parameters: `train` arena (LLM + merger) and `frozen` arena (ViT)."""
 
-    def __init__(self, cfg: ModelConfig, ops, seed=0, init="random"):
+    def __init__(self, cfg: ModelConfig, ops, seed=0, init="random", optimizer_state=True):
         self.cfg = cfg
         self.ops = ops
-        self.train = Arena(ops, _specs_llm(cfg) + _specs_merger(cfg), with_optimizer_state=True)
+        self.train = Arena(ops, _specs_llm(cfg) + _specs_merger(cfg), with_optimizer_state=optimizer_state, with_grad=True)
         self.frozen = Arena(ops, _specs_vit(cfg), with_optimizer_state=False)
         if init == "random":
             self.init_random(seed)
@@ -126,6 +129,21 @@ class ModelParams:
                     if name == "patch.w":
                         t[:, self.cfg.vision.patch_dim:] = 0
                 arena.w(name).copy_(t.to(arena.w16.dtype))
+        self.train.sync_master_from_w16()
+
+    def init_random_device(self, seed=0, std=0.02):
+        """Same distribution as init_random but generated on the device (7B-scale benchmarks: no 30 GB host staging)."""
+        dev = self.train.w16.device
+        g = torch.Generator(device=dev).manual_seed(seed) if dev.type == "cuda" else torch.Generator().manual_seed(seed)
+        for arena in (self.train, self.frozen):
+            chunk = 1 << 28
+            for a in range(0, arena.numel, chunk):
+                b = min(arena.numel, a + chunk)
+                arena.w16[a:b].copy_(torch.empty(b - a, dtype=torch.float32, device=dev).normal_(0, std, generator=g))
+            for name, shape in arena.specs:
+                if name.endswith("ln1") or name.endswith("ln2") or name == "norm" or name.endswith("ln.w") or name.endswith("n1.w") or name.endswith("n2.w"):
+                    arena.w(name).fill_(1.0)
+        self.frozen.w("patch.w")[:, self.cfg.vision.patch_dim:].zero_()
         self.train.sync_master_from_w16()
 
     # ---- HF checkpoint <-> arena ----------------------------------------------------------------------------------
