@@ -1,0 +1,66 @@
+"""GPU parity proper: the drop-in trainer on the HIP path (C ABI -> gfx950 kernels) against (a) the golden micro-steps captured from
+the unmodified reference and (b) the CPU oracle at a larger size.  bf16 activations vs an fp32 reference: logp within 0.06
+(SURVEY section 7 hard part 3), loss/KL within 5e-3 absolute, gradients within 6 % relative L2 error per tensor."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad  # noqa: E402
+
+
+def _make(fx, ops):
+    import time_r1_amd  # noqa: F401
+    from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig
+    from time_r1_amd import rewards as R
+    from oracle.text import FakeProcessor
+    cfg, pol, ref = golden_params(ops, fx)
+    args = GRPOConfig(output_dir="/tmp/tr1_gpu", num_generations=fx["G"], max_completion_length=fx["C"], beta=fx["beta"], use_grpo=fx["use_grpo"],
+                      rope_index_mode="hf5", temperature=1.0, save_strategy="no")
+    tr = TimeR1_Trainer(pol, [R.iou_timestamp_reward_v2, R.format_reward], [], args=args, processing_class=FakeProcessor(cfg), ops=ops)
+    if fx["beta"] != 0:
+        tr.ref_model.w16.copy_(ref.train.w16)
+    return cfg, tr
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_hip_trainer_vs_reference_golden(hip_ops, case):
+    fx = load_case(case)
+    cfg, tr = _make(fx, hip_ops)
+    frames = torch.randint(0, 256, (4, 3, 56, 84), generator=torch.Generator().manual_seed(fx["frames_seed"]), dtype=torch.uint8).float()
+    tr._video_inputs = lambda ex: ([frames], [2.0])
+    row = dict(fx["row"])
+    row["_forced_completion_ids"] = fx["completion_ids"].numpy()
+    loss = tr.compute_loss(tr.model, [row])
+    assert abs(float(loss) - float(fx["loss"])) < 5e-3
+    for k, v in fx["metrics"].items():
+        tol = 5e-3 if k in ("kl",) else (0.05 if k == "generation_entropy" else 1e-6)
+        assert abs(tr._metrics[k][0] - v[0]) <= tol, (k, tr._metrics[k], v)
+    assert tr.last_completions == fx["completions"]            # decode + rewards: exact
+    g = tr.params.train
+    for hk, gold in fx["grads"].items():
+        if hk in HF_GRAD_KEYS:
+            mine = pick_grad(cfg, g.g, hk).float().cpu()
+            rel = (mine - gold).norm() / gold.norm().clamp(min=1e-12)
+            assert rel < 0.06, (hk, float(rel))
+
+
+def test_hip_full_step_with_rollout_and_optimizer(hip_ops):
+    """Sampling + update end to end on the GPU: tokens valid, metrics finite, weights move, grads zeroed; two identical seeds agree."""
+    fx = load_case("grpo_beta")
+    outs = []
+    for _ in range(2):
+        cfg, tr = _make(fx, hip_ops)
+        frames = torch.randint(0, 256, (4, 3, 56, 84), generator=torch.Generator().manual_seed(3), dtype=torch.uint8).float()
+        tr._video_inputs = lambda ex: ([frames], [2.0])
+        w0 = tr.params.train.w16.clone()
+        loss = tr.compute_loss(tr.model, [dict(fx["row"])])
+        assert np.isfinite(float(loss)) and all(np.isfinite(v[0]) for v in tr._metrics.values())
+        assert len(tr.last_completions) == fx["G"]
+        gn = tr.optimizer.step(lr=1e-3)
+        assert float(gn) > 0 and float(tr.params.train.grad.abs().max()) == 0.0
+        assert not torch.equal(w0, tr.params.train.w16)
+        outs.append((tr.last_completions, tr.params.train.w16.clone()))
+    assert outs[0][0] == outs[1][0], "same seed -> same sampled completions (Philox keyed by seed,row,step)"
+    assert torch.equal(outs[0][1], outs[1][1]) or torch.allclose(outs[0][1].float(), outs[1][1].float(), atol=1e-2)

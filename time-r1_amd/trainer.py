@@ -1,0 +1,519 @@
+"""Drop-in trainer boundary: `TimeR1_Trainer` / `TimeR1_Trainer_ft` with the reference's constructor, `train()`, `compute_loss()`,
+`log()`, `save_model()` and callback protocol (reference src/time_r1/rl/timer1_trainer.py:184-438, :512-793; ft variant
+timer1_trainer_ft.py:551-563, :670-691, :789-842; wiring main.py:573-625), driving the MI355X engine instead of
+transformers.Trainer + trl + DeepSpeed (all absent offline, and replaced here by design).
+
+What is kept identical for the caller: constructor signature, dataset-row schema, identity collation (one prompt per device per
+micro-step, reference fact "only inputs[0]" :524/:548-551), processor calls (apply_chat_template / __call__ / batch_decode),
+reward callback protocol (prompts=, completions=, **row columns x G), metric keys, `state.global_step` / `trainer_state.json` /
+`checkpoint-N` layout used by main.py's resume arithmetic (:589-618), TrainerCallback hooks (on_epoch_end etc., main.py:520-539).
+What differs by construction: compute_loss also runs the backward (there is no autograd graph to return) and returns the loss value.
+"""
+import dataclasses
+import json
+import math
+import os
+import time
+import types
+from collections import defaultdict
+from typing import Any, Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .config import ModelConfig, PRESETS
+from .dist import DataParallel
+from .grpo import GRPOCore, eos_mask, group_advantages
+from .model import Engine
+from .optim import AdamWFlat
+from .params import ModelParams
+from . import vision_process as VP
+
+SYSTEM_PROMPT = "You are a video analysis expert."
+
+# Prompt wording is data the policy was trained with; kept verbatim (reference timer1_trainer.py:63-67, timer1_trainer_ft.py:61-85).
+QUESTION_TEMPLATE_TG_v1 = """To accurately pinpoint the event "[EVENT]" in the video, determine the precise time period of the event.
+
+Output your thought process within the <think> </think> tags, including analysis with either specific time ranges (xx.xx to xx.xx) in <timestep> </timestep> tags.
+
+Then, provide the start and end times (in seconds, precise to two decimal places) in the format "start time to end time" within the <answer> </answer> tags. For example: "12.54 to 17.83"."""
+
+QUESTION_TEMPLATE_TG_v2 = """To accurately pinpoint the event "[EVENT]" in the video, determine the precise time period of the event.
+
+Provide the start and end times (in seconds, precise to two decimal places) in the format "start time to end time" within the <answer> </answer> tags. For example: "12.54 to 17.83"."""
+
+QUESTION_TEMPLATE_TG_v3 = """Carefully analyze the video content to determine the precise time period during which "[EVENT]" occurs.  Within the `<think>` tags, provide a detailed description of your thought process, following the format below:
+```
+<think>
+Step-by-step Analysis:
+<timestep>Time period 1 (start time to end time)</timestep>: Describe the video content within this time period and determine if it is related to "[EVENT]".
+<timestep>Time period 2 (start time to end time)</timestep>: Describe the video content within this time period and determine if it is related to "[EVENT]".
+Based on the above analysis, state the precise time period during which "[EVENT]" occurs.
+</think>
+```
+Finally, in the `<answer>` tags, provide the start and end times of "[EVENT]" in the format "start time to end time" (in seconds, precise to two decimal places). For example: "12.54 to 17.83".
+```
+<answer>
+start time to end time
+</answer>
+```"""
+
+_TEMPLATES = {"v1": QUESTION_TEMPLATE_TG_v1, "v2": QUESTION_TEMPLATE_TG_v2, "v3": QUESTION_TEMPLATE_TG_v3}
+
+
+@dataclasses.dataclass
+class GRPOConfig:
+    """The training arguments the reference reads (trl.GRPOConfig + main.py:44-70 MY_GRPOConfig), as a plain dataclass."""
+    output_dir: str = "timer1-GRPO"
+    # GRPO
+    num_generations: int = 8
+    max_prompt_length: int = 512            # accepted, never enforced (reference quirk)
+    max_completion_length: int = 256
+    temperature: float = 0.9
+    top_k: Optional[int] = 50               # transformers 4.51 GenerationConfig default
+    beta: float = 0.04
+    use_grpo: bool = False
+    prompt_type: str = "v1"
+    fix_vit: bool = True
+    stop_at_eos: bool = False               # the reference's GenerationConfig carries no eos_token_id (a6): always C tokens
+    rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
+    # optimisation (HF TrainingArguments names)
+    learning_rate: float = 1e-6
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    lr_scheduler_type: str = "linear"
+    warmup_steps: int = 0
+    num_train_epochs: float = 1.0
+    max_steps: int = -1
+    per_device_train_batch_size: int = 1
+    gradient_accumulation_steps: int = 1
+    seed: int = 42
+    data_seed: Optional[int] = None
+    bf16: bool = True
+    # bookkeeping
+    logging_steps: int = 1
+    save_strategy: str = "steps"            # "steps" | "epoch" | "no"
+    save_steps: int = 500
+    save_only_model: bool = False
+    report_to: Any = None
+    resume_from_checkpoint: Optional[str] = None
+    # accepted for CLI compatibility; no effect on the MI355X engine (no recomputation / no DeepSpeed / no sliding window)
+    gradient_checkpointing: bool = False
+    deepspeed: Optional[str] = None
+    model_init_kwargs: Optional[dict] = None
+    slide_window: bool = False
+    max_window_layers: int = 2
+    sliding_window_length: int = 4096
+    attn_implementation: str = "flash_attention_2"
+
+
+class TrainerState:
+    def __init__(self):
+        self.global_step = 0
+        self.max_steps = 0
+        self.epoch = 0.0
+        self.num_train_epochs = 0
+        self.log_history = []
+        self.is_world_process_zero = True
+        self.is_local_process_zero = True
+
+    def to_json(self):
+        return {k: v for k, v in self.__dict__.items()}
+
+
+class TrainerControl:
+    def __init__(self):
+        self.should_training_stop = False
+        self.should_save = False
+        self.should_log = False
+        self.should_epoch_stop = False
+
+
+def _call(cb, name, *a, **k):
+    fn = getattr(cb, name, None)
+    if fn is not None:
+        r = fn(*a, **k)
+        return r
+
+
+def load_model_dir(path, ops):
+    """HF checkpoint directory (config.json + *.safetensors) -> (ModelConfig, ModelParams)."""
+    from safetensors.torch import load_file
+    hc = json.load(open(os.path.join(path, "config.json")))
+    tc = hc.get("text_config", hc)
+    vc = hc["vision_config"]
+    from .config import TextConfig, VisionConfig
+    rope = tc.get("rope_parameters") or tc.get("rope_scaling") or {}
+    text = TextConfig(vocab_size=tc["vocab_size"], hidden=tc["hidden_size"], intermediate=tc["intermediate_size"], n_layers=tc["num_hidden_layers"],
+                      n_heads=tc["num_attention_heads"], n_kv_heads=tc["num_key_value_heads"], head_dim=tc["hidden_size"] // tc["num_attention_heads"],
+                      rms_eps=tc.get("rms_norm_eps", 1e-6), rope_theta=float(rope.get("rope_theta", tc.get("rope_theta", 1e6))),
+                      mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))), tie_word_embeddings=bool(hc.get("tie_word_embeddings", tc.get("tie_word_embeddings", False))))
+    if "Qwen2_5" in "".join(hc.get("architectures", [])):
+        raise NotImplementedError("Qwen2.5-VL vision tower (windowed attention, RMSNorm, SwiGLU) is scheduled next; this build runs Qwen2-VL")
+    vision = VisionConfig(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_dim=int(vc["embed_dim"] * vc.get("mlp_ratio", 4)),
+                          out_hidden=vc["hidden_size"], patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
+                          spatial_merge_size=vc.get("spatial_merge_size", 2), in_channels=vc.get("in_channels", vc.get("in_chans", 3)))
+    cfg = ModelConfig(text=text, vision=vision, image_token_id=hc["image_token_id"], video_token_id=hc["video_token_id"],
+                      vision_start_token_id=hc["vision_start_token_id"], vision_end_token_id=hc["vision_end_token_id"],
+                      eos_token_id=tc.get("eos_token_id", hc.get("eos_token_id", 151645)), pad_token_id=tc.get("pad_token_id", hc.get("pad_token_id", 151643)) or 151643,
+                      name=os.path.basename(os.path.normpath(path)))
+    if isinstance(cfg.eos_token_id, list):
+        cfg.eos_token_id = cfg.eos_token_id[0]
+    sd = {}
+    for f in sorted(os.listdir(path)):
+        if f.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(path, f)))
+    params = ModelParams(cfg, ops, init="none")
+    params.load_hf_state_dict(sd)
+    return cfg, params
+
+
+class TimeR1_Trainer:
+    """GRPO post-training trainer (video decoded inside compute_loss, reference timer1_trainer.py:518-534)."""
+    _is_ft = False
+
+    def __init__(self, model, reward_funcs, metric_funcs, args: GRPOConfig = None, train_dataset=None, eval_dataset=None,
+                 processing_class=None, reward_processing_classes=None, callbacks=None, optimizers=(None, None), peft_config=None,
+                 max_pixels: Optional[int] = 12845056, min_pixels: Optional[int] = 3136, attn_implementation: str = "flash_attention_2",
+                 ops=None):
+        if args is None:
+            name = model if isinstance(model, str) else getattr(getattr(model, "cfg", None), "name", "model")
+            args = GRPOConfig(output_dir="%s-GRPO" % str(name).split("/")[-1])
+        self.args = args
+        if peft_config is not None:
+            raise NotImplementedError("LoRA/peft is not part of the MI355X engine (the reference scripts train full parameters)")
+        if not getattr(args, "fix_vit", True):
+            raise NotImplementedError("fix_vit=False (training the ViT blocks) is not implemented; every reference script sets fix_vit true")
+        mik = getattr(args, "model_init_kwargs", None) or {}
+        td = mik.get("torch_dtype")
+        if isinstance(td, str) and td not in ("auto", "bfloat16", "float16", "float32"):   # reference :221-235
+            raise ValueError("Invalid `torch_dtype` passed to `GRPOConfig`: %s" % td)
+        if ops is None:
+            from .ops import HipOps   # fails loudly without the HIP library / a GPU: there is no CPU fallback in the product
+            ops = HipOps("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+        self.ops = ops
+        # ---- model
+        if isinstance(model, str):
+            if model in PRESETS:
+                self.cfg = PRESETS[model]()
+                self.params = ModelParams(self.cfg, ops, seed=args.seed)
+            else:
+                self.cfg, self.params = load_model_dir(model, ops)
+        elif isinstance(model, ModelParams):
+            self.cfg, self.params = model.cfg, model
+        elif isinstance(model, ModelConfig):
+            self.cfg, self.params = model, ModelParams(model, ops, seed=args.seed)
+        else:
+            raise TypeError("model must be a checkpoint path, a preset name, a ModelConfig or a ModelParams")
+        self.model = self.params
+        self.engine = Engine(self.cfg, ops, self.params)
+        self.beta = args.beta
+        self.ref_model = self.params.train.clone_weights_only() if self.beta != 0.0 else None    # reference :295-307
+        # ---- processor
+        if processing_class is None:
+            if not isinstance(model, str) or model in PRESETS:
+                raise ValueError("processing_class is required when the model is not a checkpoint directory")
+            from transformers import AutoProcessor
+            processing_class = AutoProcessor.from_pretrained(model)
+            if hasattr(processing_class, "image_processor"):
+                processing_class.image_processor.max_pixels = max_pixels     # reference :317-319
+                processing_class.image_processor.min_pixels = min_pixels
+        self.processing_class = processing_class
+        pad = getattr(processing_class, "pad_token_id", None)
+        if pad is None and hasattr(processing_class, "tokenizer"):
+            pad = processing_class.tokenizer.pad_token_id
+            processing_class.pad_token_id = pad
+            processing_class.eos_token_id = processing_class.tokenizer.eos_token_id
+        # ---- rewards / metrics
+        if not isinstance(reward_funcs, list):
+            reward_funcs = [reward_funcs]
+        for f in reward_funcs:
+            if not callable(f):
+                raise NotImplementedError("reward models given as ids/modules are not supported; pass Python callables (main.py:416-420)")
+        self.reward_funcs = reward_funcs
+        self.metric_funcs = metric_funcs if isinstance(metric_funcs, list) else ([metric_funcs] if metric_funcs else [])
+        self.reward_processing_classes = reward_processing_classes or [None] * len(reward_funcs)
+        # ---- GRPO settings (reference :362-395)
+        self.max_prompt_length = args.max_prompt_length
+        self.max_completion_length = args.max_completion_length
+        self.num_generations = args.num_generations
+        self.use_grpo = args.use_grpo
+        self.prompt_type = args.prompt_type
+        self.epsilon_low = self.epsilon_high = 0.2          # hard-coded in the reference (:388-393)
+        self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
+        self.data_collator = lambda features: features       # identity (:360-361)
+        self.callbacks = list(callbacks or [])
+        self.dp = DataParallel()
+        self.accelerator = types.SimpleNamespace(device=ops.device, gather_for_metrics=self.dp.gather, num_processes=self.dp.world,
+                                                 is_main_process=self.dp.rank == 0, unwrap_model=lambda m: m)
+        self.core = GRPOCore(self.engine, self.ref_model, self.num_generations, self.max_completion_length, beta=self.beta,
+                             use_grpo=self.use_grpo, temperature=args.temperature, top_k=args.top_k, seed=args.seed + 1000 * self.dp.rank,
+                             rope_index_mode=args.rope_index_mode, stop_at_eos=args.stop_at_eos)
+        if optimizers[0] is not None:
+            raise NotImplementedError("custom torch optimizers are not supported; the engine owns a fused AdamW over its flat arena")
+        self.optimizer = AdamWFlat(self.params, ops, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
+                                   weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, dp=self.dp)
+        self._metrics = defaultdict(list)
+        self.state = TrainerState()
+        self.state.is_world_process_zero = self.dp.rank == 0
+        self.control = TrainerControl()
+        self.is_deepspeed_enabled = False
+        self._micro = 0
+
+    # ------------------------------------------------------------------------------------------------------ prompt building
+    def make_conversation_video(self, example):
+        if self.prompt_type not in _TEMPLATES or (not self._is_ft and self.prompt_type != "v1"):
+            raise ValueError("unsupported prompt_type %r" % self.prompt_type)
+        text = _TEMPLATES[self.prompt_type].replace("[EVENT]", example["problem"])
+        return [{"role": "user", "content": [{"type": "text", "text": text},
+                                             {"type": "video", "video": example["video_path"], "video_start": example.get("video_start"),
+                                              "video_end": example.get("video_end"), "total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}]}]
+
+    def _video_inputs(self, example):
+        """-> ([frames float T x 3 x H x W], [fps]). Non-ft: decode the whole file (the reference ignores video_start/end here)."""
+        ele = {"type": "video", "video": example["video_path"], "total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}
+        if "video_frames" in example:      # pre-decoded uint8/float frames supplied by the caller (no decoder offline)
+            ele["video"] = example["video_frames"]
+        _, vids, kw = VP.process_vision_info_v3([[{"role": "user", "content": [ele]}]], return_video_kwargs=True)
+        return vids, kw["fps"]
+
+    def _prepare_inputs(self, inputs):
+        return inputs
+
+    # ------------------------------------------------------------------------------------------------------ the micro-step
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
+        if return_outputs:
+            raise ValueError("The GRPOTrainer does not support returning outputs")
+        example = inputs[0]
+        G = self.num_generations
+        video_inputs, fps_inputs = self._video_inputs(example)
+        prompts = [self.make_conversation_video(ex) for ex in inputs]
+        prompts_text = [self.processing_class.apply_chat_template(p, tokenize=False, add_generation_prompt=True) for p in prompts]
+        prompt_inputs = self.processing_class(text=[prompts_text[0]], images=None, videos=[video_inputs[0]], fps=[fps_inputs[0]], padding=True,
+                                              return_tensors="pt", padding_side="left", add_special_tokens=False)
+        ids = np.asarray(prompt_inputs["input_ids"]).reshape(-1)
+        st = self.core.prepare(ids, prompt_inputs["pixel_values_videos"], np.asarray(prompt_inputs["video_grid_thw"]))
+        forced = example.get("_forced_completion_ids")       # test hook: teacher-forced completions instead of sampling
+        if forced is None:
+            tokens = self.core.rollout(st)
+        else:
+            from .positions import PackedLayout
+            st.layout = PackedLayout(st.P, G, self.max_completion_length)
+            tokens = st.completion_ids = self.ops.tensor(np.asarray(forced, dtype=np.int32), torch.int32)
+        self.core.forward_logps(st)                           # enqueued; the host work below overlaps with it on the GPU
+        comp_host = tokens.cpu().numpy()
+        mask_np = eos_mask(comp_host, self.processing_class.eos_token_id)
+        completions = self.processing_class.batch_decode(torch.as_tensor(comp_host), skip_special_tokens=True)
+        prompts_rep = [p for p in prompts for _ in range(G)]
+        reward_kwargs = {k: [] for k in inputs[0].keys() if k not in ("prompt", "completion") and not k.startswith("_")}
+        for k in reward_kwargs:
+            for ex in inputs:
+                reward_kwargs[k].extend([ex[k]] * G)
+        rewards_per_func = torch.zeros(len(prompts_rep), len(self.reward_funcs))
+        for i, fn in enumerate(self.reward_funcs):
+            rewards_per_func[:, i] = torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
+        rewards, advantages, std = group_advantages(rewards_per_func, G)
+        scale = 1.0 / max(1, self.args.gradient_accumulation_steps)     # HF divides the loss by GA (model_accepts_loss_kwargs=False, :421-424)
+        out3, row_len = self.core.loss_backward(st, self.ops.tensor(mask_np, torch.int32), self.ops.tensor(advantages.numpy(), torch.float32), scale)
+        # ---- metrics (reference :739-777; ft adds metrics/<fn> and clip ratios :789-842)
+        dev = self.ops.device
+        gather = self.dp.gather
+        mask_t = torch.as_tensor(mask_np)
+        self._metrics["completion_length"].append(gather(mask_t.sum(1).float().to(dev)).mean().item())
+        rpf = gather(rewards_per_func.to(dev)).mean(0)
+        for i, fn in enumerate(self.reward_funcs):
+            self._metrics["rewards/%s" % fn.__name__].append(rpf[i].item())
+        self._metrics["reward"].append(gather(rewards.to(dev)).mean().item())
+        self._metrics["reward_std"].append(gather(std.to(dev)).mean().item())
+        out3_h = out3.float().cpu()
+        if self.beta != 0.0:
+            self._metrics["kl"].append(gather(out3[1:2]).mean().item())
+        ent = st.entropy.float().cpu()
+        ent_mean = ((ent * mask_t).sum(1) / mask_t.sum(1).clamp(min=1)).mean()
+        self._metrics["generation_entropy"].append(gather(ent_mean.reshape(1).to(dev)).mean().item())
+        if self._is_ft:
+            for fn in self.metric_funcs:
+                vals = torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
+                self._metrics["metrics/%s" % fn.__name__].append(gather(vals.to(dev)).mean().item())
+            if not self.use_grpo:   # on-policy: ratio == 1, so no token is clipped (reference :820-842; undefined there for use_grpo)
+                for k in ("low_mean", "low_min", "high_mean", "high_max", "region_mean"):
+                    self._metrics["clip_ratio/" + k].append(0.0)
+        self.last_completions = completions
+        self.last_rewards = rewards
+        return out3_h[0]
+
+    # ------------------------------------------------------------------------------------------------------ training loop
+    def get_train_dataloader(self):
+        """Batches of `per_device_train_batch_size` dataset rows (identity collation), sharded rank-wise: perm(seed)[rank::world]."""
+        n = len(self.train_dataset)
+        bs = self.args.per_device_train_batch_size
+        seed = self.args.data_seed if self.args.data_seed is not None else self.args.seed
+        trainer = self
+
+        class _Loader:
+            def __init__(self):
+                self.epoch = 0
+                self.gen = torch.Generator().manual_seed(seed)
+
+            def __len__(self):
+                per_rank = len(range(trainer.dp.rank, n, trainer.dp.world))
+                return per_rank // bs
+
+            def __iter__(self):
+                perm = torch.randperm(n, generator=self.gen).tolist()
+                mine = perm[trainer.dp.rank::trainer.dp.world]
+                for i in range(0, len(mine) - bs + 1, bs):
+                    yield [trainer.train_dataset[j] for j in mine[i:i + bs]]
+        return _Loader()
+
+    def _lr(self, step):
+        a = self.args
+        base = a.learning_rate
+        if a.warmup_steps and step < a.warmup_steps:
+            return base * float(step) / float(max(1, a.warmup_steps))
+        if a.lr_scheduler_type == "constant":
+            return base
+        prog = float(step - a.warmup_steps) / float(max(1, self.state.max_steps - a.warmup_steps))
+        if a.lr_scheduler_type == "cosine":
+            return base * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+        return base * max(0.0, 1.0 - prog)     # linear (HF default)
+
+    def training_step(self, inputs):
+        return self.compute_loss(self.params, inputs)
+
+    def train(self, resume_from_checkpoint=None):
+        a = self.args
+        loader = self.get_train_dataloader()
+        ga = max(1, a.gradient_accumulation_steps)
+        steps_per_epoch = max(len(loader) // ga, 1)
+        if self.state.max_steps <= 0:
+            self.state.max_steps = a.max_steps if a.max_steps > 0 else math.ceil(a.num_train_epochs * steps_per_epoch)
+        n_epochs = math.ceil(a.num_train_epochs) if a.max_steps <= 0 else math.ceil(self.state.max_steps / steps_per_epoch)
+        self.state.num_train_epochs = n_epochs
+        start_step = 0
+        ckpt = resume_from_checkpoint if resume_from_checkpoint is not None else a.resume_from_checkpoint
+        if ckpt:
+            start_step = self._load_checkpoint(ckpt)
+        for cb in self.callbacks:
+            _call(cb, "on_train_begin", a, self.state, self.control)
+        t_start = time.time()
+        tr_loss, n_loss = 0.0, 0
+        skip_micro = start_step * ga
+        micro_seen = 0
+        self.control.should_training_stop = False
+        epoch = 0
+        while not self.control.should_training_stop and self.state.global_step < self.state.max_steps:
+            for batch in loader:
+                if micro_seen < skip_micro:       # resume: replay the sampler, skip consumed batches
+                    micro_seen += 1
+                    continue
+                micro_seen += 1
+                loss = self.training_step(batch)
+                tr_loss += float(loss)
+                n_loss += 1
+                self._micro += 1
+                if self._micro % ga == 0:
+                    gnorm = self.optimizer.step(lr=self._lr(self.state.global_step))
+                    self.state.global_step += 1
+                    self.state.epoch = epoch + (micro_seen // ga % steps_per_epoch) / steps_per_epoch
+                    for cb in self.callbacks:
+                        _call(cb, "on_step_end", a, self.state, self.control)
+                    if a.logging_steps and self.state.global_step % a.logging_steps == 0:
+                        self.log({"loss": round(tr_loss / max(n_loss, 1) / ga, 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
+                        tr_loss, n_loss = 0.0, 0
+                    if a.save_strategy == "steps" and a.save_steps and self.state.global_step % a.save_steps == 0:
+                        self._save_checkpoint()
+                    if self.state.global_step >= self.state.max_steps or self.control.should_training_stop:
+                        break
+            epoch += 1
+            self.state.epoch = float(epoch)
+            for cb in self.callbacks:
+                _call(cb, "on_epoch_end", a, self.state, self.control)
+            if a.save_strategy == "epoch":
+                self._save_checkpoint()
+            if epoch >= n_epochs:
+                break
+        for cb in self.callbacks:
+            _call(cb, "on_train_end", a, self.state, self.control)
+        return types.SimpleNamespace(global_step=self.state.global_step, training_loss=tr_loss / max(n_loss, 1), metrics={"train_runtime": time.time() - t_start})
+
+    # ------------------------------------------------------------------------------------------------------ logging / saving
+    def log(self, logs, start_time=None):
+        metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}     # reference :784-793
+        logs = {**logs, **metrics}
+        if self.state.epoch is not None:
+            logs["epoch"] = round(self.state.epoch, 4)
+        self.state.log_history.append({**logs, "step": self.state.global_step})
+        for cb in self.callbacks:
+            _call(cb, "on_log", self.args, self.state, self.control, logs=logs)
+        if self.dp.rank == 0:
+            print(logs, flush=True)
+        self._metrics.clear()
+
+    def save_model(self, output_dir=None, _internal_call=False):
+        """16-bit weights under transformers key names in one safetensors file (what the reference's ZeRO-3 save gathers, zero3.json:32)."""
+        output_dir = output_dir or self.args.output_dir
+        if self.dp.rank != 0:
+            return
+        os.makedirs(output_dir, exist_ok=True)
+        from safetensors.torch import save_file
+        save_file(self.params.export_hf_state_dict(), os.path.join(output_dir, "model.safetensors"), metadata={"format": "pt"})
+        json.dump(dataclasses.asdict(self.cfg), open(os.path.join(output_dir, "timer1_model_config.json"), "w"), indent=1)
+
+    def _save_checkpoint(self):
+        d = os.path.join(self.args.output_dir, "checkpoint-%d" % self.state.global_step)
+        self.save_model(d)
+        if self.dp.rank == 0:
+            json.dump({"global_step": self.state.global_step, "max_steps": self.state.max_steps, "epoch": self.state.epoch,
+                       "num_train_epochs": self.state.num_train_epochs, "log_history": self.state.log_history,
+                       "train_batch_size": self.args.per_device_train_batch_size}, open(os.path.join(d, "trainer_state.json"), "w"), indent=1)
+        if not self.args.save_only_model:
+            os.makedirs(d, exist_ok=True)
+            sd = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()}
+            sd["rollout_calls"] = self.core.roll.calls
+            sd["micro"] = self._micro
+            if self.ref_model is not None:
+                sd["ref_w16"] = self.ref_model.w16.cpu()
+            torch.save(sd, os.path.join(d, "optimizer_rank%d.pt" % self.dp.rank))
+        for cb in self.callbacks:
+            _call(cb, "on_save", self.args, self.state, self.control)
+        self.dp.barrier()
+
+    def _load_checkpoint(self, d):
+        from safetensors.torch import load_file
+        self.params.load_hf_state_dict(load_file(os.path.join(d, "model.safetensors")))
+        st = json.load(open(os.path.join(d, "trainer_state.json")))
+        self.state.global_step = int(st["global_step"])
+        self.state.log_history = st.get("log_history", [])
+        opt = os.path.join(d, "optimizer_rank%d.pt" % self.dp.rank)
+        if os.path.exists(opt):
+            sd = torch.load(opt, weights_only=False)
+            self.optimizer.load_state_dict({k: (v.to(self.ops.device) if torch.is_tensor(v) else v) for k, v in sd.items() if k in ("step", "master", "m", "v")})
+            self.core.roll.calls = sd.get("rollout_calls", 0)
+            self._micro = sd.get("micro", 0)
+            if self.ref_model is not None and "ref_w16" in sd:
+                self.ref_model.w16.copy_(sd["ref_w16"].to(self.ops.device))
+        return self.state.global_step
+
+    def push_to_hub(self, *a, **k):
+        raise RuntimeError("no network in this deployment; copy %s instead" % self.args.output_dir)
+
+    def create_model_card(self, *a, **k):
+        return None
+
+
+class TimeR1_Trainer_ft(TimeR1_Trainer):
+    """Fine-tune variant: dataset rows carry pre-decoded frames (`video_inputs`, `video_kwargs`), three prompt templates, shaping metrics
+    (reference timer1_trainer_ft.py:511-563, :670-691, :789-842; row format finetune.py:594-623)."""
+    _is_ft = True
+
+    def _video_inputs(self, example):
+        if example.get("video_inputs") is None:
+            return super()._video_inputs(example)
+        vids = example["video_inputs"]
+        kw = example.get("video_kwargs") or {"fps": [VP.FPS]}
+        vids = [torch.as_tensor(v).float() for v in vids]
+        return vids, kw["fps"]
