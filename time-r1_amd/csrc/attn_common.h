@@ -114,6 +114,57 @@ TR1_DEV void stage_T(char* lds, const bf16_t* srcT, int64_t ldT, int kvh, int64_
     }
 }
 
+// ---- split staging (issue the global loads early, write LDS late): hides HBM/L2 latency under the current tile's MFMAs.
+// A row-major 64 x D tile is D/8*64 16-byte chunks = (D/32) chunks per thread of a 256-thread block; same count for the D x 64 V^T tile.
+template <int D>
+struct TileRegs { u32x4_t k[D / 32]; u32x4_t v[D / 32]; };
+
+template <int D>
+TR1_DEV void tile_load_regs(TileRegs<D>& r, const bf16_t* K, int64_t k_ld, const bf16_t* VT, int64_t vt_ld, int kvh, int64_t kv0, int64_t n_slots,
+                            int d_real) {
+    // Branch-free: every lane issues all its loads from a clamped (always valid) address; out-of-range pieces are zeroed when
+    // the registers are written to LDS (tile_store_lds), so no s_waitcnt lands between the loads and the MFMAs they overlap.
+    constexpr int CH = D / 8;
+    const int64_t last_slot = n_slots - 1;
+    const int64_t last_chunk = (last_slot >> 3) << 3;
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int row = idx / CH, c = idx - row * CH;
+        int64_t slot = kv0 + row; if (slot > last_slot) slot = last_slot;
+        const int cc = (c * 8 < d_real) ? c * 8 : 0;
+        r.k[j] = *reinterpret_cast<const u32x4_t*>(K + slot * k_ld + (int64_t)kvh * d_real + cc);
+        int d = idx >> 3; if (d >= d_real) d = d_real - 1;
+        int64_t col = kv0 + (idx & 7) * 8; if (col > last_chunk) col = last_chunk;
+        r.v[j] = *reinterpret_cast<const u32x4_t*>(VT + ((int64_t)kvh * d_real + d) * vt_ld + col);
+    }
+}
+template <int D>
+TR1_DEV void tile_store_lds(const TileRegs<D>& r, char* lds_k, char* lds_vt, int64_t kv0, int64_t n_slots, int d_real) {
+    constexpr int CH = D / 8;
+    constexpr int KSTR = 2 * D + 16;
+    const u32x4_t zero = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j) {
+        const int idx = threadIdx.x + j * 256;
+        const int row = idx / CH, c = idx - row * CH;
+        const bool kok = (kv0 + row < n_slots) && (c * 8 < d_real);
+        *reinterpret_cast<u32x4_t*>(lds_k + row * KSTR + c * 16) = kok ? r.k[j] : zero;
+        const int d = idx >> 3, c2 = idx & 7;
+        const int64_t col = kv0 + c2 * 8;
+        u32x4_t v = r.v[j];
+        const int keep = (d < d_real) ? (int)min((int64_t)8, max((int64_t)0, n_slots - col)) : 0;   // valid slots in this chunk
+        if (keep < 8) {     // ragged tail / padding: stale cache slots must not leak (wave-divergent only on the last tile)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (2 * e >= keep) v[e] = 0;
+                else if (2 * e + 1 >= keep) v[e] &= 0xffffu;
+            }
+        }
+        *reinterpret_cast<u32x4_t*>(lds_vt + d * 144 + c2 * 16) = v;
+    }
+}
+
 TR1_DEV bool att_visible(int kv, int pre, int lo, int hi) { return (kv < pre) || (kv >= lo && kv <= hi); }
 
 // Which 64-key tiles can a set of rows with (max_pre, min_lo, max_hi) see?  [0, pre_tiles) U [start2, end2]

@@ -2,13 +2,14 @@
 #include "attn_common.h"
 
 // Block: 256 threads = 4 waves; wave owns 32 packed query rows (two 16-column blocks); block = 128 packed rows.
-// grid = (ceil(T*group/128), n_kv, nsplit)
+// grid = (ceil(T*group/128), n_kv, nsplit).  K / V^T tiles are double-buffered in LDS and staged through registers: the global
+// loads for tile i+2 are issued before tile i+1 is computed (guide: async-STAGE split), one barrier per tile.
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int KSTR = 2 * D + 16;
-    __shared__ __attribute__((aligned(16))) char lds_k[ATT_KV * KSTR];
-    __shared__ __attribute__((aligned(16))) char lds_vt[D * 144];
-    __shared__ int lds_meta[4][3];
+    constexpr int KBYTES = ATT_KV * KSTR, VBYTES = D * 144, BUF = KBYTES + VBYTES;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];      // [2][K tile | V^T tile] + meta
+    int* lds_meta = reinterpret_cast<int*>(dyn_lds + 2 * BUF);          // [4][3]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y, split = blockIdx.z;
     const int64_t nR = (int64_t)p.T * p.group;
@@ -31,12 +32,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int o = 1; o < 16; o <<= 1) {
         wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
     }
-    if (lane == 0) { lds_meta[wave][0] = wmaxpre; lds_meta[wave][1] = wminlo; lds_meta[wave][2] = wmaxhi; }
+    if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
     __syncthreads();
     int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w][0]); bminlo = min(bminlo, lds_meta[w][1]); bmaxhi = max(bmaxhi, lds_meta[w][2]); }
+    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
     const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
+    // a wave whose 32 rows are all out of range (decode: 56 live rows in a 128-row tile) only helps staging
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(R0 < nR)) != 0;
 
     // Q fragments (B operand): Q[q = u][d = ks*32 + g*8 .. +8]
     bf16x8_t qf[2][D / 32];
@@ -52,64 +55,100 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int dt = 0; dt < D / 16; ++dt) { o[dt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; o[dt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     float m[2] = {NEG_INF, NEG_INF}, l[2] = {0.f, 0.f};
 
-    for (int i = split; i < tr.n_rel; i += p.nsplit) {
-        const int kv0 = att_tile_at(tr, i) * ATT_KV;
-        __syncthreads();
-        stage_rows<D, ATT_KV>(lds_k, p.K, p.k_ld, (int64_t)kvh * p.d_real, kv0, p.n_slots, p.d_real);
-        stage_T<D>(lds_vt, p.VT, p.vt_ld, kvh, kv0, p.n_slots, p.d_real);
-        __syncthreads();
+    const int n_my = (split < tr.n_rel) ? (tr.n_rel - split + p.nsplit - 1) / p.nsplit : 0;
+    TileRegs<D> regs;
+    if (n_my > 0) {
+        tile_load_regs<D>(regs, p.K, p.k_ld, p.VT, p.vt_ld, kvh, (int64_t)att_tile_at(tr, split) * ATT_KV, p.n_slots, p.d_real);
+        tile_store_lds<D>(regs, dyn_lds, dyn_lds + KBYTES, (int64_t)att_tile_at(tr, split) * ATT_KV, p.n_slots, p.d_real);
+        if (n_my > 1)
+            tile_load_regs<D>(regs, p.K, p.k_ld, p.VT, p.vt_ld, kvh, (int64_t)att_tile_at(tr, split + p.nsplit) * ATT_KV, p.n_slots, p.d_real);
+    }
+    __syncthreads();
 
-        f32x4_t s[4][2];
+    for (int it = 0; it < n_my; ++it) {
+        const int kv0 = att_tile_at(tr, split + it * p.nsplit) * ATT_KV;
+        const char* lds_k = dyn_lds + (it & 1) * BUF;
+        const char* lds_vt = lds_k + KBYTES;
+        if (wave_active) {
+            f32x4_t s[4][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; s[kt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+            for (int kt = 0; kt < 4; ++kt) { s[kt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; s[kt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) {
+            for (int ks = 0; ks < D / 32; ++ks) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
-                s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
-                s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
-            }
-        }
-        bf16x8_t pf[2][2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            float mx = NEG_INF;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kv = kv0 + kt * 16 + g * 4 + r;
-                    const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
-                    const float v = ok ? s[kt][cb][r] * p.scale_log2 : NEG_INF;
-                    s[kt][cb][r] = v; mx = fmaxf(mx, v);
+                for (int kt = 0; kt < 4; ++kt) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+                    s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+                    s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m[cb], mx);
-            const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
-            const float alpha = exp2f(m[cb] - m_safe);
-            float rs = 0.f;
+            }
+            bf16x8_t pf[2][2];
+            // Tiles that every row of this wave sees completely (all shared-prefix tiles of completion rows, everything below the
+            // diagonal of prompt rows) skip the per-element visibility test - a wave-uniform branch.
+            bool full = kv0 + ATT_KV <= p.n_slots;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int cb = 0; cb < 2; ++cb)
+                full = full && (!valid[cb] || (kv0 + ATT_KV - 1 < pre[cb]) || (kv0 >= lo[cb] && kv0 + ATT_KV - 1 <= hi[cb]));
+            const bool wave_full = __all(full);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][cb][r] - m_safe); s[kt][cb][r] = e; rs += e; }
-            rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
-            l[cb] = l[cb] * alpha + rs; m[cb] = m_new;
+            for (int cb = 0; cb < 2; ++cb) {
+                float mx = NEG_INF;
+                // max over RAW scores (scale > 0 commutes with max); the scale is folded into the exp2 argument as one fma
+                if (wave_full) {
 #pragma unroll
-            for (int dt = 0; dt < D / 16; ++dt) o[dt][cb] *= alpha;
-            pf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
-            pf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
-        }
+                    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) {
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][cb][r]);
+                } else {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const char* base = lds_vt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
-                const bf16x8_t vf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
-                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][0], o[dt][0], 0, 0, 0);
-                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][1], o[dt][1], 0, 0, 0);
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kv = kv0 + kt * 16 + g * 4 + r;
+                            const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
+                            const float v = ok ? s[kt][cb][r] : NEG_INF;
+                            s[kt][cb][r] = v; mx = fmaxf(mx, v);
+                        }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m[cb], mx * p.scale_log2);
+                const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m[cb] - m_safe);
+                float rs = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][cb][r], p.scale_log2, -m_safe));
+                        s[kt][cb][r] = e; rs += e;
+                    }
+                rs += __shfl_xor(rs, 16, 64); rs += __shfl_xor(rs, 32, 64);
+                l[cb] = l[cb] * alpha + rs; m[cb] = m_new;
+                if (!__all(alpha == 1.0f)) {   // exact: the running maximum did not move for any row of the wave -> no rescale needed
+#pragma unroll
+                    for (int dt = 0; dt < D / 16; ++dt) o[dt][cb] *= alpha;
+                }
+                pf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
+                pf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const char* base = lds_vt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
+                    const bf16x8_t vf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
+                    o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][0], o[dt][0], 0, 0, 0);
+                    o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][1], o[dt][1], 0, 0, 0);
+                }
             }
         }
+        if (it + 1 < n_my) {
+            char* nk = dyn_lds + ((it + 1) & 1) * BUF;
+            tile_store_lds<D>(regs, nk, nk + KBYTES, (int64_t)att_tile_at(tr, split + (it + 1) * p.nsplit) * ATT_KV, p.n_slots, p.d_real);
+            if (it + 2 < n_my)
+                tile_load_regs<D>(regs, p.K, p.k_ld, p.VT, p.vt_ld, kvh, (int64_t)att_tile_at(tr, split + (it + 2) * p.nsplit) * ATT_KV, p.n_slots, p.d_real);
+        }
+        __syncthreads();
     }
 
     // ---- epilogue. Lane holds O^T[d = dt*16 + g*4 + r][q = u].
@@ -134,6 +173,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         const int64_t nRpad = (int64_t)gridDim.x * 128;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
+            if (!valid[cb]) continue;
             const int64_t R = R0 + cb * 16 + u;
             const int64_t slot = ((int64_t)split * p.n_kv + kvh) * nRpad + R;
             float* op = p.Opart + slot * D;
@@ -144,31 +184,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-// Merge split-KV partials: one thread per (packed row, 4 features).
+// Merge split-KV partials. Block = 256 threads = 8 packed rows x 32 lanes; each lane owns D/32 groups of 4 features.
+// The (m, l) statistics of the block's rows are staged in LDS first so the split loop carries no dependent global loads.
 template <int D>
-__global__ void attn_combine_kernel(AttnParams p, int64_t nRpad) {
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t nRpad) {
+    __shared__ float sm_m[8][64], sm_l[8][64];
     const int64_t nR = (int64_t)p.T * p.group;
     const int kvh = blockIdx.y;
-    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t R = idx / (D / 4); const int d = (int)(idx - R * (D / 4)) * 4;
+    const int rl = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int64_t Rb = (int64_t)blockIdx.x * 8;
+    for (int i = threadIdx.x; i < 8 * p.nsplit; i += 256) {
+        const int r = i / p.nsplit, s = i - r * p.nsplit;
+        const int64_t R = Rb + r;
+        const int64_t slot = ((int64_t)s * p.n_kv + kvh) * nRpad + R;
+        sm_m[r][s] = (R < nR) ? p.mpart[slot] : NEG_INF;
+        sm_l[r][s] = (R < nR) ? p.lpart[slot] : 0.f;
+    }
+    __syncthreads();
+    const int64_t R = Rb + rl;
     if (R >= nR) return;
     float M = NEG_INF;
-    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.mpart[((int64_t)s * p.n_kv + kvh) * nRpad + R]);
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, sm_m[rl][s]);
     const float Ms = (M == NEG_INF) ? 0.f : M;
-    float L = 0.f; f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.nsplit; ++s) {
-        const int64_t slot = ((int64_t)s * p.n_kv + kvh) * nRpad + R;
-        const float w = exp2f(p.mpart[slot] - Ms);
-        L += w * p.lpart[slot];
-        acc += w * *reinterpret_cast<const f32x4_t*>(p.Opart + slot * D + d);
-    }
+    float L = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) L += exp2f(sm_m[rl][s] - Ms) * sm_l[rl][s];
     const float inv = L > 0.f ? 1.f / L : 0.f;
     const int64_t t = R / p.group; const int hq = (int)(R - t * p.group);
-    if (d < p.d_real) {
-        u32x2_t w = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
-        *reinterpret_cast<u32x2_t*>(p.O + t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real + d) = w;
+    bf16_t* orow = p.O + t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real;
+#pragma unroll
+    for (int j = 0; j < (D + 127) / 128; ++j) {
+        const int d = (c + j * 32) * 4;
+        if (d >= D) break;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s = 0; s < p.nsplit; ++s) {
+            const int64_t slot = ((int64_t)s * p.n_kv + kvh) * nRpad + R;
+            acc += exp2f(sm_m[rl][s] - Ms) * *reinterpret_cast<const f32x4_t*>(p.Opart + slot * D + d);
+        }
+        if (d < p.d_real) {
+            u32x2_t w = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
+            *reinterpret_cast<u32x2_t*>(orow + d) = w;
+        }
     }
-    if (d == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
+    if (c == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
 }
 
 // out[(kvh*d + dd) * ld_out + t*group + hq] = in[t*ld_in + (kvh*group + hq)*d + dd] ; columns [T*group, ld_out) zero-filled
@@ -213,11 +271,22 @@ __global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_
     }
 }
 
+template <int D>
+static void launch_fwd(dim3 grid, hipStream_t s, const AttnParams& p) {
+    const size_t dyn = 2 * (ATT_KV * (2 * D + 16) + D * 144) + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), dyn, s, p);
+}
+
 static int attn_check(const AttnParams& p, int d_pad) {
     TR1_CHECK_ARG(d_pad == 32 || d_pad == 64 || d_pad == 96 || d_pad == 128, "attention: padded head dim must be 32/64/96/128");
     TR1_CHECK_ARG(p.d_real % 8 == 0 && p.d_real <= d_pad && p.d_real > d_pad - 32, "attention: head dim must be a multiple of 8");
     TR1_CHECK_ARG(p.q_ld % 8 == 0 && p.k_ld % 8 == 0 && p.o_ld % 4 == 0, "attention: leading dims must be multiples of 8");
-    TR1_CHECK_ARG(p.group >= 1 && p.n_kv >= 1 && p.nsplit >= 1, "attention: bad group/n_kv/nsplit");
+    TR1_CHECK_ARG(p.group >= 1 && p.n_kv >= 1 && p.nsplit >= 1 && p.nsplit <= 64, "attention: bad group/n_kv/nsplit (nsplit <= 64)");
     return 0;
 }
 
@@ -245,13 +314,13 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     dim3 grid(qtiles, (unsigned)n_kv, (unsigned)nsplit);
     hipStream_t s = (hipStream_t)stream;
     switch (d_pad) {
-        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, s, p); break;
-        case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, s, p); break;
-        case 96: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, s, p); break;
+        case 32: launch_fwd<32>(grid, s, p); break;
+        case 64: launch_fwd<64>(grid, s, p); break;
+        case 96: launch_fwd<96>(grid, s, p); break;
+        default: launch_fwd<128>(grid, s, p); break;
     }
     if (nsplit > 1) {
-        dim3 cg((unsigned)((nR * (d_pad / 4) + 255) / 256), (unsigned)n_kv);
+        dim3 cg((unsigned)((nR + 7) / 8), (unsigned)n_kv);
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;
             case 64: hipLaunchKernelGGL(attn_combine_kernel<64>, cg, dim3(256), 0, s, p, nRpad); break;

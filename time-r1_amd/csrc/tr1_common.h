@@ -16,14 +16,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 TR1_DEV float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
-// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
-TR1_DEV bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even via the gfx950 hardware conversion (v_cvt_pk_bf16_f32; the compiler selects it for __bf16 casts),
+// same rounding as torch's float->bfloat16 cast
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native_t;
+TR1_DEV bf16_t f2bf(float f) { const __bf16 b = (__bf16)f; return __builtin_bit_cast(bf16_t, b); }
+TR1_DEV unsigned pack2bf(float lo, float hi) {
+    const bf16x2_native_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
 }
-TR1_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 TR1_DEV float bflo(unsigned w) { return __uint_as_float(w << 16); }
 TR1_DEV float bfhi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks on one MI355X (HIP events on the launch stream). Usage: python tools/microbench.py <what> [...]
+   what: skinny | gemm | attn_decode | attn_train | small | sampler | all"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import time_r1_amd  # noqa: E402,F401
+from time_r1_amd.ops import HipOps  # noqa: E402
+
+ops = HipOps("cuda:0")
+BF = torch.bfloat16
+
+
+def timeit(fn, reps=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+def rnd(*s):
+    return (torch.randn(*s, device="cuda") * 0.5).to(BF)
+
+
+def skinny():
+    print("== decode GEMM (M rows x W[N,K]) : us, GB/s")
+    for M in (8, 16):
+        for N, K in [(4608, 3584), (3584, 3584), (37888, 3584), (3584, 18944), (152064, 3584), (2048, 1536), (17920, 1536), (1536, 8960)]:
+            # rotate over several weight copies so the stream really comes from HBM, not the 256 MB Infinity Cache
+            ncopy = max(1, int(600e6 // (N * K * 2)))
+            ws = [rnd(N, K) for _ in range(min(ncopy, 8))]
+            x = rnd(M, K)
+            i = [0]
+
+            def f():
+                ops.gemm_nt(x, ws[i[0] % len(ws)])
+                i[0] += 1
+            us = timeit(f, reps=40)
+            print("M=%2d N=%6d K=%6d  %8.1f us  %7.1f GB/s" % (M, N, K, us, (N * K * 2 + M * K * 2 + M * N * 2) / us / 1e3))
+
+
+def gemm():
+    print("== training GEMM: us, TFLOP/s")
+    for M, N, K in [(5074, 4608, 3584), (5074, 3584, 3584), (5074, 37888, 3584), (5074, 3584, 18944), (3474, 37888, 3584), (1600, 152064, 3584),
+                    (3584, 18944, 5120), (37888, 3584, 5120), (13376, 3840, 1280), (13376, 5120, 1280), (13376, 1280, 5120), (4096, 4096, 4096), (8192, 8192, 8192)]:
+        a, b = rnd(M, K), rnd(N, K)
+        us = timeit(lambda: ops.gemm_nt(a, b), reps=10, warm=2)
+        print("M=%6d N=%6d K=%6d  %9.1f us  %7.1f TF" % (M, N, K, us, 2.0 * M * N * K / us / 1e6))
+    a, b = rnd(3584, 5120), rnd(18944, 5120)
+    out = torch.zeros(3584, 18944, device="cuda")
+    us = timeit(lambda: ops.gemm_nt(a, b, out_f32=True, out=out, accumulate=True), reps=10, warm=2)
+    print("wgrad f32 accumulate 3584x18944x5120  %9.1f us  %7.1f TF" % (us, 2.0 * 3584 * 18944 * 5120 / us / 1e6))
+
+
+def attn_decode():
+    import numpy as np
+    print("== decode attention over the KV cache (7B: 28 q heads / 4 kv, hd 128, P=3474, G=8, C=200): us per layer")
+    P, G, C, nh, nkv, hd = 3474, 8, 200, 28, 4, 128
+    S = P + G * C
+    Scap = (S + 63) // 64 * 64
+    k, vt, q = rnd(Scap, nkv * hd), rnd(nkv * hd, Scap), rnd(G, nh * hd)
+    step = 100
+    pre = torch.full((G,), P, dtype=torch.int32, device="cuda")
+    lo = (P + torch.arange(G) * C).int().cuda()
+    hi = (lo + step).int()
+    for ns in (1, 2, 4, 8, 14, 28, 57):
+        us = timeit(lambda: ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=ns, need_lse=False), reps=100)
+        print("nsplit=%2d  %7.1f us" % (ns, us))
+
+
+def attn_train():
+    print("== packed training attention fwd/bwd (7B config 3): ms")
+    from time_r1_amd.positions import PackedLayout
+    P, G, C, nh, nkv, hd = 3474, 8, 200, 28, 4, 128
+    lay = PackedLayout(P, G, C)
+    M = lay.M
+    pre, lo, hi = [torch.tensor(a).cuda() for a in lay.masks()]
+    q, k, v, do = rnd(M, nh * hd), rnd(M, nkv * hd), rnd(M, nkv * hd), rnd(M, nh * hd)
+    vt = ops.pack_transpose(v, nkv, nkv, hd)
+    us = timeit(lambda: ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, M, hd, hd ** -0.5), reps=10, warm=2)
+    o, lse = ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, M, hd, hd ** -0.5)
+    vis = float((P * (P + 1) / 2 + G * (C * P + C * (C + 1) / 2)))
+    fl = 4.0 * vis * hd * nh
+    print("fwd %8.2f ms  %6.1f TF (visible pairs only)" % (us / 1e3, fl / us / 1e6))
+    us = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, pre, lo, hi, nh, nkv, M, hd, hd ** -0.5), reps=5, warm=1)
+    print("bwd %8.2f ms  %6.1f TF (2.5x fwd flops)" % (us / 1e3, 2.5 * fl / us / 1e6))
+
+
+def small():
+    print("== small decode-step kernels (rows = 8): us")
+    x, w = rnd(8, 3584), rnd(3584)
+    print("rmsnorm_fwd [8,3584]      %6.1f" % timeit(lambda: ops.rmsnorm_fwd(x, w, 1e-6, need_rstd=False), reps=200))
+    gu = rnd(8, 2 * 18944)
+    print("swiglu_fwd  [8,2x18944]   %6.1f" % timeit(lambda: ops.swiglu_fwd(gu), reps=200))
+    qkv = rnd(8, 4608)
+    cos, sin = torch.rand(8, 64, device="cuda"), torch.rand(8, 64, device="cuda")
+    print("rope_apply q [8,28x128]   %6.1f" % timeit(lambda: ops.rope_apply(qkv[:, :3584], 28, 128, cos, sin), reps=200))
+    xx, ww = rnd(5074, 3584), rnd(3584)
+    us = timeit(lambda: ops.rmsnorm_fwd(xx, ww, 1e-6), reps=50)
+    print("rmsnorm_fwd [5074,3584]   %6.1f us  %6.1f GB/s" % (us, 2 * 5074 * 3584 * 2 / us / 1e3))
+    big = rnd(29376, 3584)
+    us = timeit(lambda: ops.rmsnorm_fwd(big, ww, 1e-6), reps=20)
+    print("rmsnorm_fwd [29376,3584]  %6.1f us  %6.1f GB/s" % (us, 2 * 29376 * 3584 * 2 / us / 1e3))
+    t = rnd(5074, 18944)
+    us = timeit(lambda: ops.transpose(t), reps=10)
+    print("transpose [5074,18944]    %6.1f us  %6.1f GB/s" % (us, 2 * 5074 * 18944 * 2 / us / 1e3))
+
+
+def sampler():
+    logits = rnd(8, 152064)
+    tok = torch.zeros(8, 4, dtype=torch.int32, device="cuda")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for k in (0, 50):
+        print("sample top_k=%2d [8,152064]  %6.1f us" % (k, timeit(lambda: ops.sample_tokens(logits, 1.0, k, 1, st, tok, None, 1, 0, False), reps=50)))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["all"]
+    for w in what:
+        for name in (["skinny", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+            globals()[name]()
