@@ -15,6 +15,7 @@
 //     row: the epilogue is two 16-byte bf16 stores (or four fp32 ones) per row, no LDS transpose.
 //   * 1-D grid with an XCD-aware, M-grouped tile order so the 32 blocks resident on one XCD share B panels in its L2.
 #include "tr1_common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -24,6 +25,7 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+TR1_DEV bf16x8_t zero_frag8() { u32x4_t w = {0, 0, 0, 0}; return __builtin_bit_cast(bf16x8_t, w); }
 TR1_DEV int keyA(int row) { return (row >> 1) & 7; }
 TR1_DEV int keyB(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
 
@@ -162,35 +164,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // step, so a 16-lane group covers one full 128-byte line per row; the k-order inside the MFMA is permuted the same
 // way for x (any k permutation is legal as long as A and B agree).
 // ------------------------------------------------------------------------------------------------------------------
-template <int UNROLL>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
-                                                          float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
-                                                          const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
-                                                          int64_t ldw, int64_t ldc, int64_t ldr) {
-    __shared__ __attribute__((aligned(16))) float red[4][16][17];
+template <int WAVES, int UNROLL, bool NT, bool HALFLINE, bool XPRED>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
+                                                                 float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
+                                                                 int64_t ldw, int64_t ldc, int64_t ldr) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 16;
     int64_t wrow = n0 + u; if (wrow >= N) wrow = N - 1;
-    const int xrow = (u < M) ? u : (M - 1);
-    const bf16_t* wp = W + wrow * ldw;
-    const bf16_t* xp = X + (int64_t)xrow * ldx;
-    // this wave's K range, in steps of 64 elements (two MFMA k-steps)
+    const bool xlive = XPRED ? (u < M) : true;     // rows 8..15 of the MFMA B operand are padding when M = 8
+    constexpr int O2 = HALFLINE ? 32 : 8;          // element offset of the lane's second 16-byte piece within a 64-element step
+    const int goff = HALFLINE ? g * 8 : g * 16;
+    const bf16_t* wp = W + wrow * ldw + goff;
+    const bf16_t* xp = X + (int64_t)((u < M) ? u : (M - 1)) * ldx + goff;
+    // this wave's K range in steps of 64 elements (two MFMA k-steps: lane (u,g) takes k = g*8.. and 32+g*8.. of every step, so a
+    // 16-lane group reads 64 contiguous bytes of each W row per load instruction)
     const int64_t nsteps = K / 64;
-    const int64_t s_per = (nsteps + 3) / 4;
+    const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
     const int64_t s0 = wave * s_per;
     int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t zf = zero_frag8();
     int64_t s = s0;
     for (; s + UNROLL <= s1; s += UNROLL) {
         bf16x8_t wa[UNROLL][2], xa[UNROLL][2];
 #pragma unroll
         for (int q = 0; q < UNROLL; ++q) {
-            const int64_t k = (s + q) * 64 + g * 16;
-            wa[q][0] = *reinterpret_cast<const bf16x8_t*>(wp + k);
-            wa[q][1] = *reinterpret_cast<const bf16x8_t*>(wp + k + 8);
-            xa[q][0] = *reinterpret_cast<const bf16x8_t*>(xp + k);
-            xa[q][1] = *reinterpret_cast<const bf16x8_t*>(xp + k + 8);
+            const int64_t k = (s + q) * 64;
+            if (NT) {   // streamed once: non-temporal
+                wa[q][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k));
+                wa[q][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k + O2));
+            } else {
+                wa[q][0] = *reinterpret_cast<const bf16x8_t*>(wp + k);
+                wa[q][1] = *reinterpret_cast<const bf16x8_t*>(wp + k + O2);
+            }
+            xa[q][0] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k) : zf;
+            xa[q][1] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + O2) : zf;
         }
 #pragma unroll
         for (int q = 0; q < UNROLL; ++q) {
@@ -199,9 +210,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
         }
     }
     for (; s < s1; ++s) {
-        const int64_t k = s * 64 + g * 16;
-        const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp + k), w1 = *reinterpret_cast<const bf16x8_t*>(wp + k + 8);
-        const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xp + k), x1 = *reinterpret_cast<const bf16x8_t*>(xp + k + 8);
+        const int64_t k = s * 64;
+        const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp + k);
+        const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(wp + k + O2);
+        const bf16x8_t x0 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k) : zf;
+        const bf16x8_t x1 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + O2) : zf;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc1, 0, 0, 0);
     }
@@ -209,15 +222,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][u][g * 4 + r] = acc0[r] + acc1[r];
     __syncthreads();
-    // 256 threads -> 16 (m) x 16 (n)
-    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
-    const int64_t n = n0 + nn;
-    if (m < M && n < N) {
-        float v = red[0][m][nn] + red[1][m][nn] + red[2][m][nn] + red[3][m][nn];
-        if (bias) v += bf2f(bias[n]);
-        if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
-        if (Cf32) Cf32[(int64_t)m * ldc + n] = v;
-        else C[(int64_t)m * ldc + n] = f2bf(v);
+    if (threadIdx.x < 256) {   // 16 (m) x 16 (n)
+        const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+        const int64_t n = n0 + nn;
+        if (m < M && n < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) v += red[w][m][nn];
+            if (bias) v += bf2f(bias[n]);
+            if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
+            if (Cf32) Cf32[(int64_t)m * ldc + n] = v;
+            else C[(int64_t)m * ldc + n] = f2bf(v);
+        }
     }
 }
 
@@ -232,8 +248,14 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     hipStream_t s = (hipStream_t)stream;
     if (M <= 16 && !accumulate && K >= 256) {
         dim3 grid((unsigned)((N + 15) / 16));
-        hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C,
-                           out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr);
+#define SK(WV, NTF, HL, XP)                                                                                                          \
+    hipLaunchKernelGGL((gemm_skinny_kernel<WV, 4, NTF, HL, XP>), grid, dim3(WV * 64), 0, s, (const bf16_t*)A, (const bf16_t*)B,     \
+                       out_f32 ? nullptr : (bf16_t*)C, out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, \
+                       (int)M, N, K, lda, ldb, ldc, ldr)
+        // measured on MI355X (tools/microbench.py skinny): half-line lane grouping and predicated x loads help, non-temporal
+        // loads hurt (-7..12 %), 8-way in-block split-K pays only for long K (the 18944-deep down projection)
+        if (K >= 8192) SK(8, false, true, true); else SK(4, false, true, true);
+#undef SK
         TR1_LAUNCH_CHECK();
     }
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
