@@ -71,9 +71,10 @@ class Workload:
         self.micro = 0
         self.ev = []
 
-    def step(self, timing=None):
+    def window(self, timing=None):
+        """`ga` micro-steps = one optimizer step. The rollouts of the window are decoded together (weights are constant inside an
+        accumulation window, so this is the reference's sequence of micro-steps with the decode GEMMs amortised over ga*G rows)."""
         a, core = self.args, self.core
-        ids, pix, grid = self.prompts[self.micro % len(self.prompts)]
 
         def mark(name):
             if timing is not None:
@@ -81,28 +82,35 @@ class Workload:
                 e.record()
                 timing.append((name, e))
         mark("start")
-        st = core.prepare(ids, pix, grid)
+        states = []
+        for j in range(a.ga):
+            ids, pix, grid = self.prompts[(self.micro + j) % len(self.prompts)]
+            states.append(core.prepare(ids, pix, grid))
         mark("vision")
-        toks = core.rollout(st)
+        if a.no_rollout_batching:
+            for st in states:
+                core.rollout(st)
+        else:
+            core.rollout_many(states)
         mark("rollout")
-        core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
-        toks_host = toks.cpu().numpy()
-        completions = [fake_decode(r) for r in toks_host]
-        mask = eos_mask(toks_host, self.cfg.eos_token_id)
-        rew = torch.zeros(a.G, len(self.reward_funcs))
-        kw = dict(solution=[(2.0, 12.0)] * a.G, durations=[30.0] * a.G)
-        for j, fn in enumerate(self.reward_funcs):
-            rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
-        _, adv, _ = group_advantages(rew, a.G)
-        mark("logps")
-        out3, _ = core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga)
-        mark("backward")
-        self.micro += 1
-        if self.micro % a.ga == 0:
-            self.opt.step()
+        self.last_tokens = 0
+        for st in states:
+            core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
+            toks_host = st.completion_ids.cpu().numpy()
+            completions = [fake_decode(r) for r in toks_host]
+            mask = eos_mask(toks_host, self.cfg.eos_token_id)
+            rew = torch.zeros(a.G, len(self.reward_funcs))
+            kw = dict(solution=[(2.0, 12.0)] * a.G, durations=[30.0] * a.G)
+            for j, fn in enumerate(self.reward_funcs):
+                rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
+            _, adv, _ = group_advantages(rew, a.G)
+            mark("logps")
+            core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga)
+            mark("backward")
+            self.micro += 1
+            self.last_tokens += int(mask.sum())
+        self.opt.step()
         mark("optimizer")
-        self.last_tokens = int(mask.sum())
-        return out3
 
 
 def instrument_gemms(ops):
@@ -192,6 +200,7 @@ def main():
     ap.add_argument("--n-prompts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     args = ap.parse_args()
 
     rank, local, world = init_from_env("cuda")
@@ -203,14 +212,15 @@ def main():
     wl = Workload(args, ops, device, rank)
     dp = DataParallel()
 
-    for _ in range(args.warmup):
-        wl.step()
+    assert args.steps % args.ga == 0 and args.warmup % args.ga == 0, "--steps and --warmup must be multiples of --ga (whole optimizer steps)"
+    for _ in range(args.warmup // args.ga):
+        wl.window()
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     timing = []
     gen_tokens = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step(timing)
+    for _ in range(args.steps // args.ga):
+        wl.window(timing)
         gen_tokens += wl.last_tokens
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -226,7 +236,7 @@ def main():
     for (n0, e0), (n1, e1) in zip(timing[:-1], timing[1:]):
         if n1 != "start":
             phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1)
-    phases = {k: v / args.steps for k, v in phases.items()}
+    phases = {k: v / args.steps for k, v in phases.items()}     # per micro-step (the rollout / vision phases are per window / ga)
 
     out = None
     if rank == 0:
@@ -242,14 +252,15 @@ def main():
             "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step" % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta,
                                                                                     "ppo-clip" if args.clip_loss else "grpo", args.ga),
-                       "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1},
+                       "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga},
         }
     # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step
     if rank == 0 and not args.no_roofline:
         rec, orig = instrument_gemms(ops)
-        wl.step()
+        wl.window()
         torch.cuda.synchronize()
         ops.gemm_nt = orig
+        nstep = float(args.ga)
         big_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if not s)
         big_fl = sum(2.0 * M * N * K for s, M, N, K, e0, e1 in rec if not s)
         big_n = sum(1 for r in rec if not r[0])
@@ -257,10 +268,10 @@ def main():
         sk_by = sum(2.0 * (N * K + M * K + M * N) for s, M, N, K, e0, e1 in rec if s)
         sk_n = sum(1 for r in rec if r[0])
         mfma = {"kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms, "traffic": None}
+                "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms / nstep, "traffic": None}
         mfma["frac"] = mfma["achieved"] / PEAK_BF16_TFLOPS
         hbm = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
-               "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms, "traffic": None}
+               "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms / nstep, "traffic": None}
         hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
         dominant, other = (mfma, hbm) if big_ms >= sk_ms else (hbm, mfma)
         out["roofline"] = dominant

@@ -245,9 +245,12 @@ class RefOps:
         o = (p @ vh).transpose(0, 1).reshape(T, n_heads * head_dim)
         return o, lse
 
-    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True):
+    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None):
         v = vt[:, :n_slots].float().t().contiguous()  # [S, n_kv*hd]
         o, lse = self._dense_attn(q.float(), k.float(), v, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale)
+        if out is not None:
+            out.copy_(self._a(o))
+            return out, (lse if need_lse else None)
         return self._a(o), (lse if need_lse else None)
 
     def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):

@@ -72,6 +72,14 @@ class GRPOCore:
         st.completion_ids = tokens        # int32 [G, C] on device
         return tokens
 
+    def rollout_many(self, states):
+        """Decode the prompts of one accumulation window together (weights are constant inside it): every weight byte streamed
+        from HBM serves len(states)*G rows. Sampling streams stay per prompt, so tokens equal the one-by-one rollout's."""
+        outs = self.roll.generate_many(self.eng.params.train, [(st.prompt_ids, st.vid_embeds, st.vid_rows, st.pos3_prompt, st.delta) for st in states])
+        for st, (tokens, lay) in zip(states, outs):
+            st.layout, st.completion_ids = lay, tokens
+        return [st.completion_ids for st in states]
+
     # ------------------------------------------------------------------------------------------------------- phase 3
     def _packed_inputs(self, st):
         ops, lay = self.ops, st.layout

@@ -251,11 +251,11 @@ class HipOps:
         assert slots.dtype == I32
         self.L.call("tr1_scatter_slots", _p(src), _ld(src), _p(dst), _ld(dst), _p(slots), src.shape[0], src.shape[1], self._s())
 
-    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True):
+    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None):
         self._chk(q, k, vt)
         assert pre.dtype == I32 and lo.dtype == I32 and hi.dtype == I32
         T = q.shape[0]
-        o = self.empty(T, n_heads * head_dim)
+        o = out if out is not None else self.empty(T, n_heads * head_dim)
         lse = self.empty(n_heads, T, dtype=F32) if need_lse else None
         ws, nws = None, 0
         if nsplit > 1:

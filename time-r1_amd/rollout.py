@@ -1,9 +1,11 @@
-"""Rollout: G sampled completions of one prompt, replacing `unwrapped_model.generate(..., num_return_sequences=G)`
+"""Rollout: G sampled completions per prompt, replacing `unwrapped_model.generate(..., num_return_sequences=G)`
 (reference src/time_r1/rl/timer1_trainer.py:568-578, GenerationConfig at :371-377).
 
 MI355X-first structure: the vision tower and the ~3.4k-token prompt are processed ONCE (the reference replicates
 them G times), the prompt's K/V live once in the cache and are shared by all G rows through the two-interval attention mask, and
-each decode step is a batch of G single-token rows whose GEMMs take the HBM-streaming skinny kernel.
+each decode step is a batch of single-token rows whose GEMMs take the HBM-streaming skinny kernel.  Decode is weight-bandwidth
+bound, so the prompts of one gradient-accumulation window (weights are constant inside it) are decoded TOGETHER: with GA = 2 and
+G = 8 every weight byte read from HBM serves 16 rows instead of 8.  Attention stays per prompt (own prefix, own KV cache).
 """
 import numpy as np
 import torch
@@ -24,76 +26,93 @@ class Rollout:
         self.eng = engine
         self.G, self.C = int(num_generations), int(max_completion_length)
         self.temperature, self.top_k, self.seed, self.stop_at_eos = float(temperature), int(top_k or 0), int(seed), bool(stop_at_eos)
-        self._cache = None
+        self._caches = {}
         self.calls = 0
 
-    def _kv(self, layout):
+    def _kv(self, slot, layout):
         t = self.eng.cfg.text
-        if self._cache is None or self._cache.s_cap != layout.S_cap:
-            self._cache = KVCache(self.eng.ops, t.n_layers, t.kv_dim, layout.S_cap)
-        return self._cache
+        c = self._caches.get(slot)
+        if c is None or c.s_cap != layout.S_cap:
+            c = KVCache(self.eng.ops, t.n_layers, t.kv_dim, layout.S_cap)
+            self._caches[slot] = c
+        return c
 
     def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta):
-        """prompt_ids: int32 device tensor [P]; prompt_pos3: numpy [3, P]; returns (tokens int32 [G, C] on device, layout)."""
+        """One prompt. prompt_ids: int32 device tensor [P]; prompt_pos3: numpy [3, P]; returns (tokens int32 [G, C] on device, layout)."""
+        return self.generate_many(arena, [(prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta)])[0]
+
+    def generate_many(self, arena, items):
+        """items: list of (prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta), decoded together. Returns [(tokens [G, C], layout)].
+        Each prompt keeps its own sampling stream (seed advances per prompt), so results do not depend on how prompts are batched."""
         eng, ops, cfg = self.eng, self.eng.ops, self.eng.cfg
         t = cfg.text
-        G, C = self.G, self.C
-        P = int(prompt_ids.shape[0])
-        lay = PackedLayout(P, G, C)
-        kv = self._kv(lay)
-        seed = self.seed + 7919 * self.calls
-        self.calls += 1
-
-        # ---- prefill (prompt once, K/V written straight into the cache)
-        pos_p = ops.tensor(np.ascontiguousarray(prompt_pos3.astype(np.int32)), I32)
-        cos, sin = ops.mrope_table(pos_p, t.head_dim, t.mrope_section, t.rope_theta)
-        masks = [ops.tensor(a, I32) for a in lay.prompt_masks()]
-        h = eng.embed(arena, prompt_ids, vid_embeds, vid_rows)
-        hL, _ = eng.llm_fwd(arena, h, cos, sin, masks, save=False, kv_cache=kv.layers)
-        w_lm = eng.params.lm_head_w(arena)
-        hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
-        logits = ops.gemm_nt(hn, w_lm)  # [1, V]
-
-        tokens = ops.zeros(G, C, dtype=I32)
-        finished = ops.zeros(G, dtype=I32)
-        steps = ops.tensor(np.arange(C, dtype=np.int32), I32)
-        ops.sample_tokens(logits.expand(G, logits.shape[1]), self.temperature, self.top_k, seed, steps[0:1], tokens, finished,
-                          cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
-
-        # ---- per-step tables (positions, slots, masks) built once
-        comp_pos = (P + delta + np.arange(C, dtype=np.int64))
-        pos_c = ops.tensor(np.repeat(comp_pos[None, :], 3, 0).astype(np.int32), I32)            # [3, C]
-        cos_c, sin_c = ops.mrope_table(pos_c, t.head_dim, t.mrope_section, t.rope_theta)          # [C, hd/2]
-        half = t.head_dim // 2
-        cos_all = cos_c.view(C, 1, half).expand(C, G, half).contiguous()
-        sin_all = sin_c.view(C, 1, half).expand(C, G, half).contiguous()
-        slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
-        pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
-        nsplit = max(1, min(64, (P + 63) // 64 + 2))
-        qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
+        G, C, B = self.G, self.C, len(items)
+        qd, kvd, hd, half = t.q_dim, t.kv_dim, t.head_dim, t.head_dim // 2
         scale = hd ** -0.5
+        w_lm = eng.params.lm_head_w(arena)
+        steps = ops.tensor(np.arange(C, dtype=np.int32), I32)
+        tokens_all = ops.zeros(B * G, C, dtype=I32)
+        finished_all = ops.zeros(B * G, dtype=I32)
+        per = []
+        cos_rows, sin_rows = [], []
+        for b, (prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta) in enumerate(items):
+            P = int(prompt_ids.shape[0])
+            lay = PackedLayout(P, G, C)
+            kv = self._kv(b, lay)
+            seed = self.seed + 7919 * self.calls
+            self.calls += 1
+            # ---- prefill (prompt once, K/V written straight into the cache)
+            pos_p = ops.tensor(np.ascontiguousarray(prompt_pos3.astype(np.int32)), I32)
+            cos, sin = ops.mrope_table(pos_p, t.head_dim, t.mrope_section, t.rope_theta)
+            masks = [ops.tensor(a, I32) for a in lay.prompt_masks()]
+            h = eng.embed(arena, prompt_ids, vid_embeds, vid_rows)
+            hL, _ = eng.llm_fwd(arena, h, cos, sin, masks, save=False, kv_cache=kv.layers)
+            hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
+            logits = ops.gemm_nt(hn, w_lm)  # [1, V]
+            tokens = tokens_all[b * G:(b + 1) * G]
+            finished = finished_all[b * G:(b + 1) * G]
+            ops.sample_tokens(logits.expand(G, logits.shape[1]), self.temperature, self.top_k, seed, steps[0:1], tokens, finished,
+                              cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+            # ---- per-step tables (positions, slots, masks) built once
+            comp_pos = (P + delta + np.arange(C, dtype=np.int64))
+            pos_c = ops.tensor(np.repeat(comp_pos[None, :], 3, 0).astype(np.int32), I32)            # [3, C]
+            cos_c, sin_c = ops.mrope_table(pos_c, t.head_dim, t.mrope_section, t.rope_theta)          # [C, hd/2]
+            cos_rows.append(cos_c.view(C, 1, half).expand(C, G, half))
+            sin_rows.append(sin_c.view(C, 1, half).expand(C, G, half))
+            slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
+            pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
+            nsplit = max(1, min(28, ((P + 63) // 64 + 3) // 2))
+            per.append(dict(lay=lay, kv=kv, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
+        cos_all = torch.cat(cos_rows, 1).contiguous()      # [C, B*G, half]
+        sin_all = torch.cat(sin_rows, 1).contiguous()
+        R = B * G
 
         for s in range(C - 1):
-            ids_s = tokens[:, s].contiguous()
-            slots = slots_all[s]
+            ids_s = tokens_all[:, s].contiguous()
             cs, sn = cos_all[s], sin_all[s]
             h = ops.gather_rows(arena.w("embed"), ids_s)
             for i in range(t.n_layers):
                 p = "l%d." % i
-                kc, vtc = kv.layers[i]
                 xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
                 qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
                 q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cs, sn)
                 k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cs, sn)
-                ops.scatter_slots(k, kc, slots)
-                ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, slots=slots, out=vtc)
-                o, _ = ops.attn_fwd(q, kc, vtc, pre_d, lo_d, slots, t.n_heads, t.n_kv_heads, lay.M, hd, scale, nsplit=nsplit, need_lse=False)
+                o = ops.empty(R, qd)
+                for b, st in enumerate(per):
+                    kc, vtc = st["kv"].layers[i]
+                    r0, r1 = b * G, (b + 1) * G
+                    slots = st["slots"][s]
+                    ops.scatter_slots(k[r0:r1], kc, slots)
+                    ops.pack_transpose(qkv[r0:r1, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, slots=slots, out=vtc)
+                    ops.attn_fwd(q[r0:r1], kc, vtc, st["pre"], st["lo"], slots, t.n_heads, t.n_kv_heads, st["lay"].M, hd, scale,
+                                 nsplit=st["nsplit"], need_lse=False, out=o[r0:r1])
                 h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
                 xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
                 a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
                 h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
             hn, _, _ = ops.rmsnorm_fwd(h, arena.w("norm"), t.rms_eps, need_rstd=False)
             logits = ops.gemm_nt(hn, w_lm)
-            ops.sample_tokens(logits, self.temperature, self.top_k, seed, steps[s + 1:s + 2], tokens, finished, cfg.eos_token_id,
-                              cfg.pad_token_id, self.stop_at_eos)
-        return tokens, lay
+            for b, st in enumerate(per):
+                ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
+                                  st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+        return [(st["tokens"], st["lay"]) for st in per]

@@ -76,6 +76,7 @@ class GRPOConfig:
     prompt_type: str = "v1"
     fix_vit: bool = True
     stop_at_eos: bool = False               # the reference's GenerationConfig carries no eos_token_id (a6): always C tokens
+    rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
     learning_rate: float = 1e-6
@@ -287,8 +288,14 @@ class TimeR1_Trainer:
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")
+        ctx = self._step_prepare(inputs)
+        if ctx["forced"] is None:
+            self.core.rollout(ctx["st"])
+        return self._step_finish(ctx)
+
+    def _step_prepare(self, inputs):
+        """Host preprocessing + vision tower for one micro-step (one prompt: reference facts :524, :548-551)."""
         example = inputs[0]
-        G = self.num_generations
         video_inputs, fps_inputs = self._video_inputs(example)
         prompts = [self.make_conversation_video(ex) for ex in inputs]
         prompts_text = [self.processing_class.apply_chat_template(p, tokenize=False, add_generation_prompt=True) for p in prompts]
@@ -297,12 +304,16 @@ class TimeR1_Trainer:
         ids = np.asarray(prompt_inputs["input_ids"]).reshape(-1)
         st = self.core.prepare(ids, prompt_inputs["pixel_values_videos"], np.asarray(prompt_inputs["video_grid_thw"]))
         forced = example.get("_forced_completion_ids")       # test hook: teacher-forced completions instead of sampling
-        if forced is None:
-            tokens = self.core.rollout(st)
-        else:
+        if forced is not None:
             from .positions import PackedLayout
-            st.layout = PackedLayout(st.P, G, self.max_completion_length)
-            tokens = st.completion_ids = self.ops.tensor(np.asarray(forced, dtype=np.int32), torch.int32)
+            st.layout = PackedLayout(st.P, self.num_generations, self.max_completion_length)
+            st.completion_ids = self.ops.tensor(np.asarray(forced, dtype=np.int32), torch.int32)
+        return dict(inputs=inputs, st=st, prompts=prompts, forced=forced)
+
+    def _step_finish(self, ctx):
+        inputs, st, prompts = ctx["inputs"], ctx["st"], ctx["prompts"]
+        G = self.num_generations
+        tokens = st.completion_ids
         self.core.forward_logps(st)                           # enqueued; the host work below overlaps with it on the GPU
         comp_host = tokens.cpu().numpy()
         mask_np = eos_mask(comp_host, self.processing_class.eos_token_id)
@@ -344,6 +355,17 @@ class TimeR1_Trainer:
         self.last_completions = completions
         self.last_rewards = rewards
         return out3_h[0]
+
+    def accumulation_window(self, batches):
+        """All micro-steps of one optimizer step. With rollout_batching the G x len(batches) completions are decoded together
+        (weights do not change inside the window, so this equals the reference's sequential micro-steps). Returns the losses."""
+        if len(batches) == 1 or not getattr(self.args, "rollout_batching", True):
+            return [self.compute_loss(self.params, b) for b in batches]
+        ctxs = [self._step_prepare(b) for b in batches]
+        todo = [c["st"] for c in ctxs if c["forced"] is None]
+        if todo:
+            self.core.rollout_many(todo)
+        return [self._step_finish(c) for c in ctxs]
 
     # ------------------------------------------------------------------------------------------------------ training loop
     def get_train_dataloader(self):
@@ -406,28 +428,32 @@ class TimeR1_Trainer:
         self.control.should_training_stop = False
         epoch = 0
         while not self.control.should_training_stop and self.state.global_step < self.state.max_steps:
+            window = []
             for batch in loader:
                 if micro_seen < skip_micro:       # resume: replay the sampler, skip consumed batches
                     micro_seen += 1
                     continue
                 micro_seen += 1
-                loss = self.training_step(batch)
-                tr_loss += float(loss)
-                n_loss += 1
-                self._micro += 1
-                if self._micro % ga == 0:
-                    gnorm = self.optimizer.step(lr=self._lr(self.state.global_step))
-                    self.state.global_step += 1
-                    self.state.epoch = epoch + (micro_seen // ga % steps_per_epoch) / steps_per_epoch
-                    for cb in self.callbacks:
-                        _call(cb, "on_step_end", a, self.state, self.control)
-                    if a.logging_steps and self.state.global_step % a.logging_steps == 0:
-                        self.log({"loss": round(tr_loss / max(n_loss, 1) / ga, 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
-                        tr_loss, n_loss = 0.0, 0
-                    if a.save_strategy == "steps" and a.save_steps and self.state.global_step % a.save_steps == 0:
-                        self._save_checkpoint()
-                    if self.state.global_step >= self.state.max_steps or self.control.should_training_stop:
-                        break
+                window.append(batch)
+                if len(window) < ga:
+                    continue
+                for loss in self.accumulation_window(window):
+                    tr_loss += float(loss)
+                    n_loss += 1
+                    self._micro += 1
+                window = []
+                gnorm = self.optimizer.step(lr=self._lr(self.state.global_step))
+                self.state.global_step += 1
+                self.state.epoch = epoch + (micro_seen // ga % steps_per_epoch) / steps_per_epoch
+                for cb in self.callbacks:
+                    _call(cb, "on_step_end", a, self.state, self.control)
+                if a.logging_steps and self.state.global_step % a.logging_steps == 0:
+                    self.log({"loss": round(tr_loss / max(n_loss, 1) / ga, 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
+                    tr_loss, n_loss = 0.0, 0
+                if a.save_strategy == "steps" and a.save_steps and self.state.global_step % a.save_steps == 0:
+                    self._save_checkpoint()
+                if self.state.global_step >= self.state.max_steps or self.control.should_training_stop:
+                    break
             epoch += 1
             self.state.epoch = float(epoch)
             for cb in self.callbacks:
