@@ -5,6 +5,11 @@
 //
 // Gradient flow through the shared prompt prefix falls out of the mask: every completion row of every group sees the prefix
 // keys, so the dK/dV kernel accumulates all G suffixes' contributions into the single prefix K/V (hard part 1).
+//
+// Both kernels double-buffer their operand tiles in LDS and stage them through registers one tile ahead (branch-free loads,
+// masks applied at the LDS write), one barrier per tile.  The dK/dV kernel additionally splits the query-tile range over
+// gridDim.z blocks (the prefix key blocks see ~all query tiles, the suffix blocks only a few): partial dK/dV go to an fp32
+// workspace and a small reduce kernel sums and rounds them.
 #include "attn_common.h"
 
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, int64_t do_ld, const bf16_t* __restrict__ O, int64_t o_ld,
@@ -42,10 +47,9 @@ __global__ void attn_qmeta_kernel(const int* __restrict__ pre, const int* __rest
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     constexpr int KSTR = 2 * D + 16;
-    __shared__ __attribute__((aligned(16))) char lds_k[ATT_KV * KSTR];
-    __shared__ __attribute__((aligned(16))) char lds_v[ATT_KV * KSTR];
-    __shared__ __attribute__((aligned(16))) char lds_kt[D * 144];
-    __shared__ int lds_meta[4][3];
+    constexpr int RB = ATT_KV * KSTR, TB = D * 144, BUF = 2 * RB + TB;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][K rows | V rows | K^T] + meta
+    int* lds_meta = reinterpret_cast<int*>(dyn_lds + 2 * BUF);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y;
     const int64_t nR = (int64_t)p.T * p.group;
@@ -73,12 +77,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int o = 1; o < 16; o <<= 1) {
         wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
     }
-    if (lane == 0) { lds_meta[wave][0] = wmaxpre; lds_meta[wave][1] = wminlo; lds_meta[wave][2] = wmaxhi; }
+    if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
     __syncthreads();
     int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w][0]); bminlo = min(bminlo, lds_meta[w][1]); bmaxhi = max(bmaxhi, lds_meta[w][2]); }
+    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
     const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(R0 < nR)) != 0;
 
     bf16x8_t qf[2][D / 32], dof[2][D / 32];
 #pragma unroll
@@ -96,56 +101,105 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < D / 16; ++dt) { dq[dt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dq[dt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
-    for (int i = 0; i < tr.n_rel; ++i) {
-        const int kv0 = att_tile_at(tr, i) * ATT_KV;
-        __syncthreads();
-        stage_rows<D, ATT_KV>(lds_k, p.K, p.k_ld, (int64_t)kvh * p.d_real, kv0, p.n_slots, p.d_real);
-        stage_rows<D, ATT_KV>(lds_v, p.V, p.v_ld, (int64_t)kvh * p.d_real, kv0, p.n_slots, p.d_real);
-        stage_T<D>(lds_kt, p.KT, p.kt_ld, kvh, kv0, p.n_slots, p.d_real);
-        __syncthreads();
-        f32x4_t s[4][2], dp[4][2];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) { s[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(lds_v + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    s[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[cb][ks], s[kt][cb], 0, 0, 0);
-                    dp[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[cb][ks], dp[kt][cb], 0, 0, 0);
-                }
-            }
+    const int n_my = tr.n_rel;
+    const int64_t kcol = (int64_t)kvh * p.d_real;
+    TReg<D> rk, rv, rkt;
+    if (n_my > 0) {
+        const int64_t kv0 = (int64_t)att_tile_at(tr, 0) * ATT_KV;
+        rows_load<D>(rk, p.K, p.k_ld, kcol, kv0, p.n_slots, p.d_real);
+        rows_load<D>(rv, p.V, p.v_ld, kcol, kv0, p.n_slots, p.d_real);
+        T_load<D>(rkt, p.KT, p.kt_ld, kvh, kv0, p.n_slots, p.d_real);
+        rows_store<D>(rk, dyn_lds, kv0, p.n_slots, p.d_real);
+        rows_store<D>(rv, dyn_lds + RB, kv0, p.n_slots, p.d_real);
+        T_store<D>(rkt, dyn_lds + 2 * RB, kv0, p.n_slots, p.d_real);
+        if (n_my > 1) {
+            const int64_t kv1 = (int64_t)att_tile_at(tr, 1) * ATT_KV;
+            rows_load<D>(rk, p.K, p.k_ld, kcol, kv1, p.n_slots, p.d_real);
+            rows_load<D>(rv, p.V, p.v_ld, kcol, kv1, p.n_slots, p.d_real);
+            T_load<D>(rkt, p.KT, p.kt_ld, kvh, kv1, p.n_slots, p.d_real);
         }
-        bf16x8_t dsf[2][2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+    }
+    __syncthreads();
+
+    for (int it = 0; it < n_my; ++it) {
+        const int kv0 = att_tile_at(tr, it) * ATT_KV;
+        const char* lds_k = dyn_lds + (it & 1) * BUF;
+        const char* lds_v = lds_k + RB;
+        const char* lds_kt = lds_k + 2 * RB;
+        if (wave_active) {
+            f32x4_t s[4][2], dp[4][2];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kv = kv0 + kt * 16 + g * 4 + r;
-                    const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
-                    const float pr = ok ? exp2f(s[kt][cb][r] * p.scale_log2 - lse2[cb]) : 0.f;
-                    s[kt][cb][r] = pr * (dp[kt][cb][r] - dlt[cb]);
-                }
-            dsf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
-            dsf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
-        }
+                for (int cb = 0; cb < 2; ++cb) { s[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) {
+            for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(lds_v + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        s[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[cb][ks], s[kt][cb], 0, 0, 0);
+                        dp[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[cb][ks], dp[kt][cb], 0, 0, 0);
+                    }
+                }
+            }
+            bool full = kv0 + ATT_KV <= p.n_slots;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                full = full && (!valid[cb] || (kv0 + ATT_KV - 1 < pre[cb]) || (kv0 >= lo[cb] && kv0 + ATT_KV - 1 <= hi[cb]));
+            const bool wave_full = __all(full);
+            bf16x8_t dsf[2][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                if (wave_full) {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][cb][r], p.scale_log2, -lse2[cb]));
+                            s[kt][cb][r] = pr * (dp[kt][cb][r] - dlt[cb]);
+                        }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kv = kv0 + kt * 16 + g * 4 + r;
+                            const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
+                            const float pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][cb][r], p.scale_log2, -lse2[cb])) : 0.f;
+                            s[kt][cb][r] = pr * (dp[kt][cb][r] - dlt[cb]);
+                        }
+                }
+                dsf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
+                dsf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const char* base = lds_kt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
-                const bf16x8_t ktf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
-                dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][0], dq[dt][0], 0, 0, 0);
-                dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][1], dq[dt][1], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt) {
+                    const char* base = lds_kt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
+                    const bf16x8_t ktf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
+                    dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][0], dq[dt][0], 0, 0, 0);
+                    dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][1], dq[dt][1], 0, 0, 0);
+                }
             }
         }
+        if (it + 1 < n_my) {
+            char* nb = dyn_lds + ((it + 1) & 1) * BUF;
+            const int64_t kvn = (int64_t)att_tile_at(tr, it + 1) * ATT_KV;
+            rows_store<D>(rk, nb, kvn, p.n_slots, p.d_real);
+            rows_store<D>(rv, nb + RB, kvn, p.n_slots, p.d_real);
+            T_store<D>(rkt, nb + 2 * RB, kvn, p.n_slots, p.d_real);
+            if (it + 2 < n_my) {
+                const int64_t kv2 = (int64_t)att_tile_at(tr, it + 2) * ATT_KV;
+                rows_load<D>(rk, p.K, p.k_ld, kcol, kv2, p.n_slots, p.d_real);
+                rows_load<D>(rv, p.V, p.v_ld, kcol, kv2, p.n_slots, p.d_real);
+                T_load<D>(rkt, p.KT, p.kt_ld, kvh, kv2, p.n_slots, p.d_real);
+            }
+        }
+        __syncthreads();
     }
     const float scale = p.scale_log2 * 0.6931471805599453f;
 #pragma unroll
@@ -164,28 +218,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------------------- dK/dV
-// Block = 64 keys of one kv head; wave owns 16 of them (K/V fragments stay in registers), loops over 64-row query tiles.
+// Block = 64 keys of one kv head x one slice of the query tiles (gridDim.z); wave owns 16 keys (K/V fragments stay in registers).
+#define DKDV_MAXT 1024
+struct RowMeta { float lse, dlt; int pre, lo, hi; };
+
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles) {
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles, float* __restrict__ part_k, float* __restrict__ part_v) {
     constexpr int KSTR = 2 * D + 16;
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-    char* lds_q = dyn_lds;                       // [64][KSTR]   Q rows (packed)
-    char* lds_do = lds_q + 64 * KSTR;            // [64][KSTR]   dO rows
-    char* lds_qt = lds_do + 64 * KSTR;           // [D][144]     Q^T
-    char* lds_dot = lds_qt + D * 144;            // [D][144]     dO^T
-    float* lds_lse = reinterpret_cast<float*>(lds_dot + D * 144);   // [64]
-    float* lds_dlt = lds_lse + 64;                                   // [64]
-    int* lds_pre = reinterpret_cast<int*>(lds_dlt + 64);            // [64] x3
-    int* lds_lo = lds_pre + 64;
-    int* lds_hi = lds_lo + 64;
+    constexpr int RB = 64 * KSTR, TB = D * 144, BUF = 2 * RB + 2 * TB + 64 * 5 * 4;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][Q rows | dO rows | Q^T | dO^T | row meta] + tile list
+    int* lds_tiles = reinterpret_cast<int*>(dyn_lds + 2 * BUF);      // [DKDV_MAXT + 1]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int kvh = blockIdx.y;
+    const int kvh = blockIdx.y, qz = blockIdx.z, QS = gridDim.z;
     const int kvb0 = blockIdx.x * ATT_KV;
     const int kv = kvb0 + wave * 16 + u;
     const bool kv_ok = kv < p.n_slots;
     const int64_t nR = (int64_t)p.T * p.group;
 
+    // ---- this block's list of relevant query tiles (qi = qz, qz+QS, ...), compacted by wave 0
+    if (wave == 0) {
+        int count = 0;
+        const int n_cand = (n_qtiles - qz + QS - 1) / QS;
+        for (int base = 0; base < n_cand; base += 64) {
+            const int c = base + lane, qi = qz + c * QS;
+            bool rel = false;
+            if (c < n_cand) {
+                const int mp = p.qmeta[qi * 3], ml = p.qmeta[qi * 3 + 1], mh = p.qmeta[qi * 3 + 2];
+                rel = (kvb0 < mp) || (kvb0 + ATT_KV - 1 >= ml && kvb0 <= mh);
+            }
+            const unsigned long long mask = __ballot(rel);
+            if (rel) lds_tiles[count + __popcll(mask & ((1ull << lane) - 1ull))] = qi;
+            count += __popcll(mask);
+        }
+        if (lane == 0) lds_tiles[DKDV_MAXT] = count;
+    }
     bf16x8_t kf[D / 32], vf[D / 32];
     {
         const bf16_t* krow = p.K + (int64_t)(kv_ok ? kv : 0) * p.k_ld + (int64_t)kvh * p.d_real;
@@ -199,30 +266,60 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
     f32x4_t dk[D / 16], dv[D / 16];
 #pragma unroll
     for (int dt = 0; dt < D / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    __syncthreads();
+    const int n_my = lds_tiles[DKDV_MAXT];
 
-    for (int qi = 0; qi < n_qtiles; ++qi) {
-        const int mp = p.qmeta[qi * 3], ml = p.qmeta[qi * 3 + 1], mh = p.qmeta[qi * 3 + 2];
-        const bool rel = (kvb0 < mp) || (kvb0 + ATT_KV - 1 >= ml && kvb0 <= mh);
-        if (!rel) continue;  // block-uniform
+    TReg<D> rq, rdo, rqt, rdot;
+    RowMeta rm = {INFINITY, 0.f, 0, 1, 0};
+    auto load_tile = [&](int qi) {
         const int64_t Rq0 = (int64_t)qi * 64;
-        __syncthreads();
-        stage_packed_rows<D, 64>(lds_q, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
-        stage_packed_rows<D, 64>(lds_do, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
-        stage_T<D>(lds_qt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
-        stage_T<D>(lds_dot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
+        prows_load<D>(rq, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
+        prows_load<D>(rdo, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
+        T_load<D>(rqt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
+        T_load<D>(rdot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
         if (threadIdx.x < 64) {
             const int64_t R = Rq0 + threadIdx.x;
-            float ls = INFINITY, dl = 0.f; int a = 0, b = 1, c = 0;
+            rm = RowMeta{INFINITY, 0.f, 0, 1, 0};
             if (R < nR) {
                 const int t = (int)(R / p.group), hq = (int)(R - (int64_t)t * p.group);
                 const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + t;
                 const float l0 = p.lse[si];
-                ls = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
-                dl = p.delta[si]; a = p.pre[t]; b = p.lo[t]; c = p.hi[t];
+                rm.lse = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
+                rm.dlt = p.delta[si]; rm.pre = p.pre[t]; rm.lo = p.lo[t]; rm.hi = p.hi[t];
             }
-            lds_lse[threadIdx.x] = ls; lds_dlt[threadIdx.x] = dl; lds_pre[threadIdx.x] = a; lds_lo[threadIdx.x] = b; lds_hi[threadIdx.x] = c;
         }
-        __syncthreads();
+    };
+    auto store_tile = [&](int qi, char* buf) {
+        const int64_t Rq0 = (int64_t)qi * 64;
+        rows_store<D>(rq, buf, Rq0, nR, p.d_real);
+        rows_store<D>(rdo, buf + RB, Rq0, nR, p.d_real);
+        T_store<D>(rqt, buf + 2 * RB, Rq0, nR, p.d_real);
+        T_store<D>(rdot, buf + 2 * RB + TB, Rq0, nR, p.d_real);
+        if (threadIdx.x < 64) {
+            float* mf = reinterpret_cast<float*>(buf + 2 * RB + 2 * TB);
+            int* mi = reinterpret_cast<int*>(mf + 128);
+            mf[threadIdx.x] = rm.lse; mf[64 + threadIdx.x] = rm.dlt;
+            mi[threadIdx.x] = rm.pre; mi[64 + threadIdx.x] = rm.lo; mi[128 + threadIdx.x] = rm.hi;
+        }
+    };
+    if (n_my > 0) {
+        load_tile(lds_tiles[0]);
+        store_tile(lds_tiles[0], dyn_lds);
+        if (n_my > 1) load_tile(lds_tiles[1]);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < n_my; ++it) {
+        const char* buf = dyn_lds + (it & 1) * BUF;
+        const char* lds_q = buf;
+        const char* lds_do = buf + RB;
+        const char* lds_qt = buf + 2 * RB;
+        const char* lds_dot = lds_qt + TB;
+        const float* lds_lse = reinterpret_cast<const float*>(buf + 2 * RB + 2 * TB);
+        const float* lds_dlt = lds_lse + 64;
+        const int* lds_pre = reinterpret_cast<const int*>(lds_lse + 128);
+        const int* lds_lo = lds_pre + 64;
+        const int* lds_hi = lds_pre + 128;
 
         f32x4_t s[4], dp[4];
 #pragma unroll
@@ -245,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
             for (int r = 0; r < 4; ++r) {
                 const int ql = qt * 16 + g * 4 + r;
                 const bool ok = kv_ok && att_visible(kv, lds_pre[ql], lds_lo[ql], lds_hi[ql]);
-                const float pv = ok ? exp2f(s[qt][r] * p.scale_log2 - lds_lse[ql]) : 0.f;
+                const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][r], p.scale_log2, -lds_lse[ql])) : 0.f;
                 pr[qt][r] = pv; ds[qt][r] = pv * (dp[qt][r] - lds_dlt[ql]);
             }
         const bf16x8_t pf0 = pack_frag(pr[0], pr[1]), pf1 = pack_frag(pr[2], pr[3]);
@@ -255,54 +352,128 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
             const char* bq = lds_qt + (dt * 16 + u) * 144 + g * 8;
             const char* bo = lds_dot + (dt * 16 + u) * 144 + g * 8;
             const bf16x8_t q0 = make_frag(*reinterpret_cast<const u32x2_t*>(bq), *reinterpret_cast<const u32x2_t*>(bq + 32));
-            const bf16x8_t q1 = make_frag(*reinterpret_cast<const u32x2_t*>(bq + 64), *reinterpret_cast<const u32x2_t*>(bq + 96));
             const bf16x8_t o0 = make_frag(*reinterpret_cast<const u32x2_t*>(bo), *reinterpret_cast<const u32x2_t*>(bo + 32));
-            const bf16x8_t o1 = make_frag(*reinterpret_cast<const u32x2_t*>(bo + 64), *reinterpret_cast<const u32x2_t*>(bo + 96));
             dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[dt], 0, 0, 0);
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0, dk[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            const char* bq = lds_qt + (dt * 16 + u) * 144 + g * 8;
+            const char* bo = lds_dot + (dt * 16 + u) * 144 + g * 8;
+            const bf16x8_t q1 = make_frag(*reinterpret_cast<const u32x2_t*>(bq + 64), *reinterpret_cast<const u32x2_t*>(bq + 96));
+            const bf16x8_t o1 = make_frag(*reinterpret_cast<const u32x2_t*>(bo + 64), *reinterpret_cast<const u32x2_t*>(bo + 96));
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
         }
+        if (it + 1 < n_my) {
+            store_tile(lds_tiles[it + 1], dyn_lds + ((it + 1) & 1) * BUF);
+            if (it + 2 < n_my) load_tile(lds_tiles[it + 2]);
+        }
+        __syncthreads();
     }
     // lane holds dK^T/dV^T[d = dt*16 + g*4 + r][kv]
     if (kv_ok) {
-        const float scale = p.scale_log2 * 0.6931471805599453f;
-        bf16_t* kr = p.dK + (int64_t)kv * p.dk_ld + (int64_t)kvh * p.d_real;
-        bf16_t* vr = p.dV + (int64_t)kv * p.dv_ld + (int64_t)kvh * p.d_real;
+        if (part_k) {   // split over query tiles: fp32 partials, summed / scaled / rounded by attn_bwd_reduce_kernel
+            const int64_t kvd = (int64_t)p.n_kv * p.d_real;
+            float* pk = part_k + ((int64_t)qz * p.n_slots + kv) * kvd + (int64_t)kvh * p.d_real;
+            float* pv = part_v + ((int64_t)qz * p.n_slots + kv) * kvd + (int64_t)kvh * p.d_real;
 #pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) {
-            const int d = dt * 16 + g * 4;
-            if (d < p.d_real) {
-                u32x2_t wk = {pack2bf(dk[dt][0] * scale, dk[dt][1] * scale), pack2bf(dk[dt][2] * scale, dk[dt][3] * scale)};
-                u32x2_t wv = {pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
-                *reinterpret_cast<u32x2_t*>(kr + d) = wk;
-                *reinterpret_cast<u32x2_t*>(vr + d) = wv;
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < p.d_real) { *reinterpret_cast<f32x4_t*>(pk + d) = dk[dt]; *reinterpret_cast<f32x4_t*>(pv + d) = dv[dt]; }
+            }
+        } else {
+            const float scale = p.scale_log2 * 0.6931471805599453f;
+            bf16_t* kr = p.dK + (int64_t)kv * p.dk_ld + (int64_t)kvh * p.d_real;
+            bf16_t* vr = p.dV + (int64_t)kv * p.dv_ld + (int64_t)kvh * p.d_real;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < p.d_real) {
+                    u32x2_t wk = {pack2bf(dk[dt][0] * scale, dk[dt][1] * scale), pack2bf(dk[dt][2] * scale, dk[dt][3] * scale)};
+                    u32x2_t wv = {pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
+                    *reinterpret_cast<u32x2_t*>(kr + d) = wk;
+                    *reinterpret_cast<u32x2_t*>(vr + d) = wv;
+                }
             }
         }
     }
 }
 
+// dK = scale * sum_z part_k[z], dV = sum_z part_v[z]  -> bf16
+__global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const float* __restrict__ part_v, bf16_t* __restrict__ dK, int64_t dk_ld,
+                                       bf16_t* __restrict__ dV, int64_t dv_ld, int n_slots, int kvd, int QS, float scale) {
+    const int64_t nch = (int64_t)n_slots * (kvd / 4);
+    const int64_t stride = (int64_t)n_slots * kvd;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nch; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = i / (kvd / 4); const int c = (int)(i - slot * (kvd / 4)) * 4;
+        f32x4_t ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < QS; ++z) {
+            ak += *reinterpret_cast<const f32x4_t*>(part_k + z * stride + slot * kvd + c);
+            av += *reinterpret_cast<const f32x4_t*>(part_v + z * stride + slot * kvd + c);
+        }
+        u32x2_t wk = {pack2bf(ak[0] * scale, ak[1] * scale), pack2bf(ak[2] * scale, ak[3] * scale)};
+        u32x2_t wv = {pack2bf(av[0], av[1]), pack2bf(av[2], av[3])};
+        *reinterpret_cast<u32x2_t*>(dK + slot * dk_ld + c) = wk;
+        *reinterpret_cast<u32x2_t*>(dV + slot * dv_ld + c) = wv;
+    }
+}
+
+static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots) {
+    const int64_t n_qtiles = (T * group + 63) / 64;
+    const int64_t kvblocks = ((n_slots + ATT_KV - 1) / ATT_KV) * n_kv;
+    int64_t qs = (1024 + kvblocks - 1) / kvblocks;
+    if (qs > 8) qs = 8;
+    if (qs > n_qtiles) qs = n_qtiles;
+    if (qs < 1) qs = 1;
+    while ((n_qtiles + qs - 1) / qs > DKDV_MAXT) ++qs;
+    return (int)qs;
+}
+
 template <int D>
-static int launch_bwd(const AttnParams& p, hipStream_t s) {
+static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_floats) {
     const int64_t nR = (int64_t)p.T * p.group;
     const int n_qtiles = (int)((nR + 63) / 64);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), 0, s, p);
-    const size_t dyn = 2 * 64 * (2 * D + 16) + 2 * D * 144 + 64 * 5 * 4;
+    constexpr int KSTR = 2 * D + 16;
+    const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR + D * 144) + 64;
+    const size_t dyn_kv = 2 * (2 * 64 * KSTR + 2 * D * 144 + 64 * 5 * 4) + (DKDV_MAXT + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<D>, dim3((unsigned)((p.n_slots + ATT_KV - 1) / ATT_KV), p.n_kv), dim3(256), dyn, s, p, n_qtiles);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
+    const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots);
+    const int64_t kvd = (int64_t)p.n_kv * p.d_real;
+    float *pk = nullptr, *pv = nullptr;
+    if (QS > 1) {
+        const int64_t need = 2 * (int64_t)QS * p.n_slots * kvd;
+        if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
+        pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<D>, dim3((unsigned)((p.n_slots + ATT_KV - 1) / ATT_KV), p.n_kv, QS), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
+    if (QS > 1) {
+        const float scale = p.scale_log2 * 0.6931471805599453f;
+        hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(tr1_grid_1d(p.n_slots * kvd / 4, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
+                           p.n_slots, (int)kvd, QS, scale);
+    }
     return 0;
 }
 
-// Workspace (ints): qmeta needs 3*ceil(T*group/64). delta is caller-provided fp32 [n_heads*T].
+extern "C" int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim) {
+    if (n_kv <= 0 || T <= 0) return 0;
+    const int QS = dkdv_qsplit(T, (int)(n_heads / n_kv), (int)n_kv, n_slots);
+    return QS > 1 ? 2 * (int64_t)QS * n_slots * n_kv * head_dim : 0;
+}
+
+// Scratch: qmeta_ws int32 [3*ceil(T*group/64)], delta fp32 [n_heads*T], ws_f32 of tr1_attn_bwd_workspace_floats() floats.
 extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
                             int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
                             const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,
-                            void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, int64_t T,
-                            int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream) {
+                            void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32,
+                            int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale,
+                            void* stream) {
     AttnParams p; memset(&p, 0, sizeof(p));
     TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention bwd: n_heads must be a multiple of n_kv");
     p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.V = (const bf16_t*)V; p.v_ld = v_ld;
@@ -318,17 +489,20 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
                   "attention bwd: dims must be multiples of 8");
     TR1_CHECK_ARG(kt_ld % 8 == 0 && kt_ld >= n_slots && qt_ld % 8 == 0 && qt_ld >= T * p.group && dot_ld % 8 == 0 && dot_ld >= T * p.group,
                   "attention bwd: transposed leading dims too small");
+    TR1_CHECK_ARG(dk_ld % 4 == 0 && dv_ld % 4 == 0, "attention bwd: dk/dv leading dims must be multiples of 4");
     if (T == 0 || n_slots == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T * n_heads + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dO, do_ld,
                        (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim);
     const int n_qtiles = (int)((T * p.group + 63) / 64);
     hipLaunchKernelGGL(attn_qmeta_kernel, dim3(n_qtiles), dim3(64), 0, s, p.pre, p.lo, p.hi, (int*)qmeta_ws, (int)T, p.group);
+    int rc = 0;
     switch (d_pad) {
-        case 32: launch_bwd<32>(p, s); break;
-        case 64: launch_bwd<64>(p, s); break;
-        case 96: launch_bwd<96>(p, s); break;
-        default: launch_bwd<128>(p, s); break;
+        case 32: rc = launch_bwd<32>(p, s, (float*)ws_f32, ws_floats); break;
+        case 64: rc = launch_bwd<64>(p, s, (float*)ws_f32, ws_floats); break;
+        case 96: rc = launch_bwd<96>(p, s, (float*)ws_f32, ws_floats); break;
+        default: rc = launch_bwd<128>(p, s, (float*)ws_f32, ws_floats); break;
     }
+    if (rc) return rc;
     TR1_LAUNCH_CHECK();
 }

@@ -278,9 +278,11 @@ class HipOps:
         dv = dv_out if dv_out is not None else self.empty(n_slots, n_kv * head_dim)
         delta = self.empty(n_heads, T, dtype=F32)
         qmeta = self._workspace("attn_qmeta", 3 * ((T * group + 63) // 64), I32)
+        nws = self.L.raw("tr1_attn_bwd_workspace_floats")(T, n_heads, n_kv, n_slots, head_dim)
+        ws = self._workspace("attn_bwd_part", nws, F32) if nws else None
         self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kt), _ld(kt), _p(qt), _ld(qt), _p(dot), _ld(dot),
                     _p(o), _ld(o), _p(do), _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(pre), _p(lo),
-                    _p(hi), _p(qmeta), T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
+                    _p(hi), _p(qmeta), _p(ws), nws, T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
         return dq, dk, dv
 
     # ---- vocabulary side ------------------------------------------------------------------------------------------
