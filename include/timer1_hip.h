@@ -86,8 +86,12 @@ int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, 
  * partials of the query-split dK/dV kernel).  Writes dQ [T, n_heads*hd], dK, dV [slots, n_kv*hd]. */
 int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT, int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld, const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld, void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32, int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
 int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim);
-/* out[(kvh*hd + d) * ld_out + col] = in[t*ld_in + (kvh*group + hq)*hd + d], col = t*group + hq (or slots[t] when slots != NULL, group 1) */
-int tr1_pack_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* slots, int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int zero_pad, void* stream);
+/* out[(kvh*hd + d) * ld_out + col] = in[t*ld_in + (kvh*group + hq)*hd + d], col = t*group + hq (or slots[t] when slots != NULL, group 1);
+ * without slots, columns [T*group, zero_cols) are zero-filled */
+int tr1_pack_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* slots, int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t zero_cols, void* stream);
+/* Decode-step post-projection in one launch: M-RoPE on q and k of the new tokens, k -> kcache[slots[r]], v -> vtcache[:, slots[r]]
+ * (ref: Qwen2VLAttention.forward TF:521-556 with a DynamicCache update inside generate, timer1_trainer.py:568-573) */
+int tr1_decode_qkv_post(const void* qkv, int64_t ld, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t R, int64_t n_heads, int64_t n_kv, int64_t head_dim, void* stream);
 /* KV-cache append: dst[slots[t], :] = src[t, :] */
 int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const void* slots, int64_t T, int64_t cols, void* stream);
 

@@ -225,10 +225,20 @@ class RefOps:
             out[:, slots.long()] = v
         else:
             out[:, : T * group] = v
+            if zero_pad:
+                out[:, T * group:] = 0
         return out
 
     def scatter_slots(self, src, dst, slots):
         dst[slots.long(), : src.shape[1]] = src
+
+    def decode_qkv_post(self, qkv, cos, sin, kcache, vtcache, slots, n_heads, n_kv, head_dim):
+        qd, kvd = n_heads * head_dim, n_kv * head_dim
+        q = self.rope_apply(qkv[:, :qd], n_heads, head_dim, cos, sin)
+        k = self.rope_apply(qkv[:, qd:qd + kvd], n_kv, head_dim, cos, sin)
+        kcache[slots.long()] = k
+        vtcache[:, slots.long()] = qkv[:, qd + kvd:].t()
+        return q
 
     def _dense_attn(self, q, k, v, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale):
         T = q.shape[0]

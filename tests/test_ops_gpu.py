@@ -353,3 +353,20 @@ def test_adamw_and_clip(hip_ops, ref_ops):
         torch.nn.utils.clip_grad_norm_([pt], 1.0)
         opt.step()
     close(st_h[0], pt.detach(), 1e-6, rtol=1e-5, what="adamw vs torch.optim.AdamW")
+
+
+def test_decode_qkv_post(hip_ops, ref_ops):
+    """Fused decode post-projection == rope(q), rope(k) -> K cache rows, v -> V^T cache columns."""
+    R, nh, nkv, hd, S = 16, 14, 2, 128, 512
+    qkv = rnd(R, (nh + 2 * nkv) * hd, seed=1)
+    g = torch.Generator().manual_seed(0)
+    pos3 = torch.randint(0, 4000, (3, R), generator=g, dtype=torch.int32)
+    cos, sin = ref_ops.mrope_table(pos3, hd, (16, 24, 24), 1e6)
+    slots = torch.randperm(S, generator=g)[:R].int()
+    kc_h, vt_h = torch.zeros(S, nkv * hd, dtype=BF16, device="cuda:0"), torch.zeros(nkv * hd, S, dtype=BF16, device="cuda:0")
+    kc_r, vt_r = torch.zeros(S, nkv * hd), torch.zeros(nkv * hd, S)
+    q_h = hip_ops.decode_qkv_post(qkv.cuda(), cos.cuda(), sin.cuda(), kc_h, vt_h, slots.cuda(), nh, nkv, hd)
+    q_r = ref_ops.decode_qkv_post(qkv.float(), cos, sin, kc_r, vt_r, slots, nh, nkv, hd)
+    close(q_h, q_r, 0.02, what="fused q rope")
+    close(kc_h, kc_r, 0.02, what="fused k append")
+    assert torch.equal(vt_h.float().cpu(), vt_r), "fused v append must be exact"

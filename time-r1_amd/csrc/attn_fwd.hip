@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
 // when zero_pad != 0. With group = 1 this is the K^T / V^T builder (optionally through a slot map: column = slots[t]).
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
                                                              int64_t ld_out, const int* __restrict__ slots, int64_t T, int n_kv, int group,
-                                                             int d, int zero_pad) {
+                                                             int d, int64_t zero_cols) {
     __shared__ bf16_t tile[64][66];
     const int kvh = blockIdx.z;
     const int64_t nR = T * group;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const bf16_t* __res
         if (R < nR) {
             const int64_t col = slots ? (int64_t)slots[R] : R;
             out[((int64_t)kvh * d + dd) * ld_out + col] = tile[tx][ty + i * 4];
-        } else if (zero_pad && R < ld_out && !slots) {
+        } else if (R < zero_cols && !slots) {
             out[((int64_t)kvh * d + dd) * ld_out + R] = 0;
         }
     }
@@ -340,15 +340,16 @@ extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int
 }
 
 extern "C" int tr1_pack_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* slots, int64_t T, int64_t n_heads,
-                                  int64_t n_kv, int64_t head_dim, int zero_pad, void* stream) {
+                                  int64_t n_kv, int64_t head_dim, int64_t zero_cols, void* stream) {
     TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "pack_transpose: n_heads must be a multiple of n_kv");
     const int group = (int)(n_heads / n_kv);
     TR1_CHECK_ARG(slots || ld_out >= T * group, "pack_transpose: ld_out too small");
     if (T == 0) return 0;
-    const int64_t span = (zero_pad && !slots) ? ld_out : T * group;
+    TR1_CHECK_ARG(zero_cols <= ld_out, "pack_transpose: zero_cols exceeds the leading dimension");
+    const int64_t span = (zero_cols > T * group && !slots) ? zero_cols : T * group;
     dim3 grid((unsigned)((head_dim + 63) / 64), (unsigned)((span + 63) / 64), (unsigned)n_kv);
     hipLaunchKernelGGL(pack_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out,
-                       (const int*)slots, T, (int)n_kv, group, (int)head_dim, zero_pad);
+                       (const int*)slots, T, (int)n_kv, group, (int)head_dim, slots ? (int64_t)0 : zero_cols);
     TR1_LAUNCH_CHECK();
 }
 

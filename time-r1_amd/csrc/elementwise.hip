@@ -351,3 +351,64 @@ extern "C" int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int6
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
     TR1_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------- fused decode post-projection
+// One launch per decode layer-step instead of five: M-RoPE on the new token's q and k heads, append k to the K cache row
+// `slots[r]`, scatter v into the transposed V cache column `slots[r]` (reference: Qwen2VLAttention.forward TF:521-556 + DynamicCache.update).
+// qkv: [R, (n_heads + 2*n_kv)*hd]; q_out: [R, n_heads*hd]; kcache: [slots, n_kv*hd]; vtcache: [n_kv*hd, vt_ld].
+__global__ void decode_qkv_post_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const float* __restrict__ cosb, const float* __restrict__ sinb,
+                                       bf16_t* __restrict__ q_out, int64_t ld_q, bf16_t* __restrict__ kcache, int64_t k_ld,
+                                       bf16_t* __restrict__ vtcache, int64_t vt_ld, const int* __restrict__ slots, int R, int n_heads, int n_kv,
+                                       int hd) {
+    const int half = hd >> 1, hc = half >> 3;
+    const int heads_total = n_heads + 2 * n_kv;
+    const int64_t total = (int64_t)R * heads_total * hc;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % hc);
+        const int64_t rh = idx / hc;
+        const int h = (int)(rh % heads_total);
+        const int r = (int)(rh / heads_total);
+        const bf16_t* src = qkv + (int64_t)r * ld + (int64_t)h * hd + c * 8;
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(src);
+        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(src + half);
+        const int slot = slots[r];
+        if (h < n_heads + n_kv) {
+            const float* cp = cosb + (int64_t)r * half + c * 8;
+            const float* sp = sinb + (int64_t)r * half + c * 8;
+            u32x4_t oa, ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c0 = cp[2 * j], c1 = cp[2 * j + 1], s0 = sp[2 * j], s1 = sp[2 * j + 1];
+                const float a0 = bflo(a[j]), a1 = bfhi(a[j]), b0 = bflo(b[j]), b1 = bfhi(b[j]);
+                oa[j] = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+                ob[j] = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+            }
+            bf16_t* dst = (h < n_heads) ? (q_out + (int64_t)r * ld_q + (int64_t)h * hd + c * 8)
+                                        : (kcache + (int64_t)slot * k_ld + (int64_t)(h - n_heads) * hd + c * 8);
+            *reinterpret_cast<u32x4_t*>(dst) = oa;
+            *reinterpret_cast<u32x4_t*>(dst + half) = ob;
+        } else {
+            const int kvh = h - n_heads - n_kv;
+            bf16_t* col = vtcache + ((int64_t)kvh * hd + c * 8) * vt_ld + slot;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                col[(int64_t)(2 * j) * vt_ld] = (bf16_t)(a[j] & 0xffffu);
+                col[(int64_t)(2 * j + 1) * vt_ld] = (bf16_t)(a[j] >> 16);
+                col[(int64_t)(half + 2 * j) * vt_ld] = (bf16_t)(b[j] & 0xffffu);
+                col[(int64_t)(half + 2 * j + 1) * vt_ld] = (bf16_t)(b[j] >> 16);
+            }
+        }
+    }
+}
+
+extern "C" int tr1_decode_qkv_post(const void* qkv, int64_t ld, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache,
+                                   int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t R, int64_t n_heads, int64_t n_kv,
+                                   int64_t head_dim, void* stream) {
+    TR1_CHECK_ARG(head_dim % 16 == 0 && ld % 8 == 0 && ld_q % 8 == 0 && k_ld % 8 == 0, "decode_qkv_post: head_dim%16 and ld%8 required");
+    if (R == 0) return 0;
+    const int64_t total = R * (n_heads + 2 * n_kv) * (head_dim / 16);
+    hipLaunchKernelGGL(decode_qkv_post_kernel, dim3(tr1_grid_1d(total, 256, 1024)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ld,
+                       (const float*)cosb, (const float*)sinb, (bf16_t*)q_out, ld_q, (bf16_t*)kcache, k_ld, (bf16_t*)vtcache, vt_ld, (const int*)slots,
+                       (int)R, (int)n_heads, (int)n_kv, (int)head_dim);
+    TR1_LAUNCH_CHECK();
+}

@@ -164,71 +164,81 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // step, so a 16-lane group covers one full 128-byte line per row; the k-order inside the MFMA is permuted the same
 // way for x (any k permutation is legal as long as A and B agree).
 // ------------------------------------------------------------------------------------------------------------------
-template <int WAVES, int UNROLL, bool NT, bool HALFLINE, bool XPRED>
+// NCOL: 16-column groups per wave.  The x (activation) fragment is loaded once per k-step and reused for NCOL weight fragments, so
+// the L2 traffic for x drops from 1x to 1/NCOL of the weight stream (matters at M = 16, where x is as large as a block's W slab).
+template <int WAVES, int UNROLL, int NCOL>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                  float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
                                                                  const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
                                                                  int64_t ldw, int64_t ldc, int64_t ldr) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES][16][17];
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
-    int64_t wrow = n0 + u; if (wrow >= N) wrow = N - 1;
-    const bool xlive = XPRED ? (u < M) : true;     // rows 8..15 of the MFMA B operand are padding when M = 8
-    constexpr int O2 = HALFLINE ? 32 : 8;          // element offset of the lane's second 16-byte piece within a 64-element step
-    const int goff = HALFLINE ? g * 8 : g * 16;
-    const bf16_t* wp = W + wrow * ldw + goff;
-    const bf16_t* xp = X + (int64_t)((u < M) ? u : (M - 1)) * ldx + goff;
-    // this wave's K range in steps of 64 elements (two MFMA k-steps: lane (u,g) takes k = g*8.. and 32+g*8.. of every step, so a
-    // 16-lane group reads 64 contiguous bytes of each W row per load instruction)
+    const int64_t n0 = (int64_t)blockIdx.x * 16 * NCOL;
+    const bool xlive = u < M;                      // rows >= M of the MFMA B operand are padding: no loads issued for them
+    // lane (u,g) takes k = g*8.. and 32+g*8.. of every 64-element step: a 16-lane group reads 64 contiguous bytes of a W row per load
+    const bf16_t* wp[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        int64_t wrow = n0 + c * 16 + u; if (wrow >= N) wrow = N - 1;
+        wp[c] = W + wrow * ldw + g * 8;
+    }
+    const bf16_t* xp = X + (int64_t)(xlive ? u : (M - 1)) * ldx + g * 8;
     const int64_t nsteps = K / 64;
     const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
     const int64_t s0 = wave * s_per;
     int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
-    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NCOL][2];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) { acc[c][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     const bf16x8_t zf = zero_frag8();
     int64_t s = s0;
     for (; s + UNROLL <= s1; s += UNROLL) {
-        bf16x8_t wa[UNROLL][2], xa[UNROLL][2];
+        bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][2];
 #pragma unroll
         for (int q = 0; q < UNROLL; ++q) {
             const int64_t k = (s + q) * 64;
-            if (NT) {   // streamed once: non-temporal
-                wa[q][0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k));
-                wa[q][1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k + O2));
-            } else {
-                wa[q][0] = *reinterpret_cast<const bf16x8_t*>(wp + k);
-                wa[q][1] = *reinterpret_cast<const bf16x8_t*>(wp + k + O2);
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
+                wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
             }
             xa[q][0] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k) : zf;
-            xa[q][1] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + O2) : zf;
+            xa[q][1] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + 32) : zf;
         }
 #pragma unroll
-        for (int q = 0; q < UNROLL; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][0], xa[q][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][1], xa[q][1], acc1, 0, 0, 0);
-        }
+        for (int q = 0; q < UNROLL; ++q)
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], xa[q][0], acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], xa[q][1], acc[c][1], 0, 0, 0);
+            }
     }
     for (; s < s1; ++s) {
         const int64_t k = s * 64;
-        const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp + k);
-        const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(wp + k + O2);
         const bf16x8_t x0 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k) : zf;
-        const bf16x8_t x1 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + O2) : zf;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc1, 0, 0, 0);
+        const bf16x8_t x1 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + 32) : zf;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
+            const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
+            acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[c][0], 0, 0, 0);
+            acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc[c][1], 0, 0, 0);
+        }
     }
     // D[row = n index (g*4+r)][col = m (u)]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][u][g * 4 + r] = acc0[r] + acc1[r];
+    for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][c][u][g * 4 + r] = acc[c][0][r] + acc[c][1][r];
     __syncthreads();
-    if (threadIdx.x < 256) {   // 16 (m) x 16 (n)
-        const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
-        const int64_t n = n0 + nn;
+    for (int i = threadIdx.x; i < NCOL * 256; i += WAVES * 64) {   // (column group, m, n)
+        const int c = i >> 8, m = (i >> 4) & 15, nn = i & 15;
+        const int64_t n = n0 + c * 16 + nn;
         if (m < M && n < N) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) v += red[w][m][nn];
+            for (int w = 0; w < WAVES; ++w) v += red[w][c][m][nn];
             if (bias) v += bf2f(bias[n]);
             if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
             if (Cf32) Cf32[(int64_t)m * ldc + n] = v;
@@ -247,14 +257,20 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (M <= 16 && !accumulate && K >= 256) {
-        dim3 grid((unsigned)((N + 15) / 16));
-#define SK(WV, NTF, HL, XP)                                                                                                          \
-    hipLaunchKernelGGL((gemm_skinny_kernel<WV, 4, NTF, HL, XP>), grid, dim3(WV * 64), 0, s, (const bf16_t*)A, (const bf16_t*)B,     \
-                       out_f32 ? nullptr : (bf16_t*)C, out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, \
-                       (int)M, N, K, lda, ldb, ldc, ldr)
-        // measured on MI355X (tools/microbench.py skinny): half-line lane grouping and predicated x loads help, non-temporal
-        // loads hurt (-7..12 %), 8-way in-block split-K pays only for long K (the 18944-deep down projection)
-        if (K >= 8192) SK(8, false, true, true); else SK(4, false, true, true);
+        static int force_ncol = -1;
+        if (force_ncol < 0) { const char* e = getenv("TR1_SKINNY_NCOL"); force_ncol = e ? atoi(e) : 0; }
+#define SK(WV, UN, NC)                                                                                                               \
+    hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC))), dim3(WV * 64), 0, s,      \
+                       (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C, out_f32 ? (float*)C : nullptr,           \
+                       (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr)
+        // choices measured on MI355X with tools/microbench.py skinny (non-temporal loads hurt; 8-way in-block split-K pays for long K)
+        // (A/B on MI355X, M = 16: gate_up 37888x3584 67.6 -> 56.8 us with NCOL 2; lm_head 152064x3584 247 -> 188 us with NCOL 4;
+        //  the 3584x18944 down projection has too few column groups for NCOL > 1 and wants 8-way in-block split-K instead)
+        int ncol = force_ncol > 0 ? force_ncol : (N >= 100000 ? 4 : (N >= 4096 ? 2 : 1));
+        if (K >= 8192) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2); else SK(8, 4, 1); }
+        else if (ncol == 4) SK(4, 2, 4);
+        else if (ncol == 2) SK(4, 4, 2);
+        else SK(4, 4, 1);
 #undef SK
         TR1_LAUNCH_CHECK();
     }

@@ -243,13 +243,23 @@ class HipOps:
                 ld_out = (T * group + 63) // 64 * 64
             out = self.empty(n_kv * head_dim, ld_out)
         self.L.call("tr1_pack_transpose", _p(x), _ld(x), _p(out), _ld(out), _p(slots), T, n_heads, n_kv, head_dim,
-                    int(zero_pad and slots is None), self._s())
+                    out.shape[1] if (zero_pad and slots is None) else 0, self._s())
         return out
 
     def scatter_slots(self, src, dst, slots):
         self._chk(src, dst)
         assert slots.dtype == I32
         self.L.call("tr1_scatter_slots", _p(src), _ld(src), _p(dst), _ld(dst), _p(slots), src.shape[0], src.shape[1], self._s())
+
+    def decode_qkv_post(self, qkv, cos, sin, kcache, vtcache, slots, n_heads, n_kv, head_dim):
+        """RoPE(q), RoPE(k) -> K cache rows, v -> V^T cache columns, for the R new decode tokens. Returns roped q [R, n_heads*hd]."""
+        self._chk(qkv, kcache, vtcache)
+        R = qkv.shape[0]
+        assert slots.dtype == I32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (R, head_dim // 2)
+        q = self.empty(R, n_heads * head_dim)
+        self.L.call("tr1_decode_qkv_post", _p(qkv), _ld(qkv), _p(cos), _p(sin), _p(q), _ld(q), _p(kcache), _ld(kcache), _p(vtcache), _ld(vtcache),
+                    _p(slots), R, n_heads, n_kv, head_dim, self._s())
+        return q
 
     def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None):
         self._chk(q, k, vt)

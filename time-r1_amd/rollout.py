@@ -16,9 +16,17 @@ I32 = torch.int32
 
 
 class KVCache:
-    def __init__(self, ops, n_layers, kv_dim, s_cap):
-        self.s_cap = s_cap
-        self.layers = [(ops.zeros(s_cap, kv_dim), ops.zeros(kv_dim, s_cap)) for _ in range(n_layers)]
+    """Per layer ONE K buffer [B*s_cap, kv_dim] and ONE V^T buffer [kv_dim, B*s_cap] for the B prompts decoded together; prompt b owns
+    slots [b*s_cap, (b+1)*s_cap) and sees them through views, so a single fused kernel appends the new K/V of all B*G rows."""
+
+    def __init__(self, ops, n_layers, kv_dim, s_cap, B):
+        self.s_cap, self.B = s_cap, B
+        self.k = [ops.zeros(B * s_cap, kv_dim) for _ in range(n_layers)]
+        self.vt = [ops.zeros(kv_dim, B * s_cap) for _ in range(n_layers)]
+
+    def views(self, b):
+        a, e = b * self.s_cap, (b + 1) * self.s_cap
+        return [(k[a:e], vt[:, a:e]) for k, vt in zip(self.k, self.vt)]
 
 
 class Rollout:
@@ -26,15 +34,15 @@ class Rollout:
         self.eng = engine
         self.G, self.C = int(num_generations), int(max_completion_length)
         self.temperature, self.top_k, self.seed, self.stop_at_eos = float(temperature), int(top_k or 0), int(seed), bool(stop_at_eos)
-        self._caches = {}
+        self._cache = None
         self.calls = 0
 
-    def _kv(self, slot, layout):
+    def _kv(self, B, s_cap):
         t = self.eng.cfg.text
-        c = self._caches.get(slot)
-        if c is None or c.s_cap != layout.S_cap:
-            c = KVCache(self.eng.ops, t.n_layers, t.kv_dim, layout.S_cap)
-            self._caches[slot] = c
+        c = self._cache
+        if c is None or c.s_cap != s_cap or c.B != B:
+            self._cache = None      # release before re-allocating
+            c = self._cache = KVCache(self.eng.ops, t.n_layers, t.kv_dim, s_cap, B)
         return c
 
     def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta):
@@ -55,10 +63,12 @@ class Rollout:
         finished_all = ops.zeros(B * G, dtype=I32)
         per = []
         cos_rows, sin_rows = [], []
+        lays = [PackedLayout(int(it[0].shape[0]), G, C) for it in items]
+        cache = self._kv(B, max(l.S_cap for l in lays))
         for b, (prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta) in enumerate(items):
             P = int(prompt_ids.shape[0])
-            lay = PackedLayout(P, G, C)
-            kv = self._kv(b, lay)
+            lay = lays[b]
+            kv_views = cache.views(b)
             seed = self.seed + 7919 * self.calls
             self.calls += 1
             # ---- prefill (prompt once, K/V written straight into the cache)
@@ -66,7 +76,7 @@ class Rollout:
             cos, sin = ops.mrope_table(pos_p, t.head_dim, t.mrope_section, t.rope_theta)
             masks = [ops.tensor(a, I32) for a in lay.prompt_masks()]
             h = eng.embed(arena, prompt_ids, vid_embeds, vid_rows)
-            hL, _ = eng.llm_fwd(arena, h, cos, sin, masks, save=False, kv_cache=kv.layers)
+            hL, _ = eng.llm_fwd(arena, h, cos, sin, masks, save=False, kv_cache=kv_views)
             hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
             logits = ops.gemm_nt(hn, w_lm)  # [1, V]
             tokens = tokens_all[b * G:(b + 1) * G]
@@ -82,9 +92,10 @@ class Rollout:
             slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
             pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
             nsplit = max(1, min(28, ((P + 63) // 64 + 3) // 2))
-            per.append(dict(lay=lay, kv=kv, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
+            per.append(dict(lay=lay, kv=kv_views, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
         cos_all = torch.cat(cos_rows, 1).contiguous()      # [C, B*G, half]
         sin_all = torch.cat(sin_rows, 1).contiguous()
+        abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
         R = B * G
 
         for s in range(C - 1):
@@ -95,16 +106,12 @@ class Rollout:
                 p = "l%d." % i
                 xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
                 qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
-                q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cs, sn)
-                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cs, sn)
+                q = ops.decode_qkv_post(qkv, cs, sn, cache.k[i], cache.vt[i], abs_slots[s], t.n_heads, t.n_kv_heads, hd)
                 o = ops.empty(R, qd)
                 for b, st in enumerate(per):
-                    kc, vtc = st["kv"].layers[i]
+                    kc, vtc = st["kv"][i]
                     r0, r1 = b * G, (b + 1) * G
-                    slots = st["slots"][s]
-                    ops.scatter_slots(k[r0:r1], kc, slots)
-                    ops.pack_transpose(qkv[r0:r1, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, slots=slots, out=vtc)
-                    ops.attn_fwd(q[r0:r1], kc, vtc, st["pre"], st["lo"], slots, t.n_heads, t.n_kv_heads, st["lay"].M, hd, scale,
+                    ops.attn_fwd(q[r0:r1], kc, vtc, st["pre"], st["lo"], st["slots"][s], t.n_heads, t.n_kv_heads, st["lay"].M, hd, scale,
                                  nsplit=st["nsplit"], need_lse=False, out=o[r0:r1])
                 h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
                 xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
