@@ -102,7 +102,8 @@ int tr1_logp_bwd(const void* logits, int64_t ld, const void* targets, const void
 /* ref: timer1_trainer.py:635-639 (k3 KL), :713-737 (both loss branches).  out3 = {loss, mean masked kl, sum mask}. */
 int tr1_grpo_loss(const void* logp, const void* ref_logp, const void* mask, const void* adv, void* dlogp, void* out3, void* row_len, void* row_kl, int64_t G, int64_t C, float beta, int use_grpo, float grad_scale, void* stream);
 /* ref: model.generate(do_sample=True, temperature, top_k) at timer1_trainer.py:568-573.  tokens[row*tok_ld + *step_ptr] = draw. */
-int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* stream);
+int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* stream);
+int64_t tr1_sample_workspace_words(int64_t rows);
 
 /* ---- optimizer -------------------------------------------------------------------------------------------------------- */
 /* ref: DeepSpeed FusedAdam / DeepSpeedCPUAdam selected by scripts/zero3.json:13-21 and zero3_offload.json:24-31 (AdamW, clip 1.0) */

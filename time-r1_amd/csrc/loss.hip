@@ -142,83 +142,142 @@ TR1_DEV void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
-TR1_DEV unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }  // order preserving
-TR1_DEV float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+// 16-bit order-preserving key of a bf16 logit (temperature > 0 does not change the order, so top-k is selected on raw logits)
+TR1_DEV unsigned bfkey(bf16_t b) { return (b & 0x8000u) ? ((~(unsigned)b) & 0xffffu) : ((unsigned)b | 0x8000u); }
+TR1_DEV float key_logit(unsigned k) { const unsigned b = (k & 0x8000u) ? (k & 0x7fffu) : ((~k) & 0xffffu); return bf2f((bf16_t)b); }
 
-__global__ __launch_bounds__(1024) void sample_kernel(const bf16_t* __restrict__ logits, int64_t ld, int V, float inv_temp, int top_k,
-                                                      unsigned long long seed, const int* __restrict__ step_ptr, int* __restrict__ tokens,
-                                                      int64_t tok_ld, int* __restrict__ finished, int eos_id, int pad_id, int stop_at_eos,
-                                                      float* __restrict__ u_out) {
-    __shared__ unsigned hist[256];
+// Multi-block sampler.  The vocabulary row (152k bf16 logits, L2 resident) is cut into SAMP_S slices, one 256-thread block each:
+//   1. hist_hi   : 256-bin histogram of the key's high byte (+ row max)           -> finds the byte holding the k-th largest logit
+//   2. hist_lo   : histogram of the low byte among logits in that high-byte bin    -> exact k-th largest 16-bit key = threshold
+//   3. slice_sum : sum exp((x - max)/T) over kept logits per slice
+//   4. pick      : Philox uniform, locate the slice and the token by an inverse-CDF walk in vocabulary order
+// Workspace per row (uint32 words): hist_hi[256] | hist_lo[256] | misc[8] (0: max key) | slice sums[SAMP_S] (float)
+#define SAMP_S 32
+#define SAMP_WS_WORDS (256 + 256 + 8 + SAMP_S)
+
+struct SampleArgs {
+    const bf16_t* logits; int64_t ld; int V; float inv_temp; int top_k; unsigned long long seed; const int* step_ptr; int* tokens; int64_t tok_ld;
+    int* finished; int eos_id, pad_id, stop_at_eos; float* u_out; unsigned* ws;
+};
+
+TR1_DEV bool samp_row_done(const SampleArgs& a, int r) { return a.finished && a.stop_at_eos && a.finished[r]; }
+
+// threshold search over a 256-bin histogram: largest bin b with (count of keys in bins > b) < need <= (count in bins >= b)
+TR1_DEV void samp_find_bin(const unsigned* hist, int need, int& bin, int& rem) {
+    int acc = 0; int b = 255;
+    for (; b > 0; --b) { if (acc + (int)hist[b] >= need) break; acc += (int)hist[b]; }
+    bin = b; rem = need - acc;
+}
+
+__global__ __launch_bounds__(256) void samp_hist_hi_kernel(SampleArgs a) {
+    __shared__ unsigned h[256];
+    __shared__ unsigned smax;
+    const int r = blockIdx.y;
+    if (samp_row_done(a, r)) return;
+    h[threadIdx.x] = 0u; if (threadIdx.x == 0) smax = 0u;
+    __syncthreads();
+    const bf16_t* row = a.logits + (int64_t)r * a.ld;
+    const int per = (a.V + SAMP_S - 1) / SAMP_S, i0 = blockIdx.x * per, i1 = min(a.V, i0 + per);
+    unsigned mx = 0u;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) { const unsigned k = bfkey(row[i]); mx = max(mx, k); atomicAdd(&h[k >> 8], 1u); }
+    atomicMax(&smax, mx);
+    __syncthreads();
+    unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
+    if (h[threadIdx.x]) atomicAdd(&ws[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x == 0) atomicMax(&ws[512], smax);
+}
+
+__global__ __launch_bounds__(256) void samp_hist_lo_kernel(SampleArgs a) {
+    __shared__ unsigned h[256];
+    __shared__ int sbin;
+    const int r = blockIdx.y;
+    if (samp_row_done(a, r)) return;
+    unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
+    h[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) { int bin, rem; samp_find_bin(ws, a.top_k, bin, rem); sbin = bin; }
+    __syncthreads();
+    const unsigned bin = (unsigned)sbin;
+    const bf16_t* row = a.logits + (int64_t)r * a.ld;
+    const int per = (a.V + SAMP_S - 1) / SAMP_S, i0 = blockIdx.x * per, i1 = min(a.V, i0 + per);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) { const unsigned k = bfkey(row[i]); if ((k >> 8) == bin) atomicAdd(&h[k & 255u], 1u); }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&ws[256 + threadIdx.x], h[threadIdx.x]);
+}
+
+TR1_DEV unsigned samp_threshold(const SampleArgs& a, const unsigned* ws) {   // 16-bit key of the k-th largest logit (0 = keep all)
+    if (a.top_k <= 0 || a.top_k >= a.V) return 0u;
+    int bin, rem, lo, rem2;
+    samp_find_bin(ws, a.top_k, bin, rem);
+    samp_find_bin(ws + 256, rem, lo, rem2);
+    return ((unsigned)bin << 8) | (unsigned)lo;
+}
+
+__global__ __launch_bounds__(256) void samp_slice_sum_kernel(SampleArgs a) {
     __shared__ float red[16];
-    __shared__ float chunk_sum[1024];
-    __shared__ unsigned s_prefix; __shared__ int s_remaining; __shared__ int s_token;
+    __shared__ unsigned sthr;
+    const int r = blockIdx.y;
+    if (samp_row_done(a, r)) return;
+    unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
+    if (threadIdx.x == 0) sthr = samp_threshold(a, ws);
+    __syncthreads();
+    const unsigned thr = sthr;
+    const float mx = key_logit(ws[512]);
+    const bf16_t* row = a.logits + (int64_t)r * a.ld;
+    const int per = (a.V + SAMP_S - 1) / SAMP_S, i0 = blockIdx.x * per, i1 = min(a.V, i0 + per);
+    float acc = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) { const bf16_t b = row[i]; if (bfkey(b) >= thr) acc += __expf((bf2f(b) - mx) * a.inv_temp); }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) reinterpret_cast<float*>(ws + 520)[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void samp_pick_kernel(SampleArgs a) {
+    __shared__ float part[256];
+    __shared__ unsigned sthr; __shared__ int sslice; __shared__ float sbase, starget;
     const int r = blockIdx.x, tid = threadIdx.x;
-    const int step = step_ptr ? *step_ptr : 0;
-    int* tok_out = tokens + (int64_t)r * tok_ld + step;
-    if (finished && finished[r] && stop_at_eos) { if (tid == 0) *tok_out = pad_id; return; }
-    const bf16_t* row = logits + (int64_t)r * ld;
-
-    // ---- radix select of the k-th largest key (MSB first)
-    unsigned thr_key = 0u;  // keep everything
-    if (top_k > 0 && top_k < V) {
-        if (tid == 0) { s_prefix = 0u; s_remaining = top_k; }
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            if (tid < 256) hist[tid] = 0u;
-            __syncthreads();
-            const unsigned prefix = s_prefix;
-            const unsigned pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (int i = tid; i < V; i += 1024) {
-                const unsigned k = f2key(bf2f(row[i]) * inv_temp);
-                if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining; int b = 255;
-                for (; b > 0; --b) { if ((int)hist[b] >= rem) break; rem -= (int)hist[b]; }
-                s_prefix = prefix | ((unsigned)b << shift); s_remaining = rem;
-            }
-            __syncthreads();
-        }
-        thr_key = s_prefix;
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    int* tok_out = a.tokens + (int64_t)r * a.tok_ld + step;
+    if (samp_row_done(a, r)) { if (tid == 0) *tok_out = a.pad_id; return; }
+    unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
+    const float* sums = reinterpret_cast<const float*>(ws + 520);
+    if (tid == 0) {
+        sthr = samp_threshold(a, ws);
+        float Z = 0.f;
+        for (int i = 0; i < SAMP_S; ++i) Z += sums[i];
+        unsigned c[4] = {(unsigned)r, (unsigned)step, 0u, 0u};
+        philox4x32_10(c, (unsigned)(a.seed & 0xffffffffu), (unsigned)(a.seed >> 32));
+        const float uu = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        if (a.u_out) a.u_out[r] = uu;
+        const float target = uu * Z;
+        float acc = 0.f; int sl = 0;
+        for (; sl < SAMP_S - 1; ++sl) { if (acc + sums[sl] >= target) break; acc += sums[sl]; }
+        sslice = sl; sbase = acc; starget = target;
     }
-    const float thr = (thr_key == 0u) ? -INFINITY : key2f(thr_key);
-
-    // ---- max and the per-thread chunk sums of exp(x - M) over kept entries (vocabulary order)
-    const int per = (V + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(V, i0 + per);
-    float mx = -INFINITY;
-    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, bf2f(row[i]) * inv_temp);
-    mx = block_max(mx, red);
-    float cs = 0.f;
-    for (int i = i0; i < i1; ++i) { const float x = bf2f(row[i]) * inv_temp; if (x >= thr) cs += __expf(x - mx); }
-    chunk_sum[tid] = cs;
+    __syncthreads();
+    const unsigned thr = sthr;
+    const float mx = key_logit(ws[512]);
+    const bf16_t* row = a.logits + (int64_t)r * a.ld;
+    const int per = (a.V + SAMP_S - 1) / SAMP_S, i0 = sslice * per, i1 = min(a.V, i0 + per);
+    const int tper = (per + 255) / 256, j0 = i0 + tid * tper, j1 = min(i1, j0 + tper);   // contiguous run per thread: vocabulary order
+    float acc = 0.f;
+    for (int i = j0; i < j1; ++i) { const bf16_t b = row[i]; if (bfkey(b) >= thr) acc += __expf((bf2f(b) - mx) * a.inv_temp); }
+    part[tid] = acc;
     __syncthreads();
     if (tid == 0) {
-        float Z = 0.f;
-        for (int i = 0; i < 1024; ++i) Z += chunk_sum[i];
-        unsigned c[4] = {(unsigned)r, (unsigned)step, 0u, 0u};
-        philox4x32_10(c, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32));
-        const float uu = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        if (u_out) u_out[r] = uu;
-        const float target = uu * Z;
-        float acc = 0.f; int ch = 0;
-        for (; ch < 1023; ++ch) { if (acc + chunk_sum[ch] >= target) break; acc += chunk_sum[ch]; }
-        // walk inside the chunk; fall back to the last kept token for rounding slack
+        float c = sbase; int t = 0;
+        for (; t < 255; ++t) { if (c + part[t] >= starget) break; c += part[t]; }
         int tok = -1, last_kept = -1;
-        const int a0 = ch * per, a1 = min(V, a0 + per);
-        for (int i = a0; i < a1; ++i) {
-            const float x = bf2f(row[i]) * inv_temp;
-            if (x >= thr) { last_kept = i; acc += __expf(x - mx); if (acc >= target) { tok = i; break; } }
+        const int k0 = i0 + t * tper, k1 = min(i1, k0 + tper);
+        for (int i = k0; i < k1; ++i) {
+            const bf16_t b = row[i];
+            if (bfkey(b) >= thr) { last_kept = i; c += __expf((bf2f(b) - mx) * a.inv_temp); if (c >= starget) { tok = i; break; } }
         }
-        if (tok < 0) {
+        if (tok < 0) {   // rounding slack: fall back to the last kept token at or before this point
             if (last_kept >= 0) tok = last_kept;
-            else { for (int i = V - 1; i >= 0; --i) { if (bf2f(row[i]) * inv_temp >= thr) { tok = i; break; } } }
+            else { for (int i = min(k1, a.V) - 1; i >= 0; --i) { if (bfkey(row[i]) >= thr) { tok = i; break; } } }
+            if (tok < 0) { for (int i = 0; i < a.V; ++i) { if (bfkey(row[i]) >= thr) { tok = i; break; } } }
         }
-        s_token = tok;
         *tok_out = tok;
-        if (finished && tok == eos_id) finished[r] = 1;
+        if (a.finished && tok == a.eos_id) a.finished[r] = 1;
     }
 }
 
@@ -247,13 +306,24 @@ extern "C" int tr1_grpo_loss(const void* logp, const void* ref_logp, const void*
                        use_grpo, grad_scale);
     TR1_LAUNCH_CHECK();
 }
+extern "C" int64_t tr1_sample_workspace_words(int64_t rows) { return rows * SAMP_WS_WORDS; }
+
 extern "C" int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k,
                                  uint64_t seed, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id,
-                                 int64_t pad_id, int stop_at_eos, void* u_out, void* stream) {
+                                 int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* stream) {
     TR1_CHECK_ARG(temperature > 0.f, "sample: temperature must be > 0");
+    TR1_CHECK_ARG(ws_u32 && ws_words >= rows * SAMP_WS_WORDS, "sample: workspace too small (tr1_sample_workspace_words)");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, (int)V,
-                       1.0f / temperature, (int)top_k, (unsigned long long)seed, (const int*)step_ptr, (int*)tokens, tok_ld, (int*)finished,
-                       (int)eos_id, (int)pad_id, stop_at_eos, (float*)u_out);
+    hipStream_t s = (hipStream_t)stream;
+    SampleArgs a;
+    a.logits = (const bf16_t*)logits; a.ld = ld; a.V = (int)V; a.inv_temp = 1.0f / temperature; a.top_k = (int)top_k; a.seed = seed;
+    a.step_ptr = (const int*)step_ptr; a.tokens = (int*)tokens; a.tok_ld = tok_ld; a.finished = (int*)finished; a.eos_id = (int)eos_id;
+    a.pad_id = (int)pad_id; a.stop_at_eos = stop_at_eos; a.u_out = (float*)u_out; a.ws = (unsigned*)ws_u32;
+    hipMemsetAsync(ws_u32, 0, (size_t)rows * SAMP_WS_WORDS * 4, s);
+    dim3 grid(SAMP_S, (unsigned)rows);
+    hipLaunchKernelGGL(samp_hist_hi_kernel, grid, dim3(256), 0, s, a);     // also yields the row max (needed without top-k too)
+    if (top_k > 0 && top_k < V) hipLaunchKernelGGL(samp_hist_lo_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(samp_slice_sum_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(samp_pick_kernel, dim3((unsigned)rows), dim3(256), 0, s, a);
     TR1_LAUNCH_CHECK();
 }

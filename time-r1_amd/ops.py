@@ -328,9 +328,11 @@ class HipOps:
         self._chk(logits)
         assert tokens.dtype == I32 and (step_dev is None or step_dev.dtype == I32)
         rows, V = logits.shape
+        nws = self.L.raw("tr1_sample_workspace_words")(rows)
+        ws = self._workspace("sampler", nws, I32)
         self.L.call("tr1_sample_tokens", _p(logits), _ld(logits), rows, V, float(temperature), int(top_k or 0), int(seed) & (2**64 - 1),
                     _p(step_dev), _p(tokens), tokens.stride(0), _p(finished), int(eos_id), int(pad_id), int(bool(stop_at_eos)), _p(u_out),
-                    self._s())
+                    _p(ws), nws, self._s())
 
     # ---- optimizer ------------------------------------------------------------------------------------------------
     def sumsq_accum(self, g, out_scalar):
