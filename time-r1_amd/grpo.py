@@ -23,7 +23,7 @@ class StepState:
 
 class GRPOCore:
     def __init__(self, engine: Engine, ref_arena=None, num_generations=8, max_completion_length=200, beta=0.04, use_grpo=False,
-                 temperature=1.0, top_k=50, seed=1234, rope_index_mode="hf4", stop_at_eos=False):
+                 temperature=1.0, top_k=50, seed=1234, rope_index_mode="hf4", stop_at_eos=False, reuse_prefill=True):
         self.eng = engine
         self.ops = engine.ops
         self.cfg = engine.cfg
@@ -31,6 +31,9 @@ class GRPOCore:
         self.G, self.C = int(num_generations), int(max_completion_length)
         self.beta, self.use_grpo = float(beta), bool(use_grpo)
         self.rope_index_mode = rope_index_mode
+        # The rollout's prefill IS the policy forward over the prompt rows (same weights inside an accumulation window): keep its
+        # activations and run the update's policy forward over the G*C completion rows only.
+        self.reuse_prefill = bool(reuse_prefill)
         self.roll = Rollout(engine, self.G, self.C, temperature, top_k, seed, stop_at_eos)
         if self.beta != 0.0 and ref_arena is None:
             raise ValueError("beta != 0 needs a reference-policy arena (reference timer1_trainer.py:295-307)")
@@ -67,17 +70,21 @@ class GRPOCore:
 
     # ------------------------------------------------------------------------------------------------------- phase 2
     def rollout(self, st):
-        tokens, lay = self.roll.generate(self.eng.params.train, st.prompt_ids, st.vid_embeds, st.vid_rows, st.pos3_prompt, st.delta)
+        tokens, lay = self.roll.generate(self.eng.params.train, st.prompt_ids, st.vid_embeds, st.vid_rows, st.pos3_prompt, st.delta,
+                                         save_prefill=self.reuse_prefill)
         st.layout = lay
         st.completion_ids = tokens        # int32 [G, C] on device
+        st.prefill = self.roll.last_prefill[0] if self.reuse_prefill else None
         return tokens
 
     def rollout_many(self, states):
         """Decode the prompts of one accumulation window together (weights are constant inside it): every weight byte streamed
         from HBM serves len(states)*G rows. Sampling streams stay per prompt, so tokens equal the one-by-one rollout's."""
-        outs = self.roll.generate_many(self.eng.params.train, [(st.prompt_ids, st.vid_embeds, st.vid_rows, st.pos3_prompt, st.delta) for st in states])
-        for st, (tokens, lay) in zip(states, outs):
+        outs = self.roll.generate_many(self.eng.params.train, [(st.prompt_ids, st.vid_embeds, st.vid_rows, st.pos3_prompt, st.delta) for st in states],
+                                       save_prefill=self.reuse_prefill)
+        for b, (st, (tokens, lay)) in enumerate(zip(states, outs)):
             st.layout, st.completion_ids = lay, tokens
+            st.prefill = self.roll.last_prefill[b] if self.reuse_prefill else None
         return [st.completion_ids for st in states]
 
     # ------------------------------------------------------------------------------------------------------- phase 3
@@ -106,8 +113,23 @@ class GRPOCore:
         eng, ops = self.eng, self.ops
         self._packed_inputs(st)
         tr = eng.params.train
-        h0 = eng.embed(tr, st.ids_packed, st.vid_embeds, st.vid_rows)
-        hL, st.llm_ctx = eng.llm_fwd(tr, h0, st.cos, st.sin, st.masks, save=True)
+        pf = getattr(st, "prefill", None)
+        if pf is not None and pf[0] is not None:
+            # continuation: only the G*C completion rows; the prompt rows' activations and K/V come from the rollout's prefill
+            P, M = st.P, st.layout.M
+            pctx, kv = pf
+            hc = ops.gather_rows(tr.w("embed"), st.ids_packed[P:].contiguous())
+            cmask = [m[P:].contiguous() for m in st.masks]
+            hLc, cctx = eng.llm_fwd(tr, hc, st.cos[P:].contiguous(), st.sin[P:].contiguous(), cmask, save=True, kv_cache=kv, row0=P)
+            st.llm_ctx = eng.merge_ctx(pctx, cctx, kv, st.masks, st.cos, st.sin, M)
+            # the head only needs the last prompt row (it predicts every group's first completion token) and the completion rows
+            hL = ops.zeros(M, hLc.shape[1])
+            hL[P:] = hLc
+            hL[P - 1:P] = pctx["h_last"][P - 1:P]
+            st.prefill = None
+        else:
+            h0 = eng.embed(tr, st.ids_packed, st.vid_embeds, st.vid_rows)
+            hL, st.llm_ctx = eng.llm_fwd(tr, h0, st.cos, st.sin, st.masks, save=True)
         logp, ent, st.head_ctx = eng.head_fwd(tr, hL, st.pred_rows, st.targets, save=True)
         st.logp = self._to_gc(st, logp).contiguous()
         st.entropy = self._to_gc(st, ent).contiguous()

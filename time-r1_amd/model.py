@@ -97,12 +97,15 @@ class Engine:
             self.ops.scatter_rows(vid_embeds, vid_rows, h)
         return h
 
-    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None):
+    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0):
         """Decoder stack over a packed sequence of M rows. masks = (pre, lo, hi) int32 [M] over slots == rows.
         kv_cache: optional list of (K [S_cap, kv_dim], VT [kv_dim, S_cap]) to be filled (rollout prefill).
+        row0 > 0 ("continuation"): h holds only rows [row0, row0+M) of the packed sequence; their K/V are written to cache slots
+        [row0, row0+M) and attention runs over slots [0, row0+M) - the prefix K/V of rows [0,row0) must already be in kv_cache.
         Returns (h_out, ctx) where ctx holds the saved activations when save=True."""
         ops, t = self.ops, self.cfg.text
         M = h.shape[0]
+        S = row0 + M
         pre, lo, hi = masks
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
         scale = hd ** -0.5
@@ -114,14 +117,18 @@ class Engine:
             q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cos, sin)
             if kv_cache is not None:
                 kc, vtc = kv_cache[i]
-                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin, out=kc[:M])
-                vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc)
+                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin, out=kc[row0:S])
+                if row0 == 0:
+                    vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc)
+                else:
+                    vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc[:, row0:], zero_pad=False)
+                    vt = vtc
                 k_all = kc
             else:
                 k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin)
                 vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd)
                 k_all = k
-            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, M, hd, scale, need_lse=save)
+            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save)
             h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
             xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save)
             gu = ops.gemm_nt(xn2, arena.w(p + "gu.w"))
@@ -130,8 +137,23 @@ class Engine:
             if save:
                 layers.append(dict(h=h, rstd1=rstd1, xn=xn, qkv=qkv, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
             h = h_out
-        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin) if save else None
+        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin, h_last=h) if save else None
         return h, ctx
+
+    @staticmethod
+    def merge_ctx(ctx_a, ctx_b, kv_cache, masks, cos, sin, M):
+        """Stitch the saved activations of a prefix forward (rows [0,P)) and its continuation (rows [P,M)) into the [M, .] form
+        llm_bwd expects. K comes from the cache (rows [0,M) in packed order); lse is [n_heads, rows] so it is joined along dim 1."""
+        layers = []
+        for i, (a, b) in enumerate(zip(ctx_a["layers"], ctx_b["layers"])):
+            L = {}
+            for key in ("h", "xn", "qkv", "q", "o", "h2", "xn2", "gu", "a", "rstd1", "rstd2"):
+                L[key] = torch.cat([a[key], b[key]], 0)
+            L["lse"] = torch.cat([a["lse"], b["lse"]], 1).contiguous()
+            L["k"] = kv_cache[i][0][:M]
+            layers.append(L)
+            ctx_a["layers"][i] = ctx_b["layers"][i] = None
+        return dict(layers=layers, masks=masks, cos=cos, sin=sin)
 
     def llm_bwd(self, ctx, dh):
         """dh: gradient wrt the decoder stack output [M, d]. Accumulates parameter grads; returns the gradient wrt the input embeddings."""

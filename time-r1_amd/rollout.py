@@ -45,12 +45,13 @@ class Rollout:
             c = self._cache = KVCache(self.eng.ops, t.n_layers, t.kv_dim, s_cap, B)
         return c
 
-    def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta):
+    def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta, save_prefill=False):
         """One prompt. prompt_ids: int32 device tensor [P]; prompt_pos3: numpy [3, P]; returns (tokens int32 [G, C] on device, layout)."""
-        return self.generate_many(arena, [(prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta)])[0]
+        return self.generate_many(arena, [(prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta)], save_prefill)[0]
 
-    def generate_many(self, arena, items):
+    def generate_many(self, arena, items, save_prefill=False):
         """items: list of (prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta), decoded together. Returns [(tokens [G, C], layout)].
+        save_prefill: keep the prompt rows' activations so the policy forward of the update can skip the prompt (same weights).
         Each prompt keeps its own sampling stream (seed advances per prompt), so results do not depend on how prompts are batched."""
         eng, ops, cfg = self.eng, self.eng.ops, self.eng.cfg
         t = cfg.text
@@ -76,7 +77,7 @@ class Rollout:
             cos, sin = ops.mrope_table(pos_p, t.head_dim, t.mrope_section, t.rope_theta)
             masks = [ops.tensor(a, I32) for a in lay.prompt_masks()]
             h = eng.embed(arena, prompt_ids, vid_embeds, vid_rows)
-            hL, _ = eng.llm_fwd(arena, h, cos, sin, masks, save=False, kv_cache=kv_views)
+            hL, pctx = eng.llm_fwd(arena, h, cos, sin, masks, save=save_prefill, kv_cache=kv_views)
             hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
             logits = ops.gemm_nt(hn, w_lm)  # [1, V]
             tokens = tokens_all[b * G:(b + 1) * G]
@@ -92,7 +93,7 @@ class Rollout:
             slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
             pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
             nsplit = max(1, min(28, ((P + 63) // 64 + 3) // 2))
-            per.append(dict(lay=lay, kv=kv_views, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
+            per.append(dict(lay=lay, kv=kv_views, prefill_ctx=pctx, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
         cos_all = torch.cat(cos_rows, 1).contiguous()      # [C, B*G, half]
         sin_all = torch.cat(sin_rows, 1).contiguous()
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
@@ -122,4 +123,5 @@ class Rollout:
             for b, st in enumerate(per):
                 ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
                                   st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+        self.last_prefill = [(st["prefill_ctx"], st["kv"]) for st in per]    # (saved prompt activations, cache views) per prompt
         return [(st["tokens"], st["lay"]) for st in per]
