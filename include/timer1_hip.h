@@ -78,8 +78,9 @@ int tr1_embed_bwd(const void* dout, const void* ids, void* dtable_f32, int64_t T
  * ref: flash_attn_varlen_func / SDPA via TF:379-396 (ViT, cu_seqlens segments) and TF:521-556 (LLM causal GQA); the shared-prefix
  * form replaces the G-times replicated prompt of timer1_trainer.py:594-599.  Q/O: [T, n_heads*head_dim]; K: [slots, n_kv*head_dim];
  * VT: [n_kv*head_dim, vt_ld] (slot-contiguous).  lse (optional): fp32 [n_heads, T].  nsplit > 1 = split-KV (decode) with a
- * caller workspace of tr1_attn_fwd_workspace_floats() floats. */
-int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, void* stream);
+ * caller workspace of n_batch * tr1_attn_fwd_workspace_floats() floats.  n_batch > 1 runs n_batch independent problems in one launch:
+ * problem b uses Q/O/mask rows [b*T, (b+1)*T) and cache slots starting at b*kv_batch_slots (decode over several prompts' caches). */
+int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* stream);
 int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit);
 /* Backward of the above (recompute based): needs K, V row-major and the transposed copies KT, QT, dOT (tr1_pack_transpose).
  * delta: fp32 [n_heads, T] scratch; qmeta_ws: int32 [3*ceil(T*group/64)] scratch; ws_f32: tr1_attn_bwd_workspace_floats() floats (fp32 dK/dV

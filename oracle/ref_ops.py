@@ -255,7 +255,17 @@ class RefOps:
         o = (p @ vh).transpose(0, 1).reshape(T, n_heads * head_dim)
         return o, lse
 
-    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None):
+    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
+                 kv_batch_slots=0):
+        if n_batch > 1:   # independent problems: rows [b*T,(b+1)*T) against cache slots [b*kv_batch_slots, ...)
+            T = q.shape[0] // n_batch
+            res = out if out is not None else torch.zeros(q.shape[0], n_heads * head_dim, dtype=self.act_dtype)
+            for b in range(n_batch):
+                a, e = b * T, (b + 1) * T
+                s0 = b * kv_batch_slots
+                self.attn_fwd(q[a:e], k[s0:], vt[:, s0:], pre[a:e], lo[a:e], hi[a:e], n_heads, n_kv, n_slots, head_dim, scale, need_lse=False,
+                              out=res[a:e])
+            return res, None
         v = vt[:, :n_slots].float().t().contiguous()  # [S, n_kv*hd]
         o, lse = self._dense_attn(q.float(), k.float(), v, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale)
         if out is not None:

@@ -370,3 +370,25 @@ def test_decode_qkv_post(hip_ops, ref_ops):
     close(q_h, q_r, 0.02, what="fused q rope")
     close(kc_h, kc_r, 0.02, what="fused k append")
     assert torch.equal(vt_h.float().cpu(), vt_r), "fused v append must be exact"
+
+
+def test_attention_decode_batched_prompts(hip_ops, ref_ops):
+    """One launch for the decode rows of several prompts, each over its own region of a unified KV cache."""
+    B, G, C, step, nh, nkv, hd = 3, 8, 12, 5, 14, 2, 128
+    Ps = [300, 170, 420]
+    s_cap = 576
+    k, v = rnd(B * s_cap, nkv * hd, seed=1), rnd(B * s_cap, nkv * hd, seed=2)
+    q = rnd(B * G, nh * hd, seed=3)
+    pre = torch.cat([torch.full((G,), P, dtype=torch.int32) for P in Ps])
+    lo = torch.cat([(P + torch.arange(G) * C).int() for P in Ps])
+    hi = (lo + step).int()
+    vt_h = torch.zeros(nkv * hd, B * s_cap, dtype=BF16, device="cuda:0")
+    vt_r = torch.zeros(nkv * hd, B * s_cap)
+    for b in range(B):
+        vt_h[:, b * s_cap:(b + 1) * s_cap] = hip_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].cuda(), nkv, nkv, hd)
+        vt_r[:, b * s_cap:(b + 1) * s_cap] = ref_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].float(), nkv, nkv, hd)
+    o_r, _ = ref_ops.attn_fwd(q.float(), k.float(), vt_r, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, n_batch=B, kv_batch_slots=s_cap)
+    for nsplit in (1, 5, 12):
+        o_h, _ = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
+                                  need_lse=False, n_batch=B, kv_batch_slots=s_cap)
+        close(o_h, o_r, 0.02, what="batched decode attention nsplit=%d" % nsplit)

@@ -39,6 +39,7 @@ struct AttnParams {
     const int* qmeta;                  // [n_qtiles64, 3] (max pre, min lo, max hi) per 64 packed rows (backward only)
     float* Opart; float* mpart; float* lpart;       // split-KV workspaces
     int T, group, n_kv, n_slots, d_real, nsplit;
+    int n_batch; int64_t kv_batch_slots;   // forward only: batch b uses Q/O/mask rows [b*T,(b+1)*T) and cache slots [b*kv_batch_slots, ...)
     float scale_log2;                  // softmax scale * log2(e)
 };
 

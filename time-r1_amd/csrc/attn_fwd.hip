@@ -7,11 +7,18 @@
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int KSTR = 2 * D + 16;
+    {   // batched launch (decode over several prompts' caches): blockIdx.y = b * n_kv + kvh
+        const int b = blockIdx.y / p.n_kv;
+        p.Q += (int64_t)b * p.T * p.q_ld; p.O += (int64_t)b * p.T * p.o_ld;
+        p.pre += (int64_t)b * p.T; p.lo += (int64_t)b * p.T; p.hi += (int64_t)b * p.T;
+        p.K += (int64_t)b * p.kv_batch_slots * p.k_ld; p.VT += (int64_t)b * p.kv_batch_slots;
+        if (p.lse) p.lse += (int64_t)b * p.n_kv * p.group * p.T;
+    }
     constexpr int KBYTES = ATT_KV * KSTR, VBYTES = D * 144, BUF = KBYTES + VBYTES;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];      // [2][K tile | V^T tile] + meta
     int* lds_meta = reinterpret_cast<int*>(dyn_lds + 2 * BUF);          // [4][3]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int kvh = blockIdx.y, split = blockIdx.z;
+    const int kvh = blockIdx.y % p.n_kv, split = blockIdx.z;
     const int64_t nR = (int64_t)p.T * p.group;
     const int64_t R0 = (int64_t)blockIdx.x * 128 + wave * 32;
 
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int cb = 0; cb < 2; ++cb) {
             if (!valid[cb]) continue;
             const int64_t R = R0 + cb * 16 + u;
-            const int64_t slot = ((int64_t)split * p.n_kv + kvh) * nRpad + R;
+            const int64_t slot = ((int64_t)split * gridDim.y + blockIdx.y) * nRpad + R;
             float* op = p.Opart + slot * D;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4_t*>(op + dt * 16 + g * 4) = o[dt][cb];
@@ -190,13 +197,18 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t nRpad) {
     __shared__ float sm_m[8][64], sm_l[8][64];
     const int64_t nR = (int64_t)p.T * p.group;
-    const int kvh = blockIdx.y;
+    const int kvh = blockIdx.y % p.n_kv, by = blockIdx.y, nby = gridDim.y;
+    {
+        const int b = blockIdx.y / p.n_kv;
+        p.O += (int64_t)b * p.T * p.o_ld;
+        if (p.lse) p.lse += (int64_t)b * p.n_kv * p.group * p.T;
+    }
     const int rl = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int64_t Rb = (int64_t)blockIdx.x * 8;
     for (int i = threadIdx.x; i < 8 * p.nsplit; i += 256) {
         const int r = i / p.nsplit, s = i - r * p.nsplit;
         const int64_t R = Rb + r;
-        const int64_t slot = ((int64_t)s * p.n_kv + kvh) * nRpad + R;
+        const int64_t slot = ((int64_t)s * nby + by) * nRpad + R;
         sm_m[r][s] = (R < nR) ? p.mpart[slot] : NEG_INF;
         sm_l[r][s] = (R < nR) ? p.lpart[slot] : 0.f;
     }
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int s = 0; s < p.nsplit; ++s) {
-            const int64_t slot = ((int64_t)s * p.n_kv + kvh) * nRpad + R;
+            const int64_t slot = ((int64_t)s * nby + by) * nRpad + R;
             acc += exp2f(sm_m[rl][s] - Ms) * *reinterpret_cast<const f32x4_t*>(p.Opart + slot * D + d);
         }
         if (d < p.d_real) {
@@ -292,8 +304,11 @@ static int attn_check(const AttnParams& p, int d_pad) {
 
 extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
                             void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
-                            int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, void* stream) {
+                            int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
+                            int64_t kv_batch_slots, void* stream) {
     AttnParams p; memset(&p, 0, sizeof(p));
+    TR1_CHECK_ARG(n_batch >= 1, "attention: n_batch must be >= 1");
+    p.n_batch = (int)n_batch; p.kv_batch_slots = kv_batch_slots;
     p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.VT = (const bf16_t*)VT; p.vt_ld = vt_ld;
     p.O = (bf16_t*)O; p.o_ld = o_ld; p.lse = (float*)lse; p.pre = (const int*)pre; p.lo = (const int*)lo; p.hi = (const int*)hi;
     TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention: n_heads must be a multiple of n_kv");
@@ -307,11 +322,11 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     const int qtiles = (int)((nR + 127) / 128);
     const int64_t nRpad = (int64_t)qtiles * 128;
     if (nsplit > 1) {
-        const int64_t need = nsplit * n_kv * nRpad * (d_pad + 2);
+        const int64_t need = nsplit * n_batch * n_kv * nRpad * (d_pad + 2);
         TR1_CHECK_ARG(ws_f32 && ws_floats >= need, "attention: split-KV workspace too small");
-        p.Opart = (float*)ws_f32; p.mpart = p.Opart + nsplit * n_kv * nRpad * d_pad; p.lpart = p.mpart + nsplit * n_kv * nRpad;
+        p.Opart = (float*)ws_f32; p.mpart = p.Opart + nsplit * n_batch * n_kv * nRpad * d_pad; p.lpart = p.mpart + nsplit * n_batch * n_kv * nRpad;
     }
-    dim3 grid(qtiles, (unsigned)n_kv, (unsigned)nsplit);
+    dim3 grid(qtiles, (unsigned)(n_kv * n_batch), (unsigned)nsplit);
     hipStream_t s = (hipStream_t)stream;
     switch (d_pad) {
         case 32: launch_fwd<32>(grid, s, p); break;
@@ -320,7 +335,7 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
         default: launch_fwd<128>(grid, s, p); break;
     }
     if (nsplit > 1) {
-        dim3 cg((unsigned)((nR + 7) / 8), (unsigned)n_kv);
+        dim3 cg((unsigned)((nR + 7) / 8), (unsigned)(n_kv * n_batch));
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;
             case 64: hipLaunchKernelGGL(attn_combine_kernel<64>, cg, dim3(256), 0, s, p, nRpad); break;
@@ -332,6 +347,7 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
 }
 
 extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit) {
+    // per batch entry; multiply by n_batch for a batched launch
     if (nsplit <= 1 || n_kv <= 0) return 0;
     const int64_t nR = T * (n_heads / n_kv);
     const int64_t nRpad = (nR + 127) / 128 * 128;

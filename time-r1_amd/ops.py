@@ -261,18 +261,22 @@ class HipOps:
                     _p(slots), R, n_heads, n_kv, head_dim, self._s())
         return q
 
-    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None):
+    def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
+                 kv_batch_slots=0):
+        """n_batch > 1: q/out/masks hold n_batch problems of T = rows/n_batch tokens each; problem b reads cache slots from b*kv_batch_slots."""
         self._chk(q, k, vt)
         assert pre.dtype == I32 and lo.dtype == I32 and hi.dtype == I32
-        T = q.shape[0]
-        o = out if out is not None else self.empty(T, n_heads * head_dim)
-        lse = self.empty(n_heads, T, dtype=F32) if need_lse else None
+        rows = q.shape[0]
+        assert rows % n_batch == 0
+        T = rows // n_batch
+        o = out if out is not None else self.empty(rows, n_heads * head_dim)
+        lse = self.empty(n_batch * n_heads, T, dtype=F32) if need_lse else None
         ws, nws = None, 0
         if nsplit > 1:
-            nws = self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
+            nws = n_batch * self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
             ws = self._workspace("attn_split", nws, F32)
         self.L.call("tr1_attn_fwd", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
-                    n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, self._s())
+                    n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, self._s())
         return o, lse
 
     def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):

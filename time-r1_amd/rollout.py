@@ -96,6 +96,10 @@ class Rollout:
             per.append(dict(lay=lay, kv=kv_views, prefill_ctx=pctx, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
         cos_all = torch.cat(cos_rows, 1).contiguous()      # [C, B*G, half]
         sin_all = torch.cat(sin_rows, 1).contiguous()
+        pre_all = torch.cat([st["pre"] for st in per]).contiguous()
+        lo_all = torch.cat([st["lo"] for st in per]).contiguous()
+        hi_all = torch.cat([st["slots"] for st in per], 1).contiguous()        # [C, B*G]: hi of step s = the slot just appended (cache-local)
+        nsplit = max(st["nsplit"] for st in per)
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
         R = B * G
 
@@ -108,12 +112,9 @@ class Rollout:
                 xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
                 qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
                 q = ops.decode_qkv_post(qkv, cs, sn, cache.k[i], cache.vt[i], abs_slots[s], t.n_heads, t.n_kv_heads, hd)
-                o = ops.empty(R, qd)
-                for b, st in enumerate(per):
-                    kc, vtc = st["kv"][i]
-                    r0, r1 = b * G, (b + 1) * G
-                    ops.attn_fwd(q[r0:r1], kc, vtc, st["pre"], st["lo"], st["slots"][s], t.n_heads, t.n_kv_heads, st["lay"].M, hd, scale,
-                                 nsplit=st["nsplit"], need_lse=False, out=o[r0:r1])
+                # one launch for all prompts of the window: problem b = rows [b*G,(b+1)*G) over cache slots [b*s_cap, (b+1)*s_cap)
+                o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
+                                    nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap)
                 h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
                 xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
                 a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
