@@ -240,20 +240,38 @@ class RefOps:
         vtcache[:, slots.long()] = qkv[:, qd + kvd:].t()
         return q
 
-    def _dense_attn(self, q, k, v, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale):
+    def _dense_attn(self, q, k, v, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, chunk=1024):
+        """Masked softmax attention, evaluated per block of query rows against only the key range those rows can see
+        (a ViT frame segment, or the causal prefix) - same numbers as the dense [T, S] form, without materialising it."""
         T = q.shape[0]
         group = n_heads // n_kv
-        qh = q.reshape(T, n_heads, head_dim).transpose(0, 1)  # [H, T, d]
-        kh = k[:n_slots].reshape(n_slots, n_kv, head_dim).transpose(0, 1).repeat_interleave(group, 0)  # [H, S, d]
-        vh = v[:n_slots].reshape(n_slots, n_kv, head_dim).transpose(0, 1).repeat_interleave(group, 0)
-        s = (qh @ kh.transpose(1, 2)) * scale
-        vis = visible_mask(pre, lo, hi, n_slots)
-        s = s.masked_fill(~vis[None], float("-inf"))
-        lse = torch.logsumexp(s, -1)  # [H, T]
-        p = torch.exp(s - lse[..., None])
-        p = torch.nan_to_num(p, nan=0.0)
-        o = (p @ vh).transpose(0, 1).reshape(T, n_heads * head_dim)
-        return o, lse
+        kh_all = k[:n_slots].reshape(n_slots, n_kv, head_dim).transpose(0, 1)   # [n_kv, S, d]
+        vh_all = v[:n_slots].reshape(n_slots, n_kv, head_dim).transpose(0, 1)
+        outs, lses = [], []
+        pre_l, lo_l, hi_l = pre.long(), lo.long(), hi.long()
+        for a0 in range(0, T, chunk):
+            a1 = min(T, a0 + chunk)
+            pmax = int(pre_l[a0:a1].max())
+            nonempty = hi_l[a0:a1] >= lo_l[a0:a1]
+            if bool(nonempty.any()):
+                lmin, hmax = int(lo_l[a0:a1][nonempty].min()), int(hi_l[a0:a1][nonempty].max())
+            else:
+                lmin, hmax = 0, -1
+            k0 = 0 if pmax > 0 else max(0, min(lmin, n_slots))
+            k1 = min(n_slots, max(pmax, hmax + 1))
+            k1 = max(k1, k0 + 1)
+            qh = q[a0:a1].reshape(a1 - a0, n_heads, head_dim).transpose(0, 1)                      # [H, t, d]
+            kh = kh_all[:, k0:k1].repeat_interleave(group, 0)
+            vh = vh_all[:, k0:k1].repeat_interleave(group, 0)
+            s = (qh @ kh.transpose(1, 2)) * scale
+            kv = torch.arange(k0, k1)[None, :]
+            vis = (kv < pre_l[a0:a1, None]) | ((kv >= lo_l[a0:a1, None]) & (kv <= hi_l[a0:a1, None]))
+            s = s.masked_fill(~vis[None], float("-inf"))
+            lse = torch.logsumexp(s, -1)
+            p = torch.nan_to_num(torch.exp(s - lse[..., None]), nan=0.0)
+            outs.append((p @ vh).transpose(0, 1).reshape(a1 - a0, n_heads * head_dim))
+            lses.append(lse)
+        return torch.cat(outs, 0), torch.cat(lses, 1)
 
     def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
                  kv_batch_slots=0):
