@@ -157,6 +157,135 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 256x256x64 variant for large outputs: 512 threads = 8 waves (2 x 4), each wave owns 128x64 = 8x4 MFMA tiles, so every
+// ds_read_b128 feeds more MFMAs (12 fragment reads per 32 MFMAs instead of 16) and the HBM/L2 traffic per FLOP halves.
+// Same staging / swizzle / epilogue scheme as gemm_nt_kernel; 128 KiB of LDS (two buffers), one block per CU.
+// ------------------------------------------------------------------------------------------------------------------
+#define BM2 256
+#define BN2 256
+#define TILE2_BYTES (BM2 * BK * 2)  // 32 KiB per operand per buffer
+
+template <bool IS_B>
+TR1_DEV void stage_tile256(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
+                           int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = wave * 4 + i;                 // 32 instructions of 8 rows each
+        const int row = inst * 8 + (lane >> 3);
+        const int phys = lane & 7;
+        const int logical = phys ^ (IS_B ? keyB(row) : keyA(row));
+        int64_t grow = row0 + row;
+        if (grow >= rows_valid) grow = rows_valid - 1;
+        const bf16_t* src = g + grow * ld + k0 + logical * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+    }
+}
+
+template <bool OUT_F32, bool ACCUM>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
+                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                                         int64_t ldr, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];  // [buf][A|B], 4 * 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = tiles_m * tiles_n;
+    int wgid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int GROUP_M = 4;
+    const int group = wgid / (GROUP_M * tiles_n);
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = wgid - group * GROUP_M * tiles_n;
+    const int tm = first_m + in_group % gsz;
+    const int tn = in_group / gsz;
+    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(K / BK);
+    stage_tile256<false>(A, lda, m0, M, 0, smem2, wave, lane);
+    stage_tile256<true>(B, ldb, n0, N, 0, smem2 + TILE2_BYTES, wave, lane);
+    const int u = lane & 15, g = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        char* curA = smem2 + (kt & 1) * 2 * TILE2_BYTES;
+        char* curB = curA + TILE2_BYTES;
+        if (kt + 1 < nk) {
+            char* nxtA = smem2 + ((kt + 1) & 1) * 2 * TILE2_BYTES;
+            stage_tile256<false>(A, lda, m0, M, (int64_t)(kt + 1) * BK, nxtA, wave, lane);
+            stage_tile256<true>(B, ldb, n0, N, (int64_t)(kt + 1) * BK, nxtA + TILE2_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t xa[8], wb[4];
+            const int chunk = ks * 4 + g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + (u >> 2) * 16 + j * 4 + (u & 3);
+                wb[j] = *reinterpret_cast<const bf16x8_t*>(curB + row * 128 + ((chunk ^ keyB(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wm * 128 + i * 16 + u;
+                xa[i] = *reinterpret_cast<const bf16x8_t*>(curA + row * 128 + ((chunk ^ keyA(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int64_t nbase = n0 + wn * 64 + g * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + wm * 128 + i * 16 + u;
+        if (m >= M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t n = nbase + h * 8;
+            if (n + 8 > N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][h * 2 + (e >> 2)][e & 3];
+            if (bias) {
+                const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(bv[e]); v[2 * e + 1] += bfhi(bv[e]); }
+            }
+            if (residual) {
+                const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
+            }
+            if (OUT_F32) {
+                float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
+                f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                if (ACCUM) {
+                    const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(cp), p1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
+                    o0 += p0; o1 += p1;
+                }
+                *reinterpret_cast<f32x4_t*>(cp) = o0;
+                *reinterpret_cast<f32x4_t*>(cp + 4) = o1;
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(Cv) + m * ldc + n;
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<u32x4_t*>(cp) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Skinny GEMM for the decode regime (M <= 16 rows, one new token per rollout row): out[M,N] = x[M,K] * W[N,K]^T.
 // HBM-bound weight streaming: every W element is read exactly once, straight from global memory into the MFMA A
 // fragment (no LDS: the operand is not shared between waves).  A block owns 16 output columns; its 4 waves split K
@@ -273,6 +402,30 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
         else SK(4, 4, 1);
 #undef SK
         TR1_LAUNCH_CHECK();
+    }
+    {   // large outputs: 256x256 tiles when they still give >= ~2.3 rounds of 256 CUs (tile-count quantisation)
+        static int force256 = -1;
+        if (force256 < 0) { const char* e = getenv("TR1_GEMM_TILE"); force256 = e ? atoi(e) : 0; }
+        const int64_t t2m = (M + BM2 - 1) / BM2, t2n = (N + BN2 - 1) / BN2;
+        const bool big = (force256 == 256) || (force256 == 0 && t2m * t2n >= 600 && M >= 512);
+        if (big && force256 != 128) {
+            const size_t dyn = 4 * TILE2_BYTES;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                attr_set = true;
+            }
+            dim3 grid2((unsigned)(t2m * t2n));
+#define LAUNCH2(OF, AC)                                                                                                               \
+    hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
+                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n)
+            if (out_f32) { if (accumulate) LAUNCH2(true, true); else LAUNCH2(true, false); }
+            else LAUNCH2(false, false);
+#undef LAUNCH2
+            TR1_LAUNCH_CHECK();
+        }
     }
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     dim3 grid((unsigned)(tiles_m * tiles_n));

@@ -9,7 +9,7 @@
 
 #define NORM_MAXC 8  // 8 chunks x 8 elems x 64 lanes = 4096 columns
 
-template <bool HAS_RES>
+template <bool HAS_RES, bool HOIST_W>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
                                                           const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
                                                           bf16_t* __restrict__ xsum, float* __restrict__ rstd_out,
@@ -46,21 +46,32 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
                 for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
             }
         }
+        // The weight row does not depend on the reduction.  For the few-row decode case (latency bound) its loads are issued before
+        // the cross-lane sum so the two latencies overlap; for many rows (bandwidth bound) they stay behind it to save registers.
+        const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(w);
+        u32x4_t wv[NORM_MAXC];
+        if (HOIST_W) {
+#pragma unroll
+            for (int i = 0; i < NORM_MAXC; ++i) {
+                const int c = lane + i * 64;
+                if (c < nch) wv[i] = wr[c];
+            }
+        }
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss / (float)cols + eps);
         if (lane == 0 && rstd_out) rstd_out[r] = rstd;
-        const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(w);
         u32x4_t* yr = reinterpret_cast<u32x4_t*>(y + (size_t)r * cols);
 #pragma unroll
         for (int i = 0; i < NORM_MAXC; ++i) {
             const int c = lane + i * 64;
             if (c < nch) {
-                u32x4_t wv = wr[c], o;
+                u32x4_t o;
+                if (!HOIST_W) wv[i] = wr[c];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // bf16(x*rstd) then * weight, rounded again (reference cast order)
-                    float a = bf2f(f2bf(v[i][2 * j] * rstd)) * bflo(wv[j]);
-                    float b = bf2f(f2bf(v[i][2 * j + 1] * rstd)) * bfhi(wv[j]);
+                    float a = bf2f(f2bf(v[i][2 * j] * rstd)) * bflo(wv[i][j]);
+                    float b = bf2f(f2bf(v[i][2 * j + 1] * rstd)) * bfhi(wv[i][j]);
                     o[j] = pack2bf(a, b);
                 }
                 yr[c] = o;
@@ -279,12 +290,13 @@ extern "C" int tr1_rmsnorm_fwd(const void* x, const void* residual, const void* 
     TR1_CHECK_ARG(!residual || xsum, "rmsnorm: residual given without xsum output");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (residual)
-        hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, dim3(norm_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual,
-                           (const bf16_t*)w, (bf16_t*)y, (bf16_t*)xsum, (float*)rstd, (int)rows, (int)cols, eps);
-    else
-        hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, dim3(norm_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr,
-                           (const bf16_t*)w, (bf16_t*)y, (bf16_t*)nullptr, (float*)rstd, (int)rows, (int)cols, eps);
+#define RMS_LAUNCH(HR, HW)                                                                                                             \
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<HR, HW>), dim3(norm_grid(rows)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, \
+                       (const bf16_t*)w, (bf16_t*)y, (bf16_t*)xsum, (float*)rstd, (int)rows, (int)cols, eps)
+    const bool few = rows <= 256;
+    if (residual) { if (few) RMS_LAUNCH(true, true); else RMS_LAUNCH(true, false); }
+    else { if (few) RMS_LAUNCH(false, true); else RMS_LAUNCH(false, false); }
+#undef RMS_LAUNCH
     TR1_LAUNCH_CHECK();
 }
 
