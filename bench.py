@@ -227,6 +227,8 @@ def main():
 
     rank, local, world = init_from_env("cuda")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if os.environ.get("TR1_FORCE_DEVICE") is not None:      # test hook: several ranks on one GPU (gloo backend)
+        local = int(os.environ["TR1_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     from time_r1_amd.ops import HipOps
@@ -277,11 +279,14 @@ def main():
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga},
         }
     # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step
-    if rank == 0 and not args.no_roofline:
-        rec, orig = instrument_gemms(ops)
+    if not args.no_roofline:
+        # every rank runs the extra window (it contains the gradient all-reduce); only rank 0 records events
+        rec, orig = instrument_gemms(ops) if rank == 0 else ([], None)
         wl.window()
         torch.cuda.synchronize()
-        ops.gemm_nt = orig
+        if rank == 0:
+            ops.gemm_nt = orig
+    if rank == 0 and not args.no_roofline:
         nstep = float(args.ga)
         big_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if not s)
         big_fl = sum(2.0 * M * N * K for s, M, N, K, e0, e1 in rec if not s)

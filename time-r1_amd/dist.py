@@ -53,8 +53,8 @@ def init_from_env(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        backend = os.environ.get("TR1_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")   # "nccl" IS RCCL on ROCm
         if device_type == "cuda":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("TR1_FORCE_DEVICE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
