@@ -300,6 +300,16 @@ def main():
         hbm = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
                "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms / nstep, "traffic": None}
         hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
+        # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, gfx950 x2 read
+        # correction; same workload shapes) - PMC counters cannot be collected inside this un-profiled run
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if args.model == "qwen2-vl-7b" and args.G == 8 and args.ga == 2:
+                hbm["traffic"] = pmc["gemm_skinny_kernel"]["fetch_bytes_per_launch_corrected"]
+                hbm["algorithmic_bytes_per_launch"] = sk_by / max(sk_n, 1)
+                hbm["traffic_source"] = "profiles/r01_pmc_traffic.json"
+        except Exception:
+            pass
         dominant, other = (mfma, hbm) if big_ms >= sk_ms else (hbm, mfma)
         out["roofline"] = dominant
         out["roofline_secondary"] = other
