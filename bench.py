@@ -94,7 +94,7 @@ class Workload:
             core.rollout_many(states)
         mark("rollout")
         self.last_tokens = 0
-        for st in states:
+        for si, st in enumerate(states):
             core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
             toks_host = st.completion_ids.cpu().numpy()
             completions = [fake_decode(r) for r in toks_host]
@@ -105,7 +105,11 @@ class Workload:
                 rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
             _, adv, _ = group_advantages(rew, a.G)
             mark("logps")
-            core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga)
+            sync = None
+            if si == len(states) - 1 and self.opt.dp.enabled and not a.no_grad_overlap:
+                sync = self.opt.sync
+                sync.begin()                # last micro-step of the window: overlap the RCCL gradient exchange with its backward
+            core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga, grad_sync=sync)
             mark("backward")
             self.micro += 1
             self.last_tokens += int(mask.sum())
@@ -223,6 +227,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
+    ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: all-reduce the gradient arena after backward instead of during it")
     args = ap.parse_args()
 
     rank, local, world = init_from_env("cuda")

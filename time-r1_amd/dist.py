@@ -1,7 +1,13 @@
 """Data parallelism: one process per GPU, gradients of the flat arena averaged with RCCL (torch.distributed backend "nccl" IS
-RCCL on ROCm) in a few large buckets over xGMI; metrics gathered like accelerator.gather_for_metrics
-(reference src/time_r1/rl/timer1_trainer.py:741-777).  Each prompt group (G completions, rewards, group statistics) stays on
-one rank, exactly as in the reference (:703-712): the only exchange is the gradient average at the optimizer step.
+RCCL on ROCm) over xGMI; metrics gathered like accelerator.gather_for_metrics (reference src/time_r1/rl/timer1_trainer.py:741-777).
+Each prompt group (G completions, rewards, group statistics) stays on one rank, exactly as in the reference (:703-712): the only
+exchange is the gradient average at the optimizer step.
+
+MI355X-first gradient exchange (`GradSync`): the arena is laid out layer by layer, and the hand-written backward finishes layers
+from the last to the first, so during the LAST micro-step of an accumulation window each layer's gradient range is handed to RCCL
+as soon as that layer's backward kernels are enqueued - the all-reduce runs on RCCL's stream over the 7 xGMI links while the
+remaining layers are still computing.  The wire format is bf16 (half the bytes; fp32 accumulation stays local), staged through a
+bf16 twin of the arena; the 1/world average is folded into the fused AdamW kernel (grad_mult).
 """
 import os
 
@@ -17,8 +23,7 @@ class DataParallel:
         self.bucket_bytes = bucket_bytes
 
     def all_reduce_mean_(self, flat):
-        """In-place mean over ranks of a flat fp32 tensor, in buckets of `bucket_bytes` (large enough to saturate the 7 xGMI
-        links per GPU, small enough to pipeline)."""
+        """In-place mean over ranks of a flat tensor, in buckets of `bucket_bytes`."""
         if not self.enabled:
             return flat
         n = flat.numel()
@@ -43,6 +48,60 @@ class DataParallel:
     def barrier(self):
         if self.enabled:
             dist.barrier()
+
+
+class GradSync:
+    """Gradient SUM over ranks for the flat fp32 gradient arena, range by range, overlapped with backward.
+
+    usage per optimizer step:   sync.begin()  ->  [backward of the last micro-step calls sync.ready(a, b) as ranges become final]
+                                ->  sync.finish() (reduces whatever was not announced, waits, writes the sums back to fp32)
+    The caller divides by `world` (AdamWFlat passes grad_mult = 1/world to the fused kernel)."""
+
+    def __init__(self, grad_flat, dp: DataParallel, wire_dtype=torch.bfloat16, bucket_elems=1 << 28):
+        self.g, self.dp = grad_flat, dp
+        self.wire_dtype = wire_dtype
+        self.bucket = bucket_elems
+        self.stage = None
+        self.pending, self.done = [], []
+        self.active = False
+
+    def begin(self):
+        self.pending, self.done = [], []
+        self.active = self.dp.enabled
+        if self.active and self.wire_dtype != self.g.dtype and self.stage is None:
+            self.stage = torch.empty(self.g.numel(), dtype=self.wire_dtype, device=self.g.device)
+
+    def ready(self, a, b):
+        """Elements [a, b) of the gradient arena are final on this rank: start their all-reduce (asynchronous)."""
+        if not self.active or b <= a:
+            return
+        for x in range(a, b, self.bucket):
+            y = min(b, x + self.bucket)
+            if self.stage is not None:
+                buf = self.stage[x:y]
+                buf.copy_(self.g[x:y])            # fp32 -> bf16 wire format (staging copy on the compute stream)
+            else:
+                buf = self.g[x:y]
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            self.pending.append((x, y, work))
+        self.done.append((a, b))
+
+    def finish(self):
+        if not self.active:
+            return
+        n = self.g.numel()
+        covered = sorted(self.done)
+        pos = 0
+        for a, b in covered + [(n, n)]:           # reduce every range nobody announced
+            if a > pos:
+                self.ready(pos, a)
+            pos = max(pos, b)
+        for x, y, work in self.pending:
+            work.wait()
+            if self.stage is not None:
+                self.g[x:y].copy_(self.stage[x:y])
+        self.pending, self.done = [], []
+        self.active = False
 
 
 def init_from_env(device_type="cuda"):

@@ -143,14 +143,23 @@ class GRPOCore:
             st.ref_logp = self._to_gc(st, rlogp).contiguous()
 
     # ------------------------------------------------------------------------------------------------------- phase 4
-    def loss_backward(self, st, completion_mask, advantages, grad_scale=1.0):
+    def loss_backward(self, st, completion_mask, advantages, grad_scale=1.0, grad_sync=None):
         """completion_mask int32 [G, C], advantages fp32 [G] (device). Accumulates grads into the trainable arena.
+        grad_sync: a dist.GradSync in its begin() state when this is the LAST micro-step of the accumulation window - parameter ranges
+        are handed to the all-reduce as soon as their gradients are final, overlapping the exchange with the rest of the backward.
         Returns (out3 = [loss, mean kl, sum mask], row_len [G]) as device tensors."""
         eng, ops = self.eng, self.ops
+        tr = eng.params.train
+        hook = None
+        if grad_sync is not None and grad_sync.active:
+            hook = lambda i: grad_sync.ready(*tr.range_of("l%d." % i))
         dlogp, out3, row_len, _ = ops.grpo_loss(st.logp, st.ref_logp, completion_mask, advantages, self.beta, self.use_grpo, grad_scale)
         dl_pred = dlogp.reshape(-1)[st.perm].contiguous()
         dh = eng.head_bwd(st.head_ctx, dl_pred, st.layout.G)
-        dh0 = eng.llm_bwd(st.llm_ctx, dh)
+        if hook is not None and not self.cfg.text.tie_word_embeddings:
+            grad_sync.ready(*tr.range_of("norm"))          # final norm + untied lm_head gradients are complete after the head backward
+            grad_sync.ready(*tr.range_of("lm_head"))
+        dh0 = eng.llm_bwd(st.llm_ctx, dh, on_layer_done=hook)
         ids_g = st.ids_packed.clone()
         ids_g[st.vid_rows.long()] = -1
         dvid = eng.embed_bwd(dh0, ids_g, st.vid_rows)

@@ -155,8 +155,9 @@ class Engine:
             ctx_a["layers"][i] = ctx_b["layers"][i] = None
         return dict(layers=layers, masks=masks, cos=cos, sin=sin)
 
-    def llm_bwd(self, ctx, dh):
-        """dh: gradient wrt the decoder stack output [M, d]. Accumulates parameter grads; returns the gradient wrt the input embeddings."""
+    def llm_bwd(self, ctx, dh, on_layer_done=None):
+        """dh: gradient wrt the decoder stack output [M, d]. Accumulates parameter grads; returns the gradient wrt the input embeddings.
+        on_layer_done(i): called right after layer i's gradient kernels are enqueued (data-parallel overlap hook)."""
         ops, t, tr = self.ops, self.cfg.text, self.params.train
         pre, lo, hi = ctx["masks"]
         cos, sin = ctx["cos"], ctx["sin"]
@@ -187,6 +188,8 @@ class Engine:
             dxn = self._dgrad(dqkv, tr.w(p + "qkv.w"))
             dh = ops.rmsnorm_bwd(dxn, L["h"], tr.w(p + "ln1"), L["rstd1"], dres=dh2, dw=tr.g(p + "ln1"))
             ctx["layers"][i] = None  # release this layer's activations
+            if on_layer_done is not None:
+                on_layer_done(i)
         return dh
 
     def embed_bwd(self, dh0, ids_for_grad, vid_rows=None):

@@ -83,6 +83,17 @@ class Arena:
     def names(self):
         return [n for n, _ in self.specs]
 
+    def range_of(self, prefix):
+        """[start, end) element range of the (contiguous) parameters whose name starts with `prefix`, padding included."""
+        offs = [(self.offsets[n][0], n) for n, _ in self.specs if n.startswith(prefix)]
+        if not offs:
+            return 0, 0
+        start = min(o for o, _ in offs)
+        names = [n for n, _ in self.specs]
+        last = max(names.index(n) for _, n in offs)
+        end = self.offsets[names[last + 1]][0] if last + 1 < len(names) else self.numel
+        return start, end
+
     def sync_master_from_w16(self):
         if self.master is not None:
             self.master.copy_(self.w16)

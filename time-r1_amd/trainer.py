@@ -77,6 +77,7 @@ class GRPOConfig:
     fix_vit: bool = True
     stop_at_eos: bool = False               # the reference's GenerationConfig carries no eos_token_id (a6): always C tokens
     rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
+    grad_wire_dtype: str = "bf16"           # data-parallel gradient all-reduce wire format ("bf16" | "fp32")
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
     learning_rate: float = 1e-6
@@ -256,7 +257,8 @@ class TimeR1_Trainer:
         if optimizers[0] is not None:
             raise NotImplementedError("custom torch optimizers are not supported; the engine owns a fused AdamW over its flat arena")
         self.optimizer = AdamWFlat(self.params, ops, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
-                                   weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, dp=self.dp)
+                                   weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, dp=self.dp,
+                                   grad_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_dtype", "bf16") == "bf16" else torch.float32)
         self._metrics = defaultdict(list)
         self.state = TrainerState()
         self.state.is_world_process_zero = self.dp.rank == 0
@@ -310,7 +312,7 @@ class TimeR1_Trainer:
             st.completion_ids = self.ops.tensor(np.asarray(forced, dtype=np.int32), torch.int32)
         return dict(inputs=inputs, st=st, prompts=prompts, forced=forced)
 
-    def _step_finish(self, ctx):
+    def _step_finish(self, ctx, last_in_window=False):
         inputs, st, prompts = ctx["inputs"], ctx["st"], ctx["prompts"]
         G = self.num_generations
         tokens = st.completion_ids
@@ -328,7 +330,12 @@ class TimeR1_Trainer:
             rewards_per_func[:, i] = torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
         rewards, advantages, std = group_advantages(rewards_per_func, G)
         scale = 1.0 / max(1, self.args.gradient_accumulation_steps)     # HF divides the loss by GA (model_accepts_loss_kwargs=False, :421-424)
-        out3, row_len = self.core.loss_backward(st, self.ops.tensor(mask_np, torch.int32), self.ops.tensor(advantages.numpy(), torch.float32), scale)
+        sync = None
+        if last_in_window and self.dp.enabled:
+            sync = self.optimizer.sync
+            sync.begin()                      # overlap the gradient exchange with this (last) micro-step's backward
+        out3, row_len = self.core.loss_backward(st, self.ops.tensor(mask_np, torch.int32), self.ops.tensor(advantages.numpy(), torch.float32), scale,
+                                                grad_sync=sync)
         # ---- metrics (reference :739-777; ft adds metrics/<fn> and clip ratios :789-842)
         dev = self.ops.device
         gather = self.dp.gather
@@ -359,13 +366,15 @@ class TimeR1_Trainer:
     def accumulation_window(self, batches):
         """All micro-steps of one optimizer step. With rollout_batching the G x len(batches) completions are decoded together
         (weights do not change inside the window, so this equals the reference's sequential micro-steps). Returns the losses."""
-        if len(batches) == 1 or not getattr(self.args, "rollout_batching", True):
-            return [self.compute_loss(self.params, b) for b in batches]
         ctxs = [self._step_prepare(b) for b in batches]
         todo = [c["st"] for c in ctxs if c["forced"] is None]
         if todo:
-            self.core.rollout_many(todo)
-        return [self._step_finish(c) for c in ctxs]
+            if getattr(self.args, "rollout_batching", True) and len(todo) > 1:
+                self.core.rollout_many(todo)
+            else:
+                for st in todo:
+                    self.core.rollout(st)
+        return [self._step_finish(c, last_in_window=(i == len(ctxs) - 1)) for i, c in enumerate(ctxs)]
 
     # ------------------------------------------------------------------------------------------------------ training loop
     def get_train_dataloader(self):
