@@ -549,6 +549,10 @@ class TimeR1_Trainer_ft(TimeR1_Trainer):
         if example.get("video_inputs") is None:
             return super()._video_inputs(example)
         vids = example["video_inputs"]
+        while isinstance(vids, (list, tuple)) and vids and isinstance(vids[0], (list, tuple)):
+            vids = vids[0]          # the reference's dataset wraps the loaded list once more (finetune.py:598-611)
         kw = example.get("video_kwargs") or {"fps": [VP.FPS]}
+        if isinstance(kw, (list, tuple)):
+            kw = kw[0]
         vids = [torch.as_tensor(v).float() for v in vids]
         return vids, kw["fps"]
