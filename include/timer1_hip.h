@@ -96,6 +96,12 @@ int tr1_decode_qkv_post(const void* qkv, int64_t ld, const void* cosb, const voi
 /* KV-cache append: dst[slots[t], :] = src[t, :] */
 int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const void* slots, int64_t T, int64_t cols, void* stream);
 
+/* ---- video preprocessing (SURVEY 8f "next" row 1) ------------------------------------------------------------------------ */
+/* ref: torchvision resize(BICUBIC, antialias) at src/utils/vision_process.py:467-472 + Qwen2VLVideoProcessor rescale/normalize/patchify
+ * (transformers video_processing_qwen2_vl.py:236-274).  frames: uint8 [T_in,3,H,W] on the device; out: bf16 [N_v, ld_out] patch rows (caller
+ * zero-fills the K padding); ymin/wy, xmin/wx: per-output first tap + normalised weights [Ho,taps_y], [Wo,taps_x] (vision_process.aa_filter). */
+int tr1_video_preprocess(const void* frames_u8, void* out_bf16, int64_t ld_out, const void* ymin, const void* wy, int64_t taps_y, const void* xmin, const void* wx, int64_t taps_x, int64_t T_in, int64_t T_out, int64_t H, int64_t W, int64_t Ho, int64_t Wo, float mean0, float mean1, float mean2, float std0, float std1, float std2, int64_t patch, int64_t temporal_patch, int64_t merge, void* stream);
+
 /* ---- vocabulary side -------------------------------------------------------------------------------------------------- */
 /* ref: src/time_r1/rl/timer1_trainer.py:458-481 (_get_per_token_logps: log_softmax, gather, entropy) */
 int tr1_logp_entropy_fwd(const void* logits, int64_t ld, const void* targets, void* logp, void* entropy, void* lse, int64_t R, int64_t V, void* stream);

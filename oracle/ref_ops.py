@@ -303,6 +303,15 @@ class RefOps:
             return self._a(dq), self._a(dk), dv_out
         return self._a(dq), self._a(dk), self._a(dv)
 
+    # ---- video preprocessing (ref: vision_process.py:467-472 + HF video processor patchify)
+    def video_preprocess(self, frames_u8, out_hw, k_pad, patch=14, temporal=2, merge=2, mean=None, std=None):
+        from time_r1_amd import vision_process as VP
+        x = VP.resize_frames(frames_u8, out_hw)
+        pv, grid = VP.patchify(x, patch, temporal, merge)
+        out = torch.zeros(pv.shape[0], k_pad, dtype=self.act_dtype)
+        out[:, : pv.shape[1]] = pv.to(self.act_dtype)
+        return out, grid
+
     # ---- vocabulary side (ref: timer1_trainer.py:458-481, :635-639, :713-737)
     def logp_entropy_fwd(self, logits, targets):
         lp = torch.log_softmax(logits.float(), -1)

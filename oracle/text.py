@@ -30,5 +30,9 @@ class FakeProcessor:
         ids = torch.tensor([self.head + [c.vision_start_token_id] + [c.video_token_id] * n_tok + [c.vision_end_token_id] + self.tail])
         return {"input_ids": ids, "attention_mask": torch.ones_like(ids), "pixel_values_videos": pv, "video_grid_thw": torch.tensor([list(grid)])}
 
+    def prompt_ids(self, text, n_video_tokens):
+        c = self.cfg
+        return self.head + [c.vision_start_token_id] + [c.video_token_id] * n_video_tokens + [c.vision_end_token_id] + self.tail
+
     def batch_decode(self, ids, skip_special_tokens=True):
         return [fake_decode(r.tolist(), skip=(self.eos_token_id, self.pad_token_id) if skip_special_tokens else ()) for r in ids]

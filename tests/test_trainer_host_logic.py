@@ -157,3 +157,17 @@ def test_train_loop_callbacks_checkpoint_resume(tmp_path):
     from safetensors.torch import load_file
     sd = load_file(str(tmp_path / "final" / "model.safetensors"))
     assert "model.language_model.layers.0.self_attn.q_proj.weight" in sd and "model.visual.merger.mlp.0.weight" in sd
+
+
+def test_gpu_video_preprocess_path_equals_processor_path():
+    """uint8 frames through ops.video_preprocess (fused kernel on the GPU, its oracle here) == frames through the processor's pixel path."""
+    fx = load_case("grpo_beta")
+    losses = []
+    frames = torch.randint(0, 256, (4, 3, 120, 160), generator=torch.Generator().manual_seed(5), dtype=torch.uint8)
+    for gpu in (False, True):
+        cfg, tr = make_trainer(fx, gpu_video_preprocess=gpu)
+        row = dict(fx["row"])
+        row["video_frames"] = frames
+        row["_forced_completion_ids"] = fx["completion_ids"].numpy()
+        losses.append(float(tr.compute_loss(tr.model, [row])))
+    assert abs(losses[0] - losses[1]) < 1e-6

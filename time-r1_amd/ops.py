@@ -299,6 +299,29 @@ class HipOps:
                     _p(hi), _p(qmeta), _p(ws), nws, T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
         return dq, dk, dv
 
+    # ---- video preprocessing --------------------------------------------------------------------------------------
+    def video_preprocess(self, frames_u8, out_hw, k_pad, patch=14, temporal=2, merge=2, mean=(0.48145466, 0.4578275, 0.40821073),
+                         std=(0.26862954, 0.26130258, 0.27577711)):
+        """uint8 [T,3,H,W] (device) -> (bf16 [N_v, k_pad] normalised patches ready for the patch-embed GEMM, (t, h, w) grid)."""
+        from .vision_process import aa_filter
+        assert frames_u8.dtype == torch.uint8 and frames_u8.device.type == "cuda" and frames_u8.is_contiguous()
+        T, C, H, W = frames_u8.shape
+        Ho, Wo = out_hw
+        T_out = (T + temporal - 1) // temporal * temporal
+        key = ("aa", H, W, Ho, Wo)
+        tabs = self._ws.get(key)
+        if tabs is None:
+            ymin, wy = aa_filter(H, Ho)
+            xmin, wx = aa_filter(W, Wo)
+            tabs = tuple(torch.as_tensor(a).to(self.device).contiguous() for a in (ymin, wy, xmin, wx))
+            self._ws[key] = tabs
+        ymin, wy, xmin, wx = tabs
+        gt, gh, gw = T_out // temporal, Ho // patch, Wo // patch
+        out = self.zeros(gt * gh * gw, k_pad)
+        self.L.call("tr1_video_preprocess", _p(frames_u8), _p(out), _ld(out), _p(ymin), _p(wy), wy.shape[1], _p(xmin), _p(wx), wx.shape[1], T, T_out,
+                    H, W, Ho, Wo, *[float(x) for x in mean], *[float(x) for x in std], patch, temporal, merge, self._s())
+        return out, (gt, gh, gw)
+
     # ---- vocabulary side ------------------------------------------------------------------------------------------
     def logp_entropy_fwd(self, logits, targets):
         self._chk(logits)

@@ -78,6 +78,7 @@ class GRPOConfig:
     stop_at_eos: bool = False               # the reference's GenerationConfig carries no eos_token_id (a6): always C tokens
     rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
     grad_wire_dtype: str = "bf16"           # data-parallel gradient all-reduce wire format ("bf16" | "fp32")
+    gpu_video_preprocess: bool = False      # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
     learning_rate: float = 1e-6
@@ -286,6 +287,16 @@ class TimeR1_Trainer:
     def _prepare_inputs(self, inputs):
         return inputs
 
+    def _prompt_ids(self, text, n_video_tokens):
+        """Token ids of the chat-templated prompt with the single <|video_pad|> placeholder expanded to n_video_tokens copies
+        (what Qwen2VLProcessor.__call__ does before tokenising, processing_qwen2_vl.py)."""
+        pc = self.processing_class
+        if hasattr(pc, "prompt_ids"):
+            return pc.prompt_ids(text, n_video_tokens)
+        tok = getattr(pc, "tokenizer", pc)
+        pad = "<|video_pad|>"
+        return tok(text.replace(pad, pad * n_video_tokens, 1), add_special_tokens=False)["input_ids"]
+
     # ------------------------------------------------------------------------------------------------------ the micro-step
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
         if return_outputs:
@@ -298,13 +309,26 @@ class TimeR1_Trainer:
     def _step_prepare(self, inputs):
         """Host preprocessing + vision tower for one micro-step (one prompt: reference facts :524, :548-551)."""
         example = inputs[0]
-        video_inputs, fps_inputs = self._video_inputs(example)
         prompts = [self.make_conversation_video(ex) for ex in inputs]
         prompts_text = [self.processing_class.apply_chat_template(p, tokenize=False, add_generation_prompt=True) for p in prompts]
-        prompt_inputs = self.processing_class(text=[prompts_text[0]], images=None, videos=[video_inputs[0]], fps=[fps_inputs[0]], padding=True,
-                                              return_tensors="pt", padding_side="left", add_special_tokens=False)
-        ids = np.asarray(prompt_inputs["input_ids"]).reshape(-1)
-        st = self.core.prepare(ids, prompt_inputs["pixel_values_videos"], np.asarray(prompt_inputs["video_grid_thw"]))
+        frames = example.get("video_frames")
+        if getattr(self.args, "gpu_video_preprocess", False) and torch.is_tensor(frames) and frames.dtype == torch.uint8:
+            # pre-decoded uint8 frames: size plan on the host (integers), pixels on the GPU (fused resize + normalise + patchify kernel)
+            ele = {"total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}
+            T, _, H, W = frames.shape
+            th, tw = VP.video_target_size(ele, T, H, W)
+            v = self.cfg.vision
+            pixels, grid = self.ops.video_preprocess(frames.to(self.ops.device).contiguous(), (th, tw), v.patch_dim_padded, v.patch_size,
+                                                     v.temporal_patch_size, v.spatial_merge_size)
+            n_tok = grid[0] * grid[1] * grid[2] // v.merge_unit
+            ids = np.asarray(self._prompt_ids(prompts_text[0], n_tok)).reshape(-1)
+            st = self.core.prepare(ids, pixels, np.asarray([grid]))
+        else:
+            video_inputs, fps_inputs = self._video_inputs(example)
+            prompt_inputs = self.processing_class(text=[prompts_text[0]], images=None, videos=[video_inputs[0]], fps=[fps_inputs[0]], padding=True,
+                                                  return_tensors="pt", padding_side="left", add_special_tokens=False)
+            ids = np.asarray(prompt_inputs["input_ids"]).reshape(-1)
+            st = self.core.prepare(ids, prompt_inputs["pixel_values_videos"], np.asarray(prompt_inputs["video_grid_thw"]))
         forced = example.get("_forced_completion_ids")       # test hook: teacher-forced completions instead of sampling
         if forced is not None:
             from .positions import PackedLayout

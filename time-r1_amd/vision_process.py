@@ -178,3 +178,36 @@ def patchify(frames, patch=14, temporal=2, merge=2, mean=CLIP_MEAN, std=CLIP_STD
     x = x.view(gt, temporal, C, gh // merge, merge, patch, gw // merge, merge, patch)
     x = x.permute(0, 3, 6, 4, 7, 2, 1, 5, 8).reshape(gt * gh * gw, C * temporal * patch * patch)
     return x.contiguous(), (gt, gh, gw)
+
+
+def aa_filter(in_size, out_size):
+    """Bicubic (a = -0.5) antialiased resampling taps for one axis, evaluated in float32 in the same operation order as ATen's
+    _compute_indices_weights_aa (so that the rounded uint8 levels agree with torchvision's resize on all but a handful of pixels):
+    -> (first input index per output [out], weights [out, taps] fp32 normalised to 1, zero-padded)."""
+    f32 = np.float32
+    scale = f32(in_size) / f32(out_size)
+    support = f32(2.0) * scale if scale >= 1.0 else f32(2.0)
+    invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
+    taps = int(math.ceil(float(support))) * 2 + 1
+    a = f32(-0.5)
+
+    def cubic(x):
+        x = abs(x)
+        if x < 1.0:
+            return ((a + f32(2.0)) * x - (a + f32(3.0))) * x * x + f32(1.0)
+        if x < 2.0:
+            return (((x - f32(5.0)) * x + f32(8.0)) * x - f32(4.0)) * a
+        return f32(0.0)
+    xmin = np.zeros(out_size, dtype=np.int32)
+    w = np.zeros((out_size, taps), dtype=np.float32)
+    for i in range(out_size):
+        center = scale * (f32(i) + f32(0.5))
+        lo = max(0, int(center - support + f32(0.5)))
+        size = min(int(center + support + f32(0.5)), in_size) - lo
+        ws = np.array([cubic((f32(j + lo) - center + f32(0.5)) * invscale) for j in range(size)], dtype=np.float32)
+        tot = f32(0.0)
+        for v in ws:
+            tot = tot + v
+        xmin[i] = lo
+        w[i, :size] = ws / tot if tot != 0 else ws
+    return xmin, w
