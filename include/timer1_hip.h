@@ -32,6 +32,11 @@ int tr1_device_info(int device, char* arch, int64_t arch_len, int64_t* n_cu, int
  * K % 64 == 0 (pad), N % 8 == 0.  out_f32: C is fp32; accumulate (fp32 only): C += result (weight-gradient accumulation).
  * M <= 16 dispatches the HBM-streaming skinny kernel used by rollout decode. */
 int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream);
+/* Decode-regime GEMM with cross-block split-K: parts_f32[ks, M, N] = A[M, k-range ks] * B[N, k-range ks]^T (fp32, no bias/residual).
+ * For the narrow projections of a decode step (o_proj, down_proj, qkv: N/16 column groups cannot fill 256 CUs) - the slabs are summed by the
+ * consumer kernel (tr1_rmsnorm_fwd_parts / tr1_decode_qkv_post with n_parts), so the reduction costs no extra pass.  Same call sites as
+ * tr1_gemm_nt_bf16 inside generate (timer1_trainer.py:568-573). */
+int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int ksplit, void* stream);
 /* out[c, r] = in[r, c]; columns [R, ld_out) of out are zero-filled (feeds the NT GEMM for dgrad / wgrad). */
 int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* stream);
 

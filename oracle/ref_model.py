@@ -21,9 +21,66 @@ def _rot_half(x):
     return torch.cat([-x[..., h:], x[..., :h]], -1)
 
 
+def vision_tower_25(W, cfg, pixels, grid_thw):
+    """Qwen2.5-VL tower restated WITHOUT the window permutation: attention is permutation-equivariant, so a block's output in
+    natural patch order equals HF's (modeling_qwen2_5_vl.py:408-470) after its reorder -> blocks -> merger -> argsort round trip.
+    Window membership follows vision_utils.py:130-188: merged token (t, i, j) of a video lies in window (t, i // mw, j // mw),
+    mw = window_size // merge // patch.  RMSNorm :64-79, biased SwiGLU MLP :85-96 (only the first mlp_dim rows of the padded
+    gate/up halves are read), merger with RMSNorm :135-149."""
+    v = cfg.vision
+    E, H, hd, m = v.embed_dim, v.num_heads, v.head_dim, v.spatial_merge_size
+    i0, ip = v.mlp_dim, v.mlp_dim_padded
+    x = pixels @ W["patch.w"][:, : v.patch_dim].t()
+    mw = v.window_size // m // v.patch_size
+    ids, frame, win = [], [], []
+    nf = nwin = 0
+    for t, h, w in grid_thw:
+        hh, ww = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        hh = hh.reshape(h // m, m, w // m, m).permute(0, 2, 1, 3).reshape(-1)
+        ww = ww.reshape(h // m, m, w // m, m).permute(0, 2, 1, 3).reshape(-1)
+        ids.append(torch.stack([hh, ww], -1).repeat(t, 1))
+        wid = (hh // m // mw) * 10000 + (ww // m // mw)          # window of each patch inside one temporal patch
+        for ti in range(t):
+            frame.append(torch.full((h * w,), nf + ti))
+            win.append(wid + (nwin + ti) * 100000000)
+        nf += t
+        nwin += t
+    ids, frame, win = torch.cat(ids, 0), torch.cat(frame), torch.cat(win)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float32) / (hd // 2)))
+    freqs = (ids[:, :, None].float() * inv_freq[None, None, :]).flatten(1)
+    emb = torch.cat([freqs, freqs], -1)
+    cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]
+    mask_full = frame[:, None] == frame[None, :]
+    mask_win = win[:, None] == win[None, :]
+    N = x.shape[0]
+
+    def rms(h, w):
+        return w * (h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + v.ln_eps))
+    for i in range(v.depth):
+        p = "v%d." % i
+        mask = mask_full if i in v.fullatt_block_indexes else mask_win
+        qkv = (rms(x, W[p + "n1.w"]) @ W[p + "qkv.w"].t() + W[p + "qkv.b"]).reshape(N, 3, H, hd)
+        q, k, val = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+        q = q * cos + _rot_half(q) * sin
+        k = k * cos + _rot_half(k) * sin
+        sc = torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5
+        sc = sc.masked_fill(~mask[None], float("-inf"))
+        o = torch.einsum("hqk,khd->qhd", sc.softmax(-1), val).reshape(N, E)
+        x = x + o @ W[p + "proj.w"].t() + W[p + "proj.b"]
+        y = rms(x, W[p + "n2.w"])
+        gate = y @ W[p + "gu.w"][:i0].t() + W[p + "gu.b"][:i0]
+        up = y @ W[p + "gu.w"][ip:ip + i0].t() + W[p + "gu.b"][ip:ip + i0]
+        x = x + (F.silu(gate) * up) @ W[p + "down.w"][:, :i0].t() + W[p + "down.b"]
+    y = rms(x, W["merger.ln.w"]).reshape(N // v.merge_unit, E * v.merge_unit)
+    y = F.gelu(y @ W["merger.fc1.w"].t() + W["merger.fc1.b"])
+    return y @ W["merger.fc2.w"].t() + W["merger.fc2.b"]
+
+
 def vision_tower(W, cfg, pixels, grid_thw):
     """W: dict name -> tensor (params.py names). pixels [N_v, patch_dim]. Returns merged video embeddings [N_v/4, out_hidden]."""
     v = cfg.vision
+    if v.variant == "qwen2_5_vl":
+        return vision_tower_25(W, cfg, pixels, grid_thw)
     E, H, hd = v.embed_dim, v.num_heads, v.head_dim
     x = pixels @ W["patch.w"][:, : v.patch_dim].t()
     # 2-D rotary ids in merge-block order (vision_utils.py:81-127)
@@ -61,7 +118,7 @@ def vision_tower(W, cfg, pixels, grid_thw):
     return y @ W["merger.fc2.w"].t() + W["merger.fc2.b"]
 
 
-def rope_index_ref(ids, grid_thw, video_token_id, merge, mode):
+def rope_index_ref(ids, grid_thw, video_token_id, merge, mode, interval=1):
     """Per-sequence 3-D positions (one row). Same rule as positions.rope_index but written independently (loop form)."""
     pos = [[], [], []]
     cur, i, gi, L = 0, 0, 0, len(ids)
@@ -79,8 +136,8 @@ def rope_index_ref(ids, grid_thw, video_token_id, merge, mode):
             for tt in range(t):
                 for hh in range(gh):
                     for ww in range(gw):
-                        pos[0].append(cur + tt); pos[1].append(cur + hh); pos[2].append(cur + ww)
-                        mx = max(mx, cur + tt, cur + hh, cur + ww)
+                        pos[0].append(cur + tt * interval); pos[1].append(cur + hh); pos[2].append(cur + ww)
+                        mx = max(mx, cur + tt * interval, cur + hh, cur + ww)
             i += t * gh * gw
             cur = cur + max(h, w) // merge if mode == "hf5" else mx + 1
     return torch.tensor(pos)
@@ -94,7 +151,9 @@ def llm_logits(W, cfg, input_ids, vid_embeds, grid_thw, rope_mode="hf5"):
     vid_mask = input_ids == cfg.video_token_id
     x = x.clone()
     x[vid_mask] = vid_embeds.repeat(B, 1).to(x.dtype)
-    pos = torch.stack([rope_index_ref(input_ids[b].tolist(), grid_thw, cfg.video_token_id, cfg.vision.spatial_merge_size, rope_mode) for b in range(B)], 1)  # [3,B,L]
+    interval = int(cfg.tokens_per_second) if cfg.vision.variant == "qwen2_5_vl" else 1     # modeling_qwen2_5_vl.py:1043, 1 s per grid step
+    pos = torch.stack([rope_index_ref(input_ids[b].tolist(), grid_thw, cfg.video_token_id, cfg.vision.spatial_merge_size, rope_mode, interval)
+                       for b in range(B)], 1)  # [3,B,L]
     inv_freq = 1.0 / (t.rope_theta ** (torch.arange(0, t.head_dim, 2, dtype=torch.float32) / t.head_dim))
     freqs = pos[..., None].float() * inv_freq            # [3, B, L, hd/2]
     sec = list(t.mrope_section)

@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 from _ref_harness import load_ref_main, load_ref_trainers  # noqa: E402
 
 import time_r1_amd  # noqa: E402,F401
-from time_r1_amd.config import tiny_test  # noqa: E402
+from time_r1_amd.config import tiny_test, tiny_test_25  # noqa: E402
 from time_r1_amd.params import ModelParams  # noqa: E402
 from time_r1_amd import vision_process as VP  # noqa: E402
 from oracle.ref_ops import RefOps  # noqa: E402
@@ -33,6 +33,21 @@ from oracle.text import fake_decode  # noqa: E402
 def hf_tiny(cfg):
     from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
     t, v = cfg.text, cfg.vision
+    if v.variant == "qwen2_5_vl":
+        from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+        hc = Qwen2_5_VLConfig(
+            text_config=dict(vocab_size=t.vocab_size, hidden_size=t.hidden, intermediate_size=t.intermediate, num_hidden_layers=t.n_layers,
+                             num_attention_heads=t.n_heads, num_key_value_heads=t.n_kv_heads, max_position_embeddings=4096,
+                             rope_parameters={"rope_type": "default", "rope_theta": t.rope_theta, "mrope_section": list(t.mrope_section)},
+                             rms_norm_eps=t.rms_eps, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id, bos_token_id=None,
+                             tie_word_embeddings=False),
+            vision_config=dict(depth=v.depth, hidden_size=v.embed_dim, hidden_act="silu", intermediate_size=v.mlp_dim, num_heads=v.num_heads,
+                               in_channels=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2, tokens_per_second=int(cfg.tokens_per_second),
+                               window_size=v.window_size, out_hidden_size=v.out_hidden, fullatt_block_indexes=list(v.fullatt_block_indexes)),
+            image_token_id=cfg.image_token_id, video_token_id=cfg.video_token_id, vision_start_token_id=cfg.vision_start_token_id,
+            vision_end_token_id=cfg.vision_end_token_id)
+        hc._attn_implementation = "eager"
+        return Qwen2_5_VLForConditionalGeneration(hc).float()
     hc = Qwen2VLConfig(
         text_config=dict(vocab_size=t.vocab_size, hidden_size=t.hidden, intermediate_size=t.intermediate, num_hidden_layers=t.n_layers,
                          num_attention_heads=t.n_heads, num_key_value_heads=t.n_kv_heads, max_position_embeddings=4096,
@@ -98,11 +113,11 @@ class FakeProc:
         return [fake_decode(r.tolist(), skip=(self.eos_token_id, self.pad_token_id) if skip_special_tokens else ()) for r in ids]
 
 
-def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8):
+def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8, model="qwen2_vl", frames_shape=(4, 3, 56, 84)):
     ref_main = load_ref_main()
     t1, _ = load_ref_trainers()
     from transformers import GenerationConfig
-    cfg = tiny_test()
+    cfg = tiny_test_25() if model == "qwen2_5_vl" else tiny_test()
     ops = RefOps()
     params = ModelParams(cfg, ops, seed=0)
     hf = hf_tiny(cfg)
@@ -114,7 +129,7 @@ def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8):
     sd_ref = {k: (v.float() + 0.02 * torch.randn(v.shape, generator=g) * (0 if "visual.blocks" in k or "patch_embed" in k else 1)) for k, v in sd_ref.items()}
     hf_ref.load_state_dict(sd_ref, strict=True)
 
-    frames = torch.randint(0, 256, (4, 3, 56, 84), generator=torch.Generator().manual_seed(7), dtype=torch.uint8).float()
+    frames = torch.randint(0, 256, frames_shape, generator=torch.Generator().manual_seed(7), dtype=torch.uint8).float()
     row = {"problem": "person sits down", "video_path": "x.mp4", "video_start": None, "video_end": None, "solution": (2.0, 12.0), "durations": 30.0}
     t1.process_vision_info_v3 = lambda conv, return_video_kwargs=True: (None, [frames], {"fps": [2.0]})   # test-time patch of a module attribute
     tr = object.__new__(t1.TimeR1_Trainer)
@@ -151,7 +166,7 @@ def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8):
     comp = ids[:, P:]
     fx = {
         "case": name, "use_grpo": use_grpo, "beta": beta, "G": G, "C": C, "seed": seed, "param_seed": 0,
-        "frames_seed": 7, "row": {k: v for k, v in row.items()}, "prompt_ids": ids[0, :P].tolist(), "completion_ids": comp.clone(),
+        "frames_seed": 7, "frames_shape": tuple(frames_shape), "model": model, "row": {k: v for k, v in row.items()}, "prompt_ids": ids[0, :P].tolist(), "completion_ids": comp.clone(),
         "completions": proc.batch_decode(comp), "logp": cap["calls"][0]["logp"][:, P - 1:], "entropy": cap["calls"][0]["ent"][:, P - 1:],
         "ref_logp": cap["calls"][1]["logp"][:, P - 1:] if beta != 0 else None, "loss": loss.detach().clone(),
         "metrics": {k: list(v) for k, v in tr._metrics.items()},
@@ -167,7 +182,13 @@ def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8):
 
 
 if __name__ == "__main__":
-    run_case("grpo_beta", True, 0.04, None, 123)
-    run_case("clip_beta", False, 0.04, {0: 2, 2: 5}, 124)
-    run_case("grpo_nobeta_ragged", True, 0.0, {1: 0, 3: 6}, 125)
-    run_case("clip_nobeta", False, 0.0, None, 126)
+    which = sys.argv[1:] or ["qwen2_vl", "qwen2_5_vl"]
+    if "qwen2_vl" in which:
+        run_case("grpo_beta", True, 0.04, None, 123)
+        run_case("clip_beta", False, 0.04, {0: 2, 2: 5}, 124)
+        run_case("grpo_nobeta_ragged", True, 0.0, {1: 0, 3: 6}, 125)
+        run_case("clip_nobeta", False, 0.0, None, 126)
+    if "qwen2_5_vl" in which:
+        # Qwen2.5-VL (the family the reference hard-codes): windowed ViT with ragged windows (84x112 -> 3x4 merged tokens, 2x2 windows)
+        run_case("q25_grpo_beta", True, 0.04, None, 223, model="qwen2_5_vl", frames_shape=(4, 3, 84, 112))
+        run_case("q25_clip_beta_ragged", False, 0.04, {0: 3, 2: 5}, 224, model="qwen2_5_vl", frames_shape=(6, 3, 56, 140))

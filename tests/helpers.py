@@ -4,13 +4,22 @@ import os
 import torch
 
 import time_r1_amd  # noqa: F401
-from time_r1_amd.config import tiny_test
+from time_r1_amd.config import tiny_test, tiny_test_25
 from time_r1_amd.params import ModelParams
 from time_r1_amd import vision_process as VP
 from time_r1_amd import rewards as R
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["grpo_beta", "clip_beta", "grpo_nobeta_ragged", "clip_nobeta"]
+CASES = ["grpo_beta", "clip_beta", "grpo_nobeta_ragged", "clip_nobeta", "q25_grpo_beta", "q25_clip_beta_ragged"]   # q25_*: Qwen2.5-VL tower
+
+
+def cfg_for(fx):
+    return tiny_test_25() if fx.get("model") == "qwen2_5_vl" else tiny_test()
+
+
+def frames_for(fx):
+    shape = tuple(fx.get("frames_shape", (4, 3, 56, 84)))
+    return torch.randint(0, 256, shape, generator=torch.Generator().manual_seed(fx["frames_seed"]), dtype=torch.uint8).float()
 
 
 def load_case(name):
@@ -19,7 +28,7 @@ def load_case(name):
 
 def golden_params(ops, fx):
     """(policy params, reference-policy params) exactly as tests/golden/gen_grpo_golden.py built them."""
-    cfg = tiny_test()
+    cfg = cfg_for(fx)
     pol = ModelParams(cfg, ops, seed=fx["param_seed"])
     from oracle.ref_ops import RefOps
     base = ModelParams(cfg, RefOps(), seed=fx["param_seed"]).export_hf_state_dict()
@@ -31,8 +40,7 @@ def golden_params(ops, fx):
 
 
 def golden_inputs(fx):
-    frames = torch.randint(0, 256, (4, 3, 56, 84), generator=torch.Generator().manual_seed(fx["frames_seed"]), dtype=torch.uint8).float()
-    pv, grid = VP.patchify(frames)
+    pv, grid = VP.patchify(frames_for(fx))
     return pv, [grid]
 
 

@@ -48,3 +48,31 @@ def test_rollout_logits_match_training_forward(hip_ops):
         assert torch.allclose(hl[rows], rec[s], atol=0.03, rtol=0.03), "decode step %d" % s
     toks = st.completion_ids.cpu()
     assert toks.min() >= 0 and toks.max() < cfg.text.vocab_size
+
+
+@pytest.mark.parametrize("grid", [[(2, 8, 12)], [(3, 6, 10), (1, 12, 8)]])
+def test_qwen25_vision_tower_matches_oracle(hip_ops, grid):
+    """Qwen2.5-VL tower on the HIP path (window permutation + segment masks, RMSNorm, padded biased SwiGLU, merger un-permute) vs the
+    oracle's natural-order masked formulation; the oracle itself is pinned to transformers in tests/test_oracle_vs_golden.py."""
+    import time_r1_amd  # noqa: F401
+    from time_r1_amd.config import tiny_test_25, VisionConfig
+    from time_r1_amd.params import ModelParams
+    from time_r1_amd.model import Engine
+    from oracle import ref_model as RM
+    cfg = tiny_test_25()
+    cfg.vision = VisionConfig(depth=4, embed_dim=128, num_heads=2, mlp_dim=300, out_hidden=128, variant="qwen2_5_vl", window_size=112,
+                              fullatt_block_indexes=(1, 3))
+    ops = hip_ops
+    params = ModelParams(cfg, ops, seed=5)
+    eng = Engine(cfg, ops, params)
+    v = cfg.vision
+    n = sum(t * h * w for t, h, w in grid)
+    pix = torch.randn(n, v.patch_dim, generator=torch.Generator().manual_seed(3))
+    pp = ops.zeros(n, v.patch_dim_padded)
+    pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)
+    feats, perm = eng.vit_features(pp, grid)
+    out, _ = eng.merger_fwd(params.train, feats, save=False, perm=perm)
+    W = RM.weights_from_params(params)
+    want = RM.vision_tower(W, cfg, pp[:, : v.patch_dim].float().cpu(), grid)
+    err = (out.float().cpu() - want).abs().max().item()
+    assert err < 0.03 * max(1.0, want.abs().max().item()), err

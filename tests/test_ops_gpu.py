@@ -39,7 +39,9 @@ def both(hip_ops, ref_ops, fn, *tensors, **kw):
 
 # ------------------------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(1, 128, 256), (8, 512, 3584), (16, 72, 320), (130, 200, 64), (257, 384, 192), (300, 1152, 512),
-                                   (128, 128, 64), (513, 136, 1216)])
+                                   (128, 128, 64), (513, 136, 1216),
+                                   # decode regime with several 16-row groups (G = 16 / prompts batched over the accumulation window)
+                                   (17, 72, 320), (24, 512, 3584), (32, 4096, 3584), (33, 200, 8192), (48, 16400, 8192), (64, 1152, 512), (32, 100096, 256)])
 def test_gemm_nt(hip_ops, ref_ops, M, N, K):
     a, b, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
     atol = 0.02 * math.sqrt(K) * 0.1 + 0.02

@@ -43,13 +43,14 @@ def test_oracle_reproduces_reference_step(case):
         assert torch.allclose(W["embed"].grad[tok], g, atol=1e-6 + 1e-5 * g.abs().max().item(), rtol=1e-4), tok
 
 
-def test_oracle_model_matches_transformers_logits():
-    """Independent of the reference: oracle forward vs transformers' Qwen2VLForConditionalGeneration on the same weights."""
+@pytest.mark.parametrize("case", ["grpo_beta", "q25_grpo_beta", "q25_clip_beta_ragged"])
+def test_oracle_model_matches_transformers_logits(case):
+    """Independent of the reference: oracle forward vs transformers' Qwen2VL / Qwen2_5_VL ForConditionalGeneration on the same weights."""
     pytest.importorskip("transformers")
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from gen_grpo_golden import hf_tiny
-    fx = load_case("grpo_beta")
+    fx = load_case(case)
     cfg, pol, _ = golden_params(RefOps(), fx)
     hf = hf_tiny(cfg).eval()
     hf.load_state_dict({k: v.float() for k, v in pol.export_hf_state_dict().items()}, strict=True)

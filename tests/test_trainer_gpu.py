@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad  # noqa: E402
+from helpers import frames_for, CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad  # noqa: E402
 
 
 def _make(fx, ops):
@@ -28,7 +28,7 @@ def _make(fx, ops):
 def test_hip_trainer_vs_reference_golden(hip_ops, case):
     fx = load_case(case)
     cfg, tr = _make(fx, hip_ops)
-    frames = torch.randint(0, 256, (4, 3, 56, 84), generator=torch.Generator().manual_seed(fx["frames_seed"]), dtype=torch.uint8).float()
+    frames = frames_for(fx)
     tr._video_inputs = lambda ex: ([frames], [2.0])
     row = dict(fx["row"])
     row["_forced_completion_ids"] = fx["completion_ids"].numpy()

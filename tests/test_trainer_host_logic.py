@@ -8,17 +8,13 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad
+from helpers import frames_for, CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad
 from oracle.ref_ops import RefOps
 from oracle.text import FakeProcessor
 import time_r1_amd  # noqa: F401
 from time_r1_amd.trainer import TimeR1_Trainer, TimeR1_Trainer_ft, GRPOConfig
 from time_r1_amd import rewards as R
 from time_r1_amd.config import tiny_test
-
-
-def frames_for(fx):
-    return torch.randint(0, 256, (4, 3, 56, 84), generator=torch.Generator().manual_seed(fx["frames_seed"]), dtype=torch.uint8).float()
 
 
 def make_trainer(fx, cls=TimeR1_Trainer, ga=1, **over):
@@ -157,6 +153,26 @@ def test_train_loop_callbacks_checkpoint_resume(tmp_path):
     from safetensors.torch import load_file
     sd = load_file(str(tmp_path / "final" / "model.safetensors"))
     assert "model.language_model.layers.0.self_attn.q_proj.weight" in sd and "model.visual.merger.mlp.0.weight" in sd
+
+
+@pytest.mark.parametrize("case", ["grpo_beta", "q25_grpo_beta"])
+def test_saved_directory_loads_back_and_into_transformers(case, tmp_path):
+    """save_model writes an HF-layout directory: load_model_dir restores config + weights exactly, and transformers builds the same
+    architecture from config.json and accepts every tensor (strict) - the hand-off the reference's eval path relies on."""
+    from time_r1_amd.trainer import load_model_dir
+    fx = load_case(case)
+    cfg, tr = make_trainer(fx)
+    d = str(tmp_path / "m")
+    tr.save_model(d)
+    cfg2, p2 = load_model_dir(d, RefOps())
+    assert cfg2.vision == cfg.vision and cfg2.text == cfg.text and cfg2.tokens_per_second == cfg.tokens_per_second
+    assert torch.equal(p2.train.w16, tr.params.train.w16) and torch.equal(p2.frozen.w16, tr.params.frozen.w16)
+    transformers = pytest.importorskip("transformers")
+    hc = transformers.AutoConfig.from_pretrained(d)
+    from safetensors.torch import load_file
+    m = transformers.AutoModelForImageTextToText.from_config(hc)
+    missing = m.load_state_dict({k: v.float() for k, v in load_file(os.path.join(d, "model.safetensors")).items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
 
 
 def test_gpu_video_preprocess_path_equals_processor_path():

@@ -38,6 +38,10 @@ class VisionConfig:
     def merge_unit(self):
         return self.spatial_merge_size ** 2
 
+    @property
+    def mlp_dim_padded(self):     # Qwen2.5-VL: intermediate 3420 -> 3456 (zero rows/cols, exact) so GEMM K/N stay multiples of 64
+        return (self.mlp_dim + 63) // 64 * 64
+
 
 @dataclass
 class TextConfig:
@@ -91,6 +95,18 @@ def qwen2_vl_2b():
         vision=VisionConfig(out_hidden=1536), name="Qwen2-VL-2B")
 
 
+def qwen2_5_vl_7b():
+    """Qwen2.5-VL-7B (the model family the reference's trainer hard-codes, timer1_trainer.py:250-262; BASELINE configs[3])."""
+    return ModelConfig(vision=VisionConfig(mlp_dim=3420, variant="qwen2_5_vl"), name="Qwen2.5-VL-7B")
+
+
+def qwen2_5_vl_3b():
+    return ModelConfig(
+        text=TextConfig(vocab_size=151936, hidden=2048, intermediate=11008, n_layers=36, n_heads=16, n_kv_heads=2, head_dim=128,
+                        tie_word_embeddings=True),
+        vision=VisionConfig(mlp_dim=3420, out_hidden=2048, variant="qwen2_5_vl"), name="Qwen2.5-VL-3B")
+
+
 def tiny_test(vocab=512, n_layers=2, vision_depth=2, tie=False):
     """Small shapes that still satisfy the kernels' alignment rules (K % 64, head_dim % 32); used by tests and smoke()."""
     return ModelConfig(
@@ -101,4 +117,41 @@ def tiny_test(vocab=512, n_layers=2, vision_depth=2, tie=False):
         name="tiny")
 
 
-PRESETS = {"qwen2-vl-7b": qwen2_vl_7b, "qwen2-vl-2b": qwen2_vl_2b, "tiny": tiny_test}
+def tiny_test_25(vocab=512, n_layers=2, vision_depth=3, tie=False):
+    """tiny_test with the Qwen2.5-VL vision tower: RMSNorm, biased SwiGLU MLP of a non-aligned width, windows of 2x2 merged tokens,
+    full attention only in the last block."""
+    cfg = tiny_test(vocab, n_layers, vision_depth, tie)
+    cfg.vision = VisionConfig(depth=vision_depth, embed_dim=64, num_heads=2, mlp_dim=100, out_hidden=128, variant="qwen2_5_vl",
+                              window_size=56, fullatt_block_indexes=(vision_depth - 1,))
+    cfg.name = "tiny25"
+    return cfg
+
+
+def to_hf_config(cfg: ModelConfig):
+    """config.json in the transformers layout (configuration_qwen2_vl.py / configuration_qwen2_5_vl.py), so a directory written by
+    save_model loads with `from_pretrained` (the reference's eval and vLLM paths) and with trainer.load_model_dir."""
+    t, v = cfg.text, cfg.vision
+    q25 = v.variant == "qwen2_5_vl"
+    text = dict(vocab_size=t.vocab_size, hidden_size=t.hidden, intermediate_size=t.intermediate, num_hidden_layers=t.n_layers,
+                num_attention_heads=t.n_heads, num_key_value_heads=t.n_kv_heads, rms_norm_eps=t.rms_eps, hidden_act="silu",
+                rope_parameters={"rope_type": "default", "rope_theta": t.rope_theta, "mrope_section": list(t.mrope_section)},
+                rope_theta=t.rope_theta, rope_scaling={"type": "mrope", "mrope_section": list(t.mrope_section)},
+                tie_word_embeddings=t.tie_word_embeddings, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id,
+                max_position_embeddings=128000, model_type="qwen2_5_vl_text" if q25 else "qwen2_vl_text")
+    if q25:
+        vision = dict(depth=v.depth, hidden_size=v.embed_dim, hidden_act="silu", intermediate_size=v.mlp_dim, num_heads=v.num_heads,
+                      in_channels=v.in_channels, patch_size=v.patch_size, spatial_merge_size=v.spatial_merge_size,
+                      temporal_patch_size=v.temporal_patch_size, tokens_per_second=int(cfg.tokens_per_second), window_size=v.window_size,
+                      out_hidden_size=v.out_hidden, fullatt_block_indexes=list(v.fullatt_block_indexes), model_type="qwen2_5_vl")
+    else:
+        vision = dict(depth=v.depth, embed_dim=v.embed_dim, num_heads=v.num_heads, hidden_size=v.out_hidden, mlp_ratio=v.mlp_dim // v.embed_dim,
+                      hidden_act="quick_gelu", in_channels=v.in_channels, patch_size=v.patch_size, spatial_merge_size=v.spatial_merge_size,
+                      temporal_patch_size=v.temporal_patch_size, model_type="qwen2_vl")
+    return dict(architectures=["Qwen2_5_VLForConditionalGeneration" if q25 else "Qwen2VLForConditionalGeneration"],
+                model_type="qwen2_5_vl" if q25 else "qwen2_vl", text_config=text, vision_config=vision, image_token_id=cfg.image_token_id,
+                video_token_id=cfg.video_token_id, vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id,
+                tie_word_embeddings=t.tie_word_embeddings, torch_dtype="bfloat16")
+
+
+PRESETS = {"qwen2-vl-7b": qwen2_vl_7b, "qwen2-vl-2b": qwen2_vl_2b, "qwen2.5-vl-7b": qwen2_5_vl_7b, "qwen2.5-vl-3b": qwen2_5_vl_3b,
+           "tiny": tiny_test, "tiny25": tiny_test_25}

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Skinny GEMM for the decode regime (M <= 16 rows, one new token per rollout row): out[M,N] = x[M,K] * W[N,K]^T.
+// Skinny GEMM for the decode regime (M <= 64 rows, one new token per rollout row): out[M,N] = x[M,K] * W[N,K]^T.
 // HBM-bound weight streaming: every W element is read exactly once, straight from global memory into the MFMA A
 // fragment (no LDS: the operand is not shared between waves).  A block owns 16 output columns; its 4 waves split K
 // and the partial 16x16 tiles are reduced through LDS.  Each lane fetches 32 contiguous bytes of one W row per
@@ -295,16 +295,17 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------------------------
 // NCOL: 16-column groups per wave.  The x (activation) fragment is loaded once per k-step and reused for NCOL weight fragments, so
 // the L2 traffic for x drops from 1x to 1/NCOL of the weight stream (matters at M = 16, where x is as large as a block's W slab).
-template <int WAVES, int UNROLL, int NCOL>
+// MG: 16-row groups of x (M <= 16*MG): every weight fragment fetched from HBM feeds MG MFMAs, so batching more rollout rows into one
+// decode step (G = 16, or several prompts of a gradient-accumulation window) keeps the single pass over the weights.
+template <int WAVES, int UNROLL, int NCOL, int MG>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                  float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
                                                                  const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
                                                                  int64_t ldw, int64_t ldc, int64_t ldr) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][16][17];
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 16 * NCOL;
-    const bool xlive = u < M;                      // rows >= M of the MFMA B operand are padding: no loads issued for them
     // lane (u,g) takes k = g*8.. and 32+g*8.. of every 64-element step: a 16-lane group reads 64 contiguous bytes of a W row per load
     const bf16_t* wp[NCOL];
 #pragma unroll
@@ -312,18 +313,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
         int64_t wrow = n0 + c * 16 + u; if (wrow >= N) wrow = N - 1;
         wp[c] = W + wrow * ldw + g * 8;
     }
-    const bf16_t* xp = X + (int64_t)(xlive ? u : (M - 1)) * ldx + g * 8;
-    const int64_t nsteps = K / 64;
-    const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
-    const int64_t s0 = wave * s_per;
-    int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
-    f32x4_t acc[NCOL][2];
+    bool xlive[MG];                                // rows >= M of the MFMA B operand are padding: no loads issued for them
+    const bf16_t* xp[MG];
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c) { acc[c][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    for (int mg = 0; mg < MG; ++mg) {
+        xlive[mg] = mg * 16 + u < M;
+        xp[mg] = X + (int64_t)(xlive[mg] ? mg * 16 + u : (M - 1)) * ldx + g * 8;
+    }
+    // gridDim.y > 1: cross-block split-K - block (x, y) covers k-steps [kb, ke) and writes its raw fp32 partial tile to slab y of Cf32;
+    // the consumer kernel (rmsnorm / decode_qkv_post) sums the slabs while it reads them (no extra pass, deterministic order)
+    const int64_t nsteps_all = K / 64;
+    const int64_t per_split = (nsteps_all + gridDim.y - 1) / gridDim.y;
+    const int64_t kb = (int64_t)blockIdx.y * per_split;
+    int64_t ke = kb + per_split; if (ke > nsteps_all) ke = nsteps_all;
+    const int64_t nsteps = ke > kb ? ke - kb : 0;
+    const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
+    const int64_t s0 = kb + wave * s_per;
+    int64_t s1 = s0 + s_per; if (s1 > ke) s1 = ke;
+    if (gridDim.y > 1) Cf32 += (int64_t)blockIdx.y * M * ldc;
+    f32x4_t acc[NCOL][MG][2];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     const bf16x8_t zf = zero_frag8();
     int64_t s = s0;
     for (; s + UNROLL <= s1; s += UNROLL) {
-        bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][2];
+        bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2];
 #pragma unroll
         for (int q = 0; q < UNROLL; ++q) {
             const int64_t k = (s + q) * 64;
@@ -332,48 +348,95 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
                 wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
                 wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
             }
-            xa[q][0] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k) : zf;
-            xa[q][1] = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + 32) : zf;
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                xa[q][mg][0] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf;
+                xa[q][mg][1] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf;
+            }
         }
 #pragma unroll
         for (int q = 0; q < UNROLL; ++q)
 #pragma unroll
-            for (int c = 0; c < NCOL; ++c) {
-                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], xa[q][0], acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], xa[q][1], acc[c][1], 0, 0, 0);
-            }
+            for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], xa[q][mg][0], acc[c][mg][0], 0, 0, 0);
+                    acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], xa[q][mg][1], acc[c][mg][1], 0, 0, 0);
+                }
     }
     for (; s < s1; ++s) {
         const int64_t k = s * 64;
-        const bf16x8_t x0 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k) : zf;
-        const bf16x8_t x1 = xlive ? *reinterpret_cast<const bf16x8_t*>(xp + k + 32) : zf;
+        bf16x8_t x0[MG], x1[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            x0[mg] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf;
+            x1[mg] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf;
+        }
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
             const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
             const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
-            acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[c][0], 0, 0, 0);
-            acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc[c][1], 0, 0, 0);
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0[mg], acc[c][mg][0], 0, 0, 0);
+                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[mg], acc[c][mg][1], 0, 0, 0);
+            }
         }
     }
     // D[row = n index (g*4+r)][col = m (u)]
 #pragma unroll
     for (int c = 0; c < NCOL; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][c][u][g * 4 + r] = acc[c][0][r] + acc[c][1][r];
+        for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][0][r] + acc[c][mg][1][r];
     __syncthreads();
-    for (int i = threadIdx.x; i < NCOL * 256; i += WAVES * 64) {   // (column group, m, n)
-        const int c = i >> 8, m = (i >> 4) & 15, nn = i & 15;
+    for (int i = threadIdx.x; i < NCOL * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
+        const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
+        const int m = mg * 16 + mm;
         const int64_t n = n0 + c * 16 + nn;
         if (m < M && n < N) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) v += red[w][c][m][nn];
+            for (int w = 0; w < WAVES; ++w) v += red[w][c][mg][mm][nn];
             if (bias) v += bf2f(bias[n]);
             if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
             if (Cf32) Cf32[(int64_t)m * ldc + n] = v;
             else C[(int64_t)m * ldc + n] = f2bf(v);
         }
     }
+}
+
+// Launch of the decode-regime kernel.  ksplit > 1: C is fp32 [ksplit, M, ldc] partial slabs (no bias / residual).
+static void launch_skinny(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                          int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int ksplit, hipStream_t s) {
+    static int force_ncol = -1;
+    if (force_ncol < 0) { const char* e = getenv("TR1_SKINNY_NCOL"); force_ncol = e ? atoi(e) : 0; }
+#define SK(WV, UN, NC, MGR)                                                                                                          \
+    hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC, MGR>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC)), (unsigned)ksplit),    \
+                       dim3(WV * 64), 0, s, (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C,                     \
+                       out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr)
+    // choices measured on MI355X with tools/microbench.py skinny (non-temporal loads hurt; 8-way in-block split-K pays for long K)
+    // (A/B on MI355X, M = 16: gate_up 37888x3584 67.6 -> 56.8 us with NCOL 2; lm_head 152064x3584 247 -> 188 us with NCOL 4;
+    //  the 3584x18944 down projection has too few column groups for NCOL > 1 and wants split-K instead)
+    const int ncol = force_ncol > 0 ? force_ncol : (N >= 100000 ? 4 : (N >= 4096 && ksplit == 1 ? 2 : 1));
+    const bool longk = K / ksplit >= 8192;
+    if (M <= 16) {
+        if (longk) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2, 1); else SK(8, 4, 1, 1); }
+        else if (ncol == 4) SK(4, 2, 4, 1);
+        else if (ncol == 2) SK(4, 4, 2, 1);
+        else SK(4, 4, 1, 1);
+    } else if (M <= 32) {       // LDS reduce buffer: WAVES * NCOL * MG * 1088 B <= 64 KB
+        if (longk) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2, 2); else SK(8, 2, 1, 2); }
+        else if (ncol == 4) SK(4, 2, 4, 2);
+        else if (ncol == 2) SK(4, 2, 2, 2);
+        else SK(4, 4, 1, 2);
+    } else {
+        if (longk) SK(8, 2, 1, 4);
+        else if (ncol >= 2) SK(4, 2, 2, 4);
+        else SK(4, 2, 1, 4);
+    }
+#undef SK
 }
 
 extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
@@ -385,22 +448,8 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     TR1_CHECK_ARG(out_f32 || ldc % 8 == 0, "gemm_nt: ldc%8 required for bf16 output");
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 16 && !accumulate && K >= 256) {
-        static int force_ncol = -1;
-        if (force_ncol < 0) { const char* e = getenv("TR1_SKINNY_NCOL"); force_ncol = e ? atoi(e) : 0; }
-#define SK(WV, UN, NC)                                                                                                               \
-    hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC))), dim3(WV * 64), 0, s,      \
-                       (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C, out_f32 ? (float*)C : nullptr,           \
-                       (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr)
-        // choices measured on MI355X with tools/microbench.py skinny (non-temporal loads hurt; 8-way in-block split-K pays for long K)
-        // (A/B on MI355X, M = 16: gate_up 37888x3584 67.6 -> 56.8 us with NCOL 2; lm_head 152064x3584 247 -> 188 us with NCOL 4;
-        //  the 3584x18944 down projection has too few column groups for NCOL > 1 and wants 8-way in-block split-K instead)
-        int ncol = force_ncol > 0 ? force_ncol : (N >= 100000 ? 4 : (N >= 4096 ? 2 : 1));
-        if (K >= 8192) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2); else SK(8, 4, 1); }
-        else if (ncol == 4) SK(4, 2, 4);
-        else if (ncol == 2) SK(4, 4, 2);
-        else SK(4, 4, 1);
-#undef SK
+    if (M <= 64 && !accumulate && K >= 256) {
+        launch_skinny(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_f32, 1, s);
         TR1_LAUNCH_CHECK();
     }
     {   // large outputs: 256x256 tiles when they still give >= ~2.3 rounds of 256 CUs (tile-count quantisation)
@@ -435,5 +484,15 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     if (out_f32) { if (accumulate) LAUNCH(true, true); else LAUNCH(true, false); }
     else LAUNCH(false, false);
 #undef LAUNCH
+    TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                                      int ksplit, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && K >= 256, "gemm_skinny_splitk: K must be a multiple of 64 and >= 256");
+    TR1_CHECK_ARG(M >= 1 && M <= 64, "gemm_skinny_splitk: 1 <= M <= 64 (decode rows)");
+    TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_skinny_splitk: N%8, lda%8, ldb%8 required");
+    TR1_CHECK_ARG(ksplit >= 1 && ksplit <= 16 && K / 64 >= ksplit, "gemm_skinny_splitk: 1 <= ksplit <= min(16, K/64)");
+    launch_skinny(A, B, parts_f32, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 1, ksplit, (hipStream_t)stream);
     TR1_LAUNCH_CHECK();
 }

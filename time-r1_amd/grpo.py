@@ -31,6 +31,7 @@ class GRPOCore:
         self.G, self.C = int(num_generations), int(max_completion_length)
         self.beta, self.use_grpo = float(beta), bool(use_grpo)
         self.rope_index_mode = rope_index_mode
+        self.second_per_grid_t = 1.0
         # The rollout's prefill IS the policy forward over the prompt rows (same weights inside an accumulation window): keep its
         # activations and run the update's policy forward over the G*C completion rows only.
         self.reuse_prefill = bool(reuse_prefill)
@@ -52,8 +53,12 @@ class GRPOCore:
         st.prompt_ids = ops.tensor(ids.astype(np.int32), I32)
         vid_rows = np.nonzero(ids == cfg.video_token_id)[0].astype(np.int32)
         st.vid_rows = ops.tensor(vid_rows, I32)
+        # Qwen2.5-VL spaces temporal ids by tokens_per_second * second_per_grid_t (modeling_qwen2_5_vl.py:1043); the reference's logprob
+        # forwards omit second_per_grid_ts (timer1_trainer.py:452-457) -> 1 s per grid step, which is also what its default FPS=2 gives
+        # the rollout (temporal_patch_size / fps = 1.0), so one rule serves both phases here.
+        interval = int(cfg.tokens_per_second * self.second_per_grid_t) if cfg.vision.variant == "qwen2_5_vl" else 1
         st.pos3_prompt, st.delta = rope_index(ids, grid, cfg.video_token_id, cfg.image_token_id, cfg.vision.spatial_merge_size,
-                                              mode=self.rope_index_mode)
+                                              mode=self.rope_index_mode, time_interval=interval)
         v = cfg.vision
         pix = torch.as_tensor(pixel_values_videos)
         n_vid_tokens = sum(t * h * w for t, h, w in grid) // v.merge_unit
@@ -64,8 +69,8 @@ class GRPOCore:
             assert pix.dim() == 2 and pix.shape[1] == v.patch_dim, pix.shape
             pp = ops.zeros(pix.shape[0], v.patch_dim_padded)
             pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)
-        st.feats = eng.vit_features(pp, grid)                     # frozen blocks: once per prompt (reference: 3 x G times)
-        st.vid_embeds, st.merger_ctx = eng.merger_fwd(eng.params.train, st.feats, save=True)
+        st.feats, st.vis_perm = eng.vit_features(pp, grid)        # frozen blocks: once per prompt (reference: 3 x G times)
+        st.vid_embeds, st.merger_ctx = eng.merger_fwd(eng.params.train, st.feats, save=True, perm=st.vis_perm)
         return st
 
     # ------------------------------------------------------------------------------------------------------- phase 2
@@ -136,7 +141,7 @@ class GRPOCore:
         st.ref_logp = None
         if self.beta != 0.0:
             ra = self.ref_arena
-            ref_vid, _ = eng.merger_fwd(ra, st.feats, save=False)
+            ref_vid, _ = eng.merger_fwd(ra, st.feats, save=False, perm=st.vis_perm)
             h0r = eng.embed(ra, st.ids_packed, ref_vid, st.vid_rows)
             hLr, _ = eng.llm_fwd(ra, h0r, st.cos, st.sin, st.masks, save=False)
             rlogp, _, _ = eng.head_fwd(ra, hLr, st.pred_rows, st.targets, save=False)

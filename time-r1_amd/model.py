@@ -14,7 +14,7 @@ import torch
 
 from .config import ModelConfig
 from .params import ModelParams, Arena
-from .positions import vision_hw_ids, vision_segments
+from .positions import vision_hw_ids, vision_segments, vision_window_index, segments_from_cu
 
 I32 = torch.int32
 F32 = torch.float32
@@ -23,7 +23,7 @@ F32 = torch.float32
 class Engine:
     def __init__(self, cfg: ModelConfig, ops, params: ModelParams):
         self.cfg, self.ops, self.params = cfg, ops, params
-        assert cfg.vision.variant == "qwen2_vl", "this round implements the Qwen2-VL vision tower (Qwen2.5-VL windows: next)"
+        assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
     def _wgrad(self, dy, x, gw):
@@ -41,7 +41,11 @@ class Engine:
 
     # ============================================================================================================ ViT
     def vit_features(self, pixels, grid_thw):
-        """Frozen Qwen2-VL vision blocks. pixels: [N_v, patch_dim_padded] act dtype; grid_thw: list of (t,h,w). -> [N_v, embed]"""
+        """Frozen vision blocks. pixels: [N_v, patch_dim_padded] act dtype; grid_thw: list of (t,h,w).
+        Returns (feats [N_v, embed], perm): perm is None for Qwen2-VL; for Qwen2.5-VL the rows of feats are in WINDOW order and perm is
+        the int32 device tensor (window_index) merger_fwd/bwd use to restore the natural order of the merged tokens."""
+        if self.cfg.vision.variant == "qwen2_5_vl":
+            return self._vit_features_25(pixels, grid_thw)
         ops, v, fz = self.ops, self.cfg.vision, self.params.frozen
         E, H, hd = v.embed_dim, v.num_heads, v.head_dim
         hw = ops.tensor(vision_hw_ids(grid_thw, v.spatial_merge_size), I32)
@@ -63,22 +67,68 @@ class Engine:
             y, _, _ = ops.layernorm_fwd(x, fz.w(p + "n2.w"), fz.w(p + "n2.b"), v.ln_eps, need_stats=False)
             z = ops.quickgelu_fwd(ops.gemm_nt(y, fz.w(p + "fc1.w"), bias=fz.w(p + "fc1.b")))
             x = ops.gemm_nt(z, fz.w(p + "fc2.w"), bias=fz.w(p + "fc2.b"), residual=x)
-        return x
+        return x, None
 
-    def merger_fwd(self, arena: Arena, feats, save):
-        """PatchMerger (trainable even with fix_vit, reference timer1_trainer.py:277-280). feats [N_v, E] -> [N_v/4, out_hidden]"""
+    def _vit_features_25(self, pixels, grid_thw):
+        """Qwen2.5-VL tower (transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:408-470 forward, :294-325 block, :85-96 MLP):
+        merged tokens are permuted once into window-major order, so BOTH attention flavours are contiguous segments of the same
+        two-interval mask kernel - windows for most blocks, whole temporal patches for `fullatt_block_indexes` (a frame's windows
+        stay contiguous after the permutation).  RMSNorm + biased SwiGLU MLP (width zero-padded to a multiple of 64)."""
+        ops, v, fz = self.ops, self.cfg.vision, self.params.frozen
+        E, H, hd, U = v.embed_dim, v.num_heads, v.head_dim, v.merge_unit
+        N = pixels.shape[0]
+        widx, cu_win = vision_window_index(grid_thw, v.spatial_merge_size, v.window_size, v.patch_size)
+        hw = vision_hw_ids(grid_thw, v.spatial_merge_size)
+        assert hw.shape[0] == N and widx.shape[0] * U == N, (hw.shape, widx.shape, N)
+        hw = hw.reshape(N // U, U, 2)[widx].reshape(N, 2)
+        cos, sin = ops.vision_rope_table(ops.tensor(np.ascontiguousarray(hw), I32), hd)
+        seg_win = [ops.tensor(a, I32) for a in segments_from_cu(cu_win)]
+        seg_full = [ops.tensor(a, I32) for a in vision_segments(grid_thw)]
+        perm = ops.tensor(widx.astype(np.int32), I32)
+        x = ops.gemm_nt(pixels, fz.w("patch.w"))
+        x = ops.gather_rows(x.view(N // U, U * E), perm).view(N, E)
+        scale = hd ** -0.5
+        for i in range(v.depth):
+            p = "v%d." % i
+            pre, lo, hi = seg_full if i in v.fullatt_block_indexes else seg_win
+            y, _, _ = ops.rmsnorm_fwd(x, fz.w(p + "n1.w"), v.ln_eps, need_rstd=False)
+            qkv = ops.gemm_nt(y, fz.w(p + "qkv.w"), bias=fz.w(p + "qkv.b"))
+            q = ops.rope_apply(qkv[:, :E], H, hd, cos, sin)
+            k = ops.rope_apply(qkv[:, E:2 * E], H, hd, cos, sin)
+            vt = ops.pack_transpose(qkv[:, 2 * E:], H, H, hd)
+            o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
+            x = ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
+            y, _, _ = ops.rmsnorm_fwd(x, fz.w(p + "n2.w"), v.ln_eps, need_rstd=False)
+            a = ops.swiglu_fwd(ops.gemm_nt(y, fz.w(p + "gu.w"), bias=fz.w(p + "gu.b")))
+            x = ops.gemm_nt(a, fz.w(p + "down.w"), bias=fz.w(p + "down.b"), residual=x)
+        return x, perm
+
+    def merger_fwd(self, arena: Arena, feats, save, perm=None):
+        """PatchMerger (trainable even with fix_vit, reference timer1_trainer.py:277-280). feats [N_v, E] -> [N_v/4, out_hidden].
+        Qwen2-VL: LayerNorm; Qwen2.5-VL: RMSNorm, and the output rows go back from window order to natural order
+        (modeling_qwen2_5_vl.py:462-464: merged[argsort(window_index)])."""
         ops, v = self.ops, self.cfg.vision
         N, E = feats.shape
-        xn, mean, rstd = ops.layernorm_fwd(feats, arena.w("merger.ln.w"), arena.w("merger.ln.b"), v.ln_eps, need_stats=save)
+        if v.variant == "qwen2_5_vl":
+            xn, rstd, _ = ops.rmsnorm_fwd(feats, arena.w("merger.ln.w"), v.ln_eps, need_rstd=save)
+            mean = None
+        else:
+            xn, mean, rstd = ops.layernorm_fwd(feats, arena.w("merger.ln.w"), arena.w("merger.ln.b"), v.ln_eps, need_stats=save)
         xv = xn.view(N // v.merge_unit, E * v.merge_unit)
         z1 = ops.gemm_nt(xv, arena.w("merger.fc1.w"), bias=arena.w("merger.fc1.b"))
         g1 = ops.gelu_fwd(z1)
         out = ops.gemm_nt(g1, arena.w("merger.fc2.w"), bias=arena.w("merger.fc2.b"))
-        ctx = dict(feats=feats, mean=mean, rstd=rstd, xv=xv, z1=z1, g1=g1) if save else None
+        if perm is not None:           # out_nat[perm[j]] = out_win[j]
+            nat = ops.empty(*out.shape)
+            ops.scatter_rows(out, perm, nat)
+            out = nat
+        ctx = dict(feats=feats, mean=mean, rstd=rstd, xv=xv, z1=z1, g1=g1, perm=perm) if save else None
         return out, ctx
 
     def merger_bwd(self, ctx, dout):
         ops, tr = self.ops, self.params.train
+        if ctx["perm"] is not None:
+            dout = ops.gather_rows(dout, ctx["perm"])
         self._wgrad(dout, ctx["g1"], tr.g("merger.fc2.w"))
         ops.colsum_accum(dout, tr.g("merger.fc2.b"))
         dg1 = self._dgrad(dout, tr.w("merger.fc2.w"))
@@ -87,8 +137,11 @@ class Engine:
         ops.colsum_accum(dz1, tr.g("merger.fc1.b"))
         dxv = self._dgrad(dz1, tr.w("merger.fc1.w"))
         dxn = dxv.view(ctx["feats"].shape)
-        ops.layernorm_bwd(dxn, ctx["feats"], tr.w("merger.ln.w"), ctx["mean"], ctx["rstd"], tr.g("merger.ln.w"), tr.g("merger.ln.b"),
-                          need_dx=False)  # the blocks below are frozen: no dx
+        if self.cfg.vision.variant == "qwen2_5_vl":
+            ops.rmsnorm_bwd(dxn, ctx["feats"], tr.w("merger.ln.w"), ctx["rstd"], dw=tr.g("merger.ln.w"))
+        else:
+            ops.layernorm_bwd(dxn, ctx["feats"], tr.w("merger.ln.w"), ctx["mean"], ctx["rstd"], tr.g("merger.ln.w"), tr.g("merger.ln.b"),
+                              need_dx=False)  # the blocks below are frozen: no dx
 
     # ============================================================================================================ LLM
     def embed(self, arena: Arena, ids, vid_embeds=None, vid_rows=None):

@@ -74,6 +74,16 @@ class HipOps:
                     _ld(residual) if residual is not None else 0, int(out_f32), int(accumulate), self._s())
         return out
 
+    def gemm_skinny_splitk(self, a, b, ksplit):
+        """fp32 partial slabs [ksplit, M, N] of a @ b^T (decode rows; summed by rmsnorm_fwd_parts / decode_qkv_post)."""
+        self._chk(a, b)
+        M, K = a.shape
+        N = b.shape[0]
+        assert a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
+        parts = self.empty(ksplit, M, N, dtype=F32)
+        self.L.call("tr1_gemm_skinny_splitk", _p(a), _p(b), _p(parts), M, N, K, a.stride(0), b.stride(0), ksplit, self._s())
+        return parts
+
     def transpose(self, x, pad_to=64, out=None):
         """x[R,C] -> [C, Rpad] with zero-filled padding columns (Rpad = R rounded up to pad_to)."""
         self._chk(x)

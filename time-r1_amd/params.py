@@ -40,6 +40,14 @@ def _specs_merger(cfg: ModelConfig):
 def _specs_vit(cfg: ModelConfig):
     v = cfg.vision
     s = [("patch.w", (v.embed_dim, v.patch_dim_padded))]
+    if v.variant == "qwen2_5_vl":       # RMSNorm (no bias) + biased SwiGLU MLP, width padded with zeros to a multiple of 64
+        ip = v.mlp_dim_padded
+        for i in range(v.depth):
+            p = "v%d." % i
+            s += [(p + "n1.w", (v.embed_dim,)), (p + "qkv.w", (3 * v.embed_dim, v.embed_dim)), (p + "qkv.b", (3 * v.embed_dim,)),
+                  (p + "proj.w", (v.embed_dim, v.embed_dim)), (p + "proj.b", (v.embed_dim,)), (p + "n2.w", (v.embed_dim,)),
+                  (p + "gu.w", (2 * ip, v.embed_dim)), (p + "gu.b", (2 * ip,)), (p + "down.w", (v.embed_dim, ip)), (p + "down.b", (v.embed_dim,))]
+        return s
     for i in range(v.depth):
         p = "v%d." % i
         s += [(p + "n1.w", (v.embed_dim,)), (p + "n1.b", (v.embed_dim,)), (p + "qkv.w", (3 * v.embed_dim, v.embed_dim)),
@@ -140,6 +148,7 @@ class ModelParams:
                     if name == "patch.w":
                         t[:, self.cfg.vision.patch_dim:] = 0
                 arena.w(name).copy_(t.to(arena.w16.dtype))
+        self._zero_vision_mlp_padding()
         self.train.sync_master_from_w16()
 
     def init_random_device(self, seed=0, std=0.02):
@@ -155,7 +164,18 @@ class ModelParams:
                 if name.endswith("ln1") or name.endswith("ln2") or name == "norm" or name.endswith("ln.w") or name.endswith("n1.w") or name.endswith("n2.w"):
                     arena.w(name).fill_(1.0)
         self.frozen.w("patch.w")[:, self.cfg.vision.patch_dim:].zero_()
+        self._zero_vision_mlp_padding()
         self.train.sync_master_from_w16()
+
+    def _zero_vision_mlp_padding(self):
+        v = self.cfg.vision
+        if v.variant != "qwen2_5_vl" or v.mlp_dim_padded == v.mlp_dim:
+            return
+        i0, ip = v.mlp_dim, v.mlp_dim_padded
+        for i in range(v.depth):
+            p = "v%d." % i
+            gu, gb, dw = self.frozen.w(p + "gu.w"), self.frozen.w(p + "gu.b"), self.frozen.w(p + "down.w")
+            gu[i0:ip].zero_(); gu[ip + i0:].zero_(); gb[i0:ip].zero_(); gb[ip + i0:].zero_(); dw[:, i0:].zero_()
 
     # ---- HF checkpoint <-> arena ----------------------------------------------------------------------------------
     def load_hf_state_dict(self, sd):
@@ -203,6 +223,25 @@ class ModelParams:
         put(fz, "patch.w", pwp)
         for i in range(v.depth):
             p, h = "v%d." % i, "blocks.%d." % i
+            if v.variant == "qwen2_5_vl":
+                i0, ip = v.mlp_dim, v.mlp_dim_padded
+                put(fz, p + "n1.w", get(h + "norm1.weight"))
+                put(fz, p + "n2.w", get(h + "norm2.weight"))
+                for a, b in (("qkv", "attn.qkv"), ("proj", "attn.proj")):
+                    put(fz, p + a + ".w", get(h + b + ".weight"))
+                    put(fz, p + a + ".b", get(h + b + ".bias"))
+                gw, uw, dw = get(h + "mlp.gate_proj.weight"), get(h + "mlp.up_proj.weight"), get(h + "mlp.down_proj.weight")
+                guw = torch.zeros(2 * ip, v.embed_dim, dtype=gw.dtype)
+                guw[:i0], guw[ip:ip + i0] = gw, uw
+                gub = torch.zeros(2 * ip, dtype=gw.dtype)
+                gub[:i0], gub[ip:ip + i0] = get(h + "mlp.gate_proj.bias"), get(h + "mlp.up_proj.bias")
+                dwp = torch.zeros(v.embed_dim, ip, dtype=dw.dtype)
+                dwp[:, :i0] = dw
+                put(fz, p + "gu.w", guw)
+                put(fz, p + "gu.b", gub)
+                put(fz, p + "down.w", dwp)
+                put(fz, p + "down.b", get(h + "mlp.down_proj.bias"))
+                continue
             for a, b in (("n1", "norm1"), ("n2", "norm2"), ("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
                 put(fz, p + a + ".w", get(h + b + ".weight"))
                 put(fz, p + a + ".b", get(h + b + ".bias"))
@@ -239,6 +278,16 @@ class ModelParams:
         sd["model.visual.patch_embed.proj.weight"] = fz.w("patch.w")[:, : v.patch_dim].reshape(v.embed_dim, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size)
         for i in range(v.depth):
             p, h = "v%d." % i, "model.visual.blocks.%d." % i
+            if v.variant == "qwen2_5_vl":
+                i0, ip = v.mlp_dim, v.mlp_dim_padded
+                sd[h + "norm1.weight"], sd[h + "norm2.weight"] = fz.w(p + "n1.w"), fz.w(p + "n2.w")
+                for a, b in (("qkv", "attn.qkv"), ("proj", "attn.proj")):
+                    sd[h + b + ".weight"], sd[h + b + ".bias"] = fz.w(p + a + ".w"), fz.w(p + a + ".b")
+                gu, gb = fz.w(p + "gu.w"), fz.w(p + "gu.b")
+                sd[h + "mlp.gate_proj.weight"], sd[h + "mlp.up_proj.weight"] = gu[:i0], gu[ip:ip + i0]
+                sd[h + "mlp.gate_proj.bias"], sd[h + "mlp.up_proj.bias"] = gb[:i0], gb[ip:ip + i0]
+                sd[h + "mlp.down_proj.weight"], sd[h + "mlp.down_proj.bias"] = fz.w(p + "down.w")[:, :i0], fz.w(p + "down.b")
+                continue
             for a, b in (("n1", "norm1"), ("n2", "norm2"), ("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
                 sd[h + b + ".weight"] = fz.w(p + a + ".w")
                 sd[h + b + ".bias"] = fz.w(p + a + ".b")

@@ -77,6 +77,38 @@ def vision_segments(grid_thw):
     return np.zeros(a, dtype=np.int32), np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32)
 
 
+def segments_from_cu(cu):
+    """(pre, lo, hi) int32 [N] from cumulative segment boundaries: row r in [cu[j], cu[j+1]) attends exactly that range."""
+    cu = np.asarray(cu, dtype=np.int64)
+    n = np.diff(cu)
+    lo = np.repeat(cu[:-1], n)
+    hi = np.repeat(cu[1:] - 1, n)
+    return np.zeros(int(cu[-1]), dtype=np.int32), lo.astype(np.int32), hi.astype(np.int32)
+
+
+def vision_window_index(grid_thw, spatial_merge=2, window_size=112, patch_size=14):
+    """Qwen2.5-VL window partition (transformers vision_utils.py:130-188, get_vision_window_index).  Works in units of merged tokens
+    (spatial_merge^2 consecutive patches): every temporal patch's (h/m, w/m) grid is cut into windows of mw x mw merged tokens
+    (mw = window_size // merge // patch), ragged at the right/bottom edges.
+    Returns (window_index int64 [N/unit]: window-major order -> natural merged-token index,
+             cu_window int64 [n_windows+1]: window boundaries in PATCH units)."""
+    mw = window_size // spatial_merge // patch_size
+    unit = spatial_merge ** 2
+    order, cu = [], [0]
+    base = 0
+    for t, h, w in grid_thw:
+        t, gh, gw = int(t), int(h) // spatial_merge, int(w) // spatial_merge
+        idx = np.arange(t * gh * gw, dtype=np.int64).reshape(t, gh, gw) + base
+        for ti in range(t):
+            for a in range(0, gh, mw):
+                for b in range(0, gw, mw):
+                    win = idx[ti, a:a + mw, b:b + mw].reshape(-1)
+                    order.append(win)
+                    cu.append(cu[-1] + win.size * unit)
+        base += t * gh * gw
+    return np.concatenate(order), np.asarray(cu, dtype=np.int64)
+
+
 class PackedLayout:
     """Packed sequence for one prompt and its G completions of (up to) C tokens:
 

@@ -154,15 +154,24 @@ def load_model_dir(path, ops):
                       n_heads=tc["num_attention_heads"], n_kv_heads=tc["num_key_value_heads"], head_dim=tc["hidden_size"] // tc["num_attention_heads"],
                       rms_eps=tc.get("rms_norm_eps", 1e-6), rope_theta=float(rope.get("rope_theta", tc.get("rope_theta", 1e6))),
                       mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))), tie_word_embeddings=bool(hc.get("tie_word_embeddings", tc.get("tie_word_embeddings", False))))
-    if "Qwen2_5" in "".join(hc.get("architectures", [])):
-        raise NotImplementedError("Qwen2.5-VL vision tower (windowed attention, RMSNorm, SwiGLU) is scheduled next; this build runs Qwen2-VL")
-    vision = VisionConfig(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_dim=int(vc["embed_dim"] * vc.get("mlp_ratio", 4)),
+    tps = 2.0
+    if "Qwen2_5" in "".join(hc.get("architectures", [])) or hc.get("model_type") == "qwen2_5_vl":
+        # Qwen2.5-VL vision config (configuration_qwen2_5_vl.py): hidden_size = ViT width, out_hidden_size = LLM width
+        vision = VisionConfig(depth=vc["depth"], embed_dim=vc["hidden_size"], num_heads=vc["num_heads"], mlp_dim=vc["intermediate_size"],
+                              out_hidden=vc["out_hidden_size"], patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
+                              spatial_merge_size=vc.get("spatial_merge_size", 2), in_channels=vc.get("in_channels", vc.get("in_chans", 3)),
+                              variant="qwen2_5_vl", window_size=vc.get("window_size", 112),
+                              fullatt_block_indexes=tuple(vc.get("fullatt_block_indexes", (7, 15, 23, 31))))
+        tps = float(vc.get("tokens_per_second", 2))
+    else:
+        vision = None
+    vision = vision or VisionConfig(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_dim=int(vc["embed_dim"] * vc.get("mlp_ratio", 4)),
                           out_hidden=vc["hidden_size"], patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
                           spatial_merge_size=vc.get("spatial_merge_size", 2), in_channels=vc.get("in_channels", vc.get("in_chans", 3)))
     cfg = ModelConfig(text=text, vision=vision, image_token_id=hc["image_token_id"], video_token_id=hc["video_token_id"],
                       vision_start_token_id=hc["vision_start_token_id"], vision_end_token_id=hc["vision_end_token_id"],
                       eos_token_id=tc.get("eos_token_id", hc.get("eos_token_id", 151645)), pad_token_id=tc.get("pad_token_id", hc.get("pad_token_id", 151643)) or 151643,
-                      name=os.path.basename(os.path.normpath(path)))
+                      tokens_per_second=tps, name=os.path.basename(os.path.normpath(path)))
     if isinstance(cfg.eos_token_id, list):
         cfg.eos_token_id = cfg.eos_token_id[0]
     sd = {}
@@ -521,6 +530,8 @@ class TimeR1_Trainer:
         from safetensors.torch import save_file
         save_file(self.params.export_hf_state_dict(), os.path.join(output_dir, "model.safetensors"), metadata={"format": "pt"})
         json.dump(dataclasses.asdict(self.cfg), open(os.path.join(output_dir, "timer1_model_config.json"), "w"), indent=1)
+        from .config import to_hf_config
+        json.dump(to_hf_config(self.cfg), open(os.path.join(output_dir, "config.json"), "w"), indent=1)   # reference: save_pretrained via Trainer
 
     def _save_checkpoint(self):
         d = os.path.join(self.args.output_dir, "checkpoint-%d" % self.state.global_step)
