@@ -129,11 +129,22 @@ def instrument_gemms(ops):
         e0.record()
         r = orig(a, b, bias=bias, residual=residual, out_f32=out_f32, out=out, accumulate=accumulate)
         e1.record()
-        skinny = M <= 16 and not accumulate and K >= 256
+        skinny = M <= 64 and not accumulate and K >= 256
         rec.append((skinny, M, N, K, e0, e1))
         return r
+
+    orig_ng = ops.norm_gemm
+
+    def timed_ng(x, lnw, eps, w, bias=None, glu=False):      # decode-step fused rmsnorm + projection (+ SwiGLU): same weight stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_ng(x, lnw, eps, w, bias=bias, glu=glu)
+        e1.record()
+        rec.append((True, x.shape[0], w.shape[0], x.shape[1], e0, e1))
+        return r
     ops.gemm_nt = timed
-    return rec, orig
+    ops.norm_gemm = timed_ng
+    return rec, (orig, orig_ng)
 
 
 def cpu_baseline(args, budget_note=True):
@@ -290,7 +301,7 @@ def main():
         wl.window()
         torch.cuda.synchronize()
         if rank == 0:
-            ops.gemm_nt = orig
+            ops.gemm_nt, ops.norm_gemm = orig
     if rank == 0 and not args.no_roofline:
         nstep = float(args.ga)
         big_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if not s)
@@ -302,7 +313,7 @@ def main():
         mfma = {"kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms / nstep, "traffic": None}
         mfma["frac"] = mfma["achieved"] / PEAK_BF16_TFLOPS
-        hbm = {"kernel": "gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
+        hbm = {"kernel": "gemm_skinny_kernel+norm_gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
                "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms / nstep, "traffic": None}
         hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
         # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, gfx950 x2 read

@@ -37,6 +37,10 @@ int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, co
  * consumer kernel (tr1_rmsnorm_fwd_parts / tr1_decode_qkv_post with n_parts), so the reduction costs no extra pass.  Same call sites as
  * tr1_gemm_nt_bf16 inside generate (timer1_trainer.py:568-573). */
 int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int ksplit, void* stream);
+/* Decode-step fusion (M <= 64 rows): out = rmsnorm(x; lnw, eps) @ W[N,K]^T (+ bias), the norm folded into the GEMM's operand load
+ * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
+ * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */
+int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream);
 /* out[c, r] = in[r, c]; columns [R, ld_out) of out are zero-filled (feeds the NT GEMM for dgrad / wgrad). */
 int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* stream);
 

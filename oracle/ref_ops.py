@@ -131,6 +131,11 @@ class RefOps:
         return self._a(dx)
 
     # ---- activations (ref: TF:459-466 SwiGLU; TF:277-290 GELU; TF:293-301 quick_gelu)
+    def norm_gemm(self, x, lnw, eps, w, bias=None, glu=False):
+        xn, _, _ = self.rmsnorm_fwd(x, lnw, eps, need_rstd=False)
+        y = self.gemm_nt(xn, w, bias=bias)
+        return self.swiglu_fwd(y) if glu else y
+
     def swiglu_fwd(self, gu):
         i = gu.shape[1] // 2
         g, u = gu[:, :i].float(), gu[:, i:].float()

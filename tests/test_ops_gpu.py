@@ -410,3 +410,22 @@ def test_video_preprocess_fused(hip_ops, ref_ops, T, H, W, Ho, Wo):
     err = (a - b).abs()
     assert float(err.max()) <= 0.0151 + 0.008
     assert float((err > 0.009).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,glu", [(8, 512, 256, False), (16, 4608, 3584, False), (5, 72, 320, False), (16, 1024, 3584, True), (13, 200, 512, True),
+                                       (32, 4608, 3584, False), (24, 1024, 1536, True), (64, 512, 3584, False), (40, 136, 832, True)])
+def test_norm_gemm_fused(hip_ops, ref_ops, M, N, K, glu):
+    """rmsnorm folded into the decode GEMM (and SwiGLU into its epilogue) vs the unfused oracle composition."""
+    x, lnw = rnd(M, K, seed=1, scale=2.0), (1.0 + 0.1 * rnd(K, seed=2).float()).to(BF16)
+    # GLU: products of two O(sqrt(K)*scale) values amplify the bf16 rounding of either factor - keep gate/up at O(1) like real activations
+    w = rnd(2 * N if glu else N, K, seed=3, scale=1.5 / math.sqrt(K) if glu else 0.1)
+    bias = None if glu else rnd(N, seed=4)
+    h = hip_ops.norm_gemm(x.cuda(), lnw.cuda(), 1e-6, w.cuda(), bias=None if bias is None else bias.cuda(), glu=glu)
+    r = ref_ops.norm_gemm(x.float(), lnw.float(), 1e-6, w.float(), bias=None if bias is None else bias.float(), glu=glu)
+    close(h, r, 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=0.02, what="norm_gemm glu=%s" % glu)
+    # and against the unfused HIP path (same rounding points except the norm scale order)
+    xn, _, _ = hip_ops.rmsnorm_fwd(x.cuda(), lnw.cuda(), 1e-6, need_rstd=False)
+    y = hip_ops.gemm_nt(xn, w.cuda(), bias=None if bias is None else bias.cuda())
+    if glu:
+        y = hip_ops.swiglu_fwd(y)
+    close(h, y.float().cpu(), 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=0.02, what="norm_gemm vs unfused HIP")

@@ -407,6 +407,171 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Decode-step fusion: out = rmsnorm(x; lnw) @ W^T with the normalisation folded into the GEMM (every block streams all of x anyway):
+//   prologue  x'[m,k] = bf16(x[m,k] * lnw[k]) feeds the MFMA while sum_k x^2 is accumulated per row; the epilogue scales row m by
+//             rstd[m] = rsqrt(mean x^2 + eps)  (rmsnorm is linear after the row scale, so the GEMM commutes with it)
+//   GLU       the block's two column groups are gate rows n0.. and up rows up_off+n0.. of W; the epilogue writes
+//             silu(gate) * up (Qwen2MLP TF:459-466), so the [M, 2I] intermediate never reaches HBM.
+// Saves the separate rmsnorm / swiglu launches of a decode layer (each ~6-7 us of pure launch + fill/drain at M <= 64 rows).
+// ------------------------------------------------------------------------------------------------------------------
+TR1_DEV float silu_f32(float x) { return x / (1.f + __expf(-x)); }
+TR1_DEV bf16x8_t scale_frag_sumsq(bf16x8_t x, bf16x8_t w, float& ss) {
+    const u32x4_t xu = __builtin_bit_cast(u32x4_t, x), wu = __builtin_bit_cast(u32x4_t, w);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = bflo(xu[e]), b = bfhi(xu[e]);
+        ss = fmaf(a, a, fmaf(b, b, ss));
+        o[e] = pack2bf(a * bflo(wu[e]), b * bfhi(wu[e]));
+    }
+    return __builtin_bit_cast(bf16x8_t, o);
+}
+
+template <int WAVES, int UNROLL, int MG, bool GLU>
+__global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
+                                                                      const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
+                                                                      const bf16_t* __restrict__ bias, int M, int64_t N, int64_t K, int64_t ldx,
+                                                                      int64_t ldw, int64_t ldc, float eps, int64_t up_off) {
+    constexpr int NCOL = 2;
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
+    __shared__ float ssred[WAVES][MG][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * (GLU ? 16 : 32);
+    const bf16_t* wp[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        int64_t wrow = GLU ? n0 + u : n0 + c * 16 + u;
+        if (wrow >= N) wrow = N - 1;
+        if (GLU && c == 1) wrow += up_off;
+        wp[c] = W + wrow * ldw + g * 8;
+    }
+    bool xlive[MG];
+    const bf16_t* xp[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        xlive[mg] = mg * 16 + u < M;
+        xp[mg] = X + (int64_t)(xlive[mg] ? mg * 16 + u : (M - 1)) * ldx + g * 8;
+    }
+    const bf16_t* lp = lnw + g * 8;
+    const int64_t nsteps = K / 64;
+    const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
+    const int64_t s0 = wave * s_per;
+    int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
+    f32x4_t acc[NCOL][MG][2];
+    float ss[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        ss[mg] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    }
+    const bf16x8_t zf = zero_frag8();
+    int64_t s = s0;
+    for (; s + UNROLL <= s1; s += UNROLL) {
+        bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2], la[UNROLL][2];
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            const int64_t k = (s + q) * 64;
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
+                wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
+            }
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                xa[q][mg][0] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf;
+                xa[q][mg][1] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf;
+            }
+            la[q][0] = *reinterpret_cast<const bf16x8_t*>(lp + k);
+            la[q][1] = *reinterpret_cast<const bf16x8_t*>(lp + k + 32);
+        }
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                const bf16x8_t x0 = scale_frag_sumsq(xa[q][mg][0], la[q][0], ss[mg]);
+                const bf16x8_t x1 = scale_frag_sumsq(xa[q][mg][1], la[q][1], ss[mg]);
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) {
+                    acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], x0, acc[c][mg][0], 0, 0, 0);
+                    acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], x1, acc[c][mg][1], 0, 0, 0);
+                }
+            }
+    }
+    for (; s < s1; ++s) {
+        const int64_t k = s * 64;
+        const bf16x8_t l0 = *reinterpret_cast<const bf16x8_t*>(lp + k), l1 = *reinterpret_cast<const bf16x8_t*>(lp + k + 32);
+        bf16x8_t w0[NCOL], w1[NCOL];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            w0[c] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
+            w1[c] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
+        }
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            const bf16x8_t x0 = scale_frag_sumsq(xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf, l0, ss[mg]);
+            const bf16x8_t x1 = scale_frag_sumsq(xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf, l1, ss[mg]);
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[c], x0, acc[c][mg][0], 0, 0, 0);
+                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[c], x1, acc[c][mg][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {     // lanes u, u+16, u+32, u+48 hold disjoint k chunks of row u
+        float v = ss[mg];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) ssred[wave][mg][u] = v;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][0][r] + acc[c][mg][1][r];
+    }
+    __syncthreads();
+    const float inv_k = 1.f / (float)K;
+    for (int i = threadIdx.x; i < (GLU ? 1 : NCOL) * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
+        const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
+        const int m = mg * 16 + mm;
+        const int64_t n = n0 + c * 16 + nn;
+        if (m < M && n < N) {
+            float sq = 0.f, v = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { sq += ssred[w][mg][mm]; v += red[w][c][mg][mm][nn]; if (GLU) v2 += red[w][1][mg][mm][nn]; }
+            const float rstd = rsqrtf(sq * inv_k + eps);
+            v *= rstd;
+            if (GLU) {      // same rounding points as the unfused path: gate/up rounded to bf16, silu rounded, product rounded
+                const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
+                C[(int64_t)m * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
+            } else {
+                if (bias) v += bf2f(bias[n]);
+                C[(int64_t)m * ldc + n] = f2bf(v);
+            }
+        }
+    }
+}
+
+extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                                    int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && K >= BK, "norm_gemm_skinny: K must be a positive multiple of 64");
+    TR1_CHECK_ARG(M >= 1 && M <= 64, "norm_gemm_skinny: 1 <= M <= 64 (decode rows)");
+    TR1_CHECK_ARG(N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0, "norm_gemm_skinny: N%8, ldx%8, ldw%8, ldc%8 required");
+    TR1_CHECK_ARG(!glu || !bias, "norm_gemm_skinny: the GLU form takes no bias");
+    hipStream_t s = (hipStream_t)stream;
+    // N = output columns (glu: the intermediate size I; W then has 2*I rows, gate rows first)
+#define NG(WV, UN, MGR, GL)                                                                                                          \
+    hipLaunchKernelGGL((norm_gemm_skinny_kernel<WV, UN, MGR, GL>), dim3((unsigned)((N + (GL ? 16 : 32) - 1) / (GL ? 16 : 32))),      \
+                       dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W, (bf16_t*)out, (const bf16_t*)bias, \
+                       (int)M, N, K, ldx, ldw, ldc, eps, N)
+    if (glu) { if (M <= 16) NG(4, 4, 1, true); else if (M <= 32) NG(4, 2, 2, true); else NG(4, 2, 4, true); }
+    else     { if (M <= 16) NG(4, 4, 1, false); else if (M <= 32) NG(4, 2, 2, false); else NG(4, 2, 4, false); }
+#undef NG
+    TR1_LAUNCH_CHECK();
+}
+
 // Launch of the decode-regime kernel.  ksplit > 1: C is fp32 [ksplit, M, ldc] partial slabs (no bias / residual).
 static void launch_skinny(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                           int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int ksplit, hipStream_t s) {

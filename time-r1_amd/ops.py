@@ -74,6 +74,16 @@ class HipOps:
                     _ld(residual) if residual is not None else 0, int(out_f32), int(accumulate), self._s())
         return out
 
+    def norm_gemm(self, x, lnw, eps, w, bias=None, glu=False):
+        """Decode rows: rmsnorm(x; lnw) @ w^T (+bias), or with glu=True silu(gate)*up of the [2I, K] weight - one launch."""
+        self._chk(x, lnw, w, bias)
+        M, K = x.shape
+        N = w.shape[0] // 2 if glu else w.shape[0]
+        assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and lnw.numel() == K and M <= 64
+        out = self.empty(M, N)
+        self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), int(glu), self._s())
+        return out
+
     def gemm_skinny_splitk(self, a, b, ksplit):
         """fp32 partial slabs [ksplit, M, N] of a @ b^T (decode rows; summed by rmsnorm_fwd_parts / decode_qkv_post)."""
         self._chk(a, b)

@@ -102,6 +102,7 @@ class Rollout:
         nsplit = max(st["nsplit"] for st in per)
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
         R = B * G
+        fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set
 
         for s in range(C - 1):
             ids_s = tokens_all[:, s].contiguous()
@@ -109,15 +110,21 @@ class Rollout:
             h = ops.gather_rows(arena.w("embed"), ids_s)
             for i in range(t.n_layers):
                 p = "l%d." % i
-                xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
-                qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
+                if fused:      # rmsnorm folded into the projection's operand load (one launch instead of two)
+                    qkv = ops.norm_gemm(h, arena.w(p + "ln1"), t.rms_eps, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
+                else:
+                    xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
+                    qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
                 q = ops.decode_qkv_post(qkv, cs, sn, cache.k[i], cache.vt[i], abs_slots[s], t.n_heads, t.n_kv_heads, hd)
                 # one launch for all prompts of the window: problem b = rows [b*G,(b+1)*G) over cache slots [b*s_cap, (b+1)*s_cap)
                 o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
                                     nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap)
                 h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
-                xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
-                a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
+                if fused:      # rmsnorm -> gate/up projection -> SwiGLU in one launch; the [R, 2I] intermediate never reaches HBM
+                    a = ops.norm_gemm(h2, arena.w(p + "ln2"), t.rms_eps, arena.w(p + "gu.w"), glu=True)
+                else:
+                    xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
+                    a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
                 h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
             hn, _, _ = ops.rmsnorm_fwd(h, arena.w("norm"), t.rms_eps, need_rstd=False)
             logits = ops.gemm_nt(hn, w_lm)

@@ -71,6 +71,30 @@ def splitk():
             print("M=%2d N=%6d K=%6d  " % (M, N, K) + "  ".join(row))
 
 
+def fused():
+    import ctypes
+    print("== decode layer pieces, raw C-ABI calls: us  (unfused rmsnorm + gemm [+ swiglu]  vs  norm_gemm)")
+    L = ops.L
+    for M in (16, 32):
+        for N, K, glu in [(4608, 3584, False), (18944, 3584, True)]:
+            nw = 2 * N if glu else N
+            ws = [rnd(nw, K) for _ in range(max(1, min(8, int(600e6 // (nw * K * 2)))))]
+            x, lnw, bias = rnd(M, K), rnd(K), rnd(N)
+            i = [0]
+
+            def unf():
+                w = ws[i[0] % len(ws)]; i[0] += 1
+                xn, _, _ = ops.rmsnorm_fwd(x, lnw, 1e-6, need_rstd=False)
+                y = ops.gemm_nt(xn, w, bias=None if glu else bias)
+                if glu:
+                    ops.swiglu_fwd(y)
+
+            def fu():
+                w = ws[i[0] % len(ws)]; i[0] += 1
+                ops.norm_gemm(x, lnw, 1e-6, w, bias=None if glu else bias, glu=glu)
+            print("M=%2d N=%6d K=%6d glu=%d   unfused %7.1f   fused %7.1f" % (M, N, K, glu, timeit(unf, reps=60), timeit(fu, reps=60)))
+
+
 def gemm():
     print("== training GEMM: us, TFLOP/s")
     for M, N, K in [(5074, 4608, 3584), (5074, 3584, 3584), (5074, 37888, 3584), (5074, 3584, 18944), (3474, 37888, 3584), (1600, 152064, 3584),
@@ -149,5 +173,5 @@ def sampler():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     for w in what:
-        for name in (["skinny", "splitk", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+        for name in (["skinny", "splitk", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
             globals()[name]()
