@@ -12,7 +12,7 @@
  *   - the library never allocates device memory: workspaces are caller-provided.
  *
  * This header is parsed by time-r1_amd/hip.py to build the ctypes signatures, so keep one declaration per statement and
- * only the types: void*, const void*, char*, int64_t*, int64_t, uint64_t, int, float.
+ * only the types: void*, const void*, char*, int64_t*, const int64_t*, int64_t, uint64_t, int, float.
  */
 #ifndef TIMER1_HIP_H
 #define TIMER1_HIP_H
@@ -104,6 +104,17 @@ int tr1_pack_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
 int tr1_decode_qkv_post(const void* qkv, int64_t ld, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t R, int64_t n_heads, int64_t n_kv, int64_t head_dim, void* stream);
 /* KV-cache append: dst[slots[t], :] = src[t, :] */
 int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const void* slots, int64_t T, int64_t cols, void* stream);
+
+/* ---- native decode-step driver ------------------------------------------------------------------------------------------------ */
+/* One call enqueues a whole rollout decode step for R <= 64 rows: embed gather -> n_layers x {norm+qkv, rope + KV append, split-KV attention,
+ * o_proj + residual, norm + gate/up + SwiGLU, down_proj + residual} -> final norm + lm_head -> logits[R, vocab] (bf16).
+ * ref: per-token body of model.generate (timer1_trainer.py:568-573; Qwen2VLDecoderLayer TF:559-624, norm TF:839, lm_head TF:1323).
+ * layer_ptrs: HOST array of 9 * n_layers DEVICE pointers {ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache [B*s_cap, kv_dim],
+ * V^T cache [kv_dim, B*s_cap]} per layer; dims: HOST int64[11] {n_layers, hidden, n_heads, n_kv, head_dim, intermediate, vocab, rows,
+ * n_batch, s_cap, nsplit}; ids int32[R]; cosb/sinb fp32 [R, head_dim/2]; slots int32[R] (absolute cache slot of each row's new token);
+ * pre/lo/hi int32[R] (two-interval mask, cache-local per batch entry); work: device scratch of tr1_decode_step_workspace_bytes(dims). */
+int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
+int64_t tr1_decode_step_workspace_bytes(const int64_t* dims);
 
 /* ---- video preprocessing (SURVEY 8f "next" row 1) ------------------------------------------------------------------------ */
 /* ref: torchvision resize(BICUBIC, antialias) at src/utils/vision_process.py:467-472 + Qwen2VLVideoProcessor rescale/normalize/patchify

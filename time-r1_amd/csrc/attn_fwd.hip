@@ -1,10 +1,14 @@
 // Attention forward (flash style, online softmax) + split-KV combine + layout helpers. See attn_common.h for the design.
 #include "attn_common.h"
 
-// Block: 256 threads = 4 waves; wave owns 32 packed query rows (two 16-column blocks); block = 128 packed rows.
-// grid = (ceil(T*group/128), n_kv, nsplit).  K / V^T tiles are double-buffered in LDS and staged through registers: the global
-// loads for tile i+2 are issued before tile i+1 is computed (guide: async-STAGE split), one barrier per tile.
-template <int D>
+// Block: 256 threads = 4 waves; wave owns 16*CB packed query rows (CB 16-column blocks); block = 64*CB packed rows.
+// grid = (ceil(T*group/(64*CB)), n_kv, nsplit).  K / V^T tiles are double-buffered in LDS and staged through registers: the global
+// loads for tile i+1+PF are issued before tile i+1 is computed (guide: async-STAGE split), one barrier per tile.
+//   CB = 2, PF = 1: training / prefill (MFMA-bound, 256 VGPRs at D = 128).
+//   CB = 1, PF = 3: split-KV decode.  A decode block sees only 2-3 tiles, so its time is a chain of memory latencies: with PF = 3
+//                   register sets all of its tiles are in flight at once (one latency instead of three), and 16 rows per wave keep
+//                   all four waves busy for the 56 packed rows of G = 8 x group 7.
+template <int D, int CB, int PF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int KSTR = 2 * D + 16;
     {   // batched launch (decode over several prompts' caches): blockIdx.y = b * n_kv + kvh
@@ -20,12 +24,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y % p.n_kv, split = blockIdx.z;
     const int64_t nR = (int64_t)p.T * p.group;
-    const int64_t R0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t R0 = (int64_t)blockIdx.x * (64 * CB) + wave * (16 * CB);
 
-    int tq[2], hq[2], pre[2], lo[2], hi[2]; bool valid[2];
+    int tq[CB], hq[CB], pre[CB], lo[CB], hi[CB]; bool valid[CB];
     int wmaxpre = 0, wminlo = 0x7fffffff, wmaxhi = -1;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
         const int64_t R = R0 + cb * 16 + u;
         valid[cb] = R < nR;
         const int64_t Rc = valid[cb] ? R : nR - 1;
@@ -49,56 +53,68 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const bool wave_active = __builtin_amdgcn_readfirstlane((int)(R0 < nR)) != 0;
 
     // Q fragments (B operand): Q[q = u][d = ks*32 + g*8 .. +8]
-    bf16x8_t qf[2][D / 32];
+    bf16x8_t qf[CB][D / 32];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
         const bf16_t* qrow = p.Q + (int64_t)tq[cb] * p.q_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
 #pragma unroll
         for (int ks = 0; ks < D / 32; ++ks) qf[cb][ks] = load_row_frag(qrow, ks * 32 + g * 8, p.d_real, valid[cb]);
     }
 
-    f32x4_t o[D / 16][2];
+    f32x4_t o[D / 16][CB];
+    float m[CB], l[CB];
 #pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt) { o[dt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; o[dt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-    float m[2] = {NEG_INF, NEG_INF}, l[2] = {0.f, 0.f};
+    for (int cb = 0; cb < CB; ++cb) {
+        m[cb] = NEG_INF; l[cb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) o[dt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int n_my = (split < tr.n_rel) ? (tr.n_rel - split + p.nsplit - 1) / p.nsplit : 0;
-    TileRegs<D> regs;
+    TileRegs<D> rg[PF];
+#define TILE_KV0(i) ((int64_t)att_tile_at(tr, split + (i) * p.nsplit) * ATT_KV)
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (j < n_my) tile_load_regs<D>(rg[j], p.K, p.k_ld, p.VT, p.vt_ld, kvh, TILE_KV0(j), p.n_slots, p.d_real);
     if (n_my > 0) {
-        tile_load_regs<D>(regs, p.K, p.k_ld, p.VT, p.vt_ld, kvh, (int64_t)att_tile_at(tr, split) * ATT_KV, p.n_slots, p.d_real);
-        tile_store_lds<D>(regs, dyn_lds, dyn_lds + KBYTES, (int64_t)att_tile_at(tr, split) * ATT_KV, p.n_slots, p.d_real);
-        if (n_my > 1)
-            tile_load_regs<D>(regs, p.K, p.k_ld, p.VT, p.vt_ld, kvh, (int64_t)att_tile_at(tr, split + p.nsplit) * ATT_KV, p.n_slots, p.d_real);
+        tile_store_lds<D>(rg[0], dyn_lds, dyn_lds + KBYTES, TILE_KV0(0), p.n_slots, p.d_real);
+        if (PF < n_my) tile_load_regs<D>(rg[0], p.K, p.k_ld, p.VT, p.vt_ld, kvh, TILE_KV0(PF), p.n_slots, p.d_real);
     }
     __syncthreads();
 
-    for (int it = 0; it < n_my; ++it) {
+    for (int it0 = 0; it0 < n_my; it0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int it = it0 + j;
+        if (it >= n_my) break;
         const int kv0 = att_tile_at(tr, split + it * p.nsplit) * ATT_KV;
         const char* lds_k = dyn_lds + (it & 1) * BUF;
         const char* lds_vt = lds_k + KBYTES;
         if (wave_active) {
-            f32x4_t s[4][2];
+            f32x4_t s[4][CB];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) { s[kt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; s[kt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) s[kt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < D / 32; ++ks) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lds_k + (kt * 16 + u) * KSTR + (ks * 4 + g) * 16);
-                    s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
-                    s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) s[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[cb][ks], s[kt][cb], 0, 0, 0);
                 }
             }
-            bf16x8_t pf[2][2];
+            bf16x8_t pf[2][CB];
             // Tiles that every row of this wave sees completely (all shared-prefix tiles of completion rows, everything below the
             // diagonal of prompt rows) skip the per-element visibility test - a wave-uniform branch.
             bool full = kv0 + ATT_KV <= p.n_slots;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < CB; ++cb)
                 full = full && (!valid[cb] || (kv0 + ATT_KV - 1 < pre[cb]) || (kv0 >= lo[cb] && kv0 + ATT_KV - 1 <= hi[cb]));
             const bool wave_full = __all(full);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < CB; ++cb) {
                 float mx = NEG_INF;
                 // max over RAW scores (scale > 0 commutes with max); the scale is folded into the exp2 argument as one fma
                 if (wave_full) {
@@ -144,24 +160,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 for (int kk = 0; kk < 2; ++kk) {
                     const char* base = lds_vt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
                     const bf16x8_t vf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
-                    o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][0], o[dt][0], 0, 0, 0);
-                    o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][1], o[dt][1], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) o[dt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk][cb], o[dt][cb], 0, 0, 0);
                 }
             }
         }
         if (it + 1 < n_my) {
             char* nk = dyn_lds + ((it + 1) & 1) * BUF;
-            tile_store_lds<D>(regs, nk, nk + KBYTES, (int64_t)att_tile_at(tr, split + (it + 1) * p.nsplit) * ATT_KV, p.n_slots, p.d_real);
-            if (it + 2 < n_my)
-                tile_load_regs<D>(regs, p.K, p.k_ld, p.VT, p.vt_ld, kvh, (int64_t)att_tile_at(tr, split + (it + 2) * p.nsplit) * ATT_KV, p.n_slots, p.d_real);
+            tile_store_lds<D>(rg[(j + 1) % PF], nk, nk + KBYTES, TILE_KV0(it + 1), p.n_slots, p.d_real);
+            if (it + 1 + PF < n_my)
+                tile_load_regs<D>(rg[(j + 1) % PF], p.K, p.k_ld, p.VT, p.vt_ld, kvh, TILE_KV0(it + 1 + PF), p.n_slots, p.d_real);
         }
         __syncthreads();
     }
+    }
+#undef TILE_KV0
 
     // ---- epilogue. Lane holds O^T[d = dt*16 + g*4 + r][q = u].
     if (p.nsplit == 1) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < CB; ++cb) {
             if (!valid[cb]) continue;
             const float inv = l[cb] > 0.f ? 1.f / l[cb] : 0.f;
             bf16_t* orow = p.O + (int64_t)tq[cb] * p.o_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
@@ -177,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 p.lse[(int64_t)(kvh * p.group + hq[cb]) * p.T + tq[cb]] = l[cb] > 0.f ? (m[cb] + log2f(l[cb])) * 0.6931471805599453f : NEG_INF;
         }
     } else {
-        const int64_t nRpad = (int64_t)gridDim.x * 128;
+        const int64_t nRpad = (int64_t)gridDim.x * (64 * CB);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < CB; ++cb) {
             if (!valid[cb]) continue;
             const int64_t R = R0 + cb * 16 + u;
             const int64_t slot = ((int64_t)split * gridDim.y + blockIdx.y) * nRpad + R;
@@ -283,15 +301,15 @@ __global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_
     }
 }
 
-template <int D>
+template <int D, int CB, int PF>
 static void launch_fwd(dim3 grid, hipStream_t s, const AttnParams& p) {
     const size_t dyn = 2 * (ATT_KV * (2 * D + 16) + D * 144) + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, CB, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), dyn, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, CB, PF>), grid, dim3(256), dyn, s, p);
 }
 
 static int attn_check(const AttnParams& p, int d_pad) {
@@ -319,8 +337,10 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     TR1_CHECK_ARG(vt_ld % 8 == 0 && vt_ld >= n_slots, "attention: vt_ld must be a multiple of 8 and >= n_slots");
     if (T == 0) return 0;
     const int64_t nR = T * p.group;
-    const int qtiles = (int)((nR + 127) / 128);
-    const int64_t nRpad = (int64_t)qtiles * 128;
+    const bool decode = nsplit > 1;                 // split-KV: 64-row query tiles, 3 tiles in flight per block
+    const int qrows = decode ? 64 : 128;
+    const int qtiles = (int)((nR + qrows - 1) / qrows);
+    const int64_t nRpad = (int64_t)qtiles * qrows;
     if (nsplit > 1) {
         const int64_t need = nsplit * n_batch * n_kv * nRpad * (d_pad + 2);
         TR1_CHECK_ARG(ws_f32 && ws_floats >= need, "attention: split-KV workspace too small");
@@ -328,11 +348,20 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     }
     dim3 grid(qtiles, (unsigned)(n_kv * n_batch), (unsigned)nsplit);
     hipStream_t s = (hipStream_t)stream;
-    switch (d_pad) {
-        case 32: launch_fwd<32>(grid, s, p); break;
-        case 64: launch_fwd<64>(grid, s, p); break;
-        case 96: launch_fwd<96>(grid, s, p); break;
-        default: launch_fwd<128>(grid, s, p); break;
+    if (decode) {
+        switch (d_pad) {
+            case 32: launch_fwd<32, 1, 3>(grid, s, p); break;
+            case 64: launch_fwd<64, 1, 3>(grid, s, p); break;
+            case 96: launch_fwd<96, 1, 3>(grid, s, p); break;
+            default: launch_fwd<128, 1, 3>(grid, s, p); break;
+        }
+    } else {
+        switch (d_pad) {
+            case 32: launch_fwd<32, 2, 1>(grid, s, p); break;
+            case 64: launch_fwd<64, 2, 1>(grid, s, p); break;
+            case 96: launch_fwd<96, 2, 1>(grid, s, p); break;
+            default: launch_fwd<128, 2, 1>(grid, s, p); break;
+        }
     }
     if (nsplit > 1) {
         dim3 cg((unsigned)((nR + 7) / 8), (unsigned)(n_kv * n_batch));

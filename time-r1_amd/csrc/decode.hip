@@ -1,0 +1,66 @@
+// Native decode-step driver: one C call enqueues every kernel of a rollout decode step (28 layers x 7 launches + head) on the stream.
+//
+// Why: at M <= 64 rows a decode layer is ~150 us of GPU work in 7 launches; driven op by op from the host language each launch costs
+// ~20 us of interpreter + binding time, so the host cannot stay ahead of the GPU and every kernel starts after an idle gap
+// (measured with tools/rocpd_gaps.py: 2-4 us in front of each GEMM, 16 us per layer).  Launched back to back from native code the
+// gaps are < 0.5 us and the host spends ~0.5 ms per step instead of ~4 ms.
+//
+// Reference: the per-token body of `model.generate` (transformers GenerationMixin sampling loop, called from
+// src/time_r1/rl/timer1_trainer.py:568-573): Qwen2VLDecoderLayer.forward TF:559-624 x n_layers, final norm TF:839, lm_head TF:1323.
+#include "tr1_common.h"
+#include "../../include/timer1_hip.h"
+
+namespace {
+struct Carve {
+    char* p; size_t left; bool ok = true;
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > left) { ok = false; return nullptr; }
+        void* r = p; p += bytes; left -= bytes; return r;
+    }
+};
+enum { D_LAYERS, D_HIDDEN, D_HEADS, D_KV, D_HEAD_DIM, D_INTER, D_VOCAB, D_ROWS, D_BATCH, D_SCAP, D_NSPLIT, D_N };
+}  // namespace
+
+static int64_t decode_ws_bytes(const int64_t* d) {
+    const int64_t R = d[D_ROWS], hid = d[D_HIDDEN], qd = d[D_HEADS] * d[D_HEAD_DIM], kvd = d[D_KV] * d[D_HEAD_DIM];
+    const int64_t T = R / d[D_BATCH];
+    const int64_t att = d[D_BATCH] * tr1_attn_fwd_workspace_floats(T, d[D_HEADS], d[D_KV], d[D_HEAD_DIM], d[D_NSPLIT]);
+    auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + 4096;
+}
+
+extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
+
+extern "C" int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head,
+                               const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo,
+                               const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream) {
+    const int64_t L = dims[D_LAYERS], hid = dims[D_HIDDEN], nh = dims[D_HEADS], nkv = dims[D_KV], hd = dims[D_HEAD_DIM], inter = dims[D_INTER];
+    const int64_t V = dims[D_VOCAB], R = dims[D_ROWS], B = dims[D_BATCH], scap = dims[D_SCAP], nsplit = dims[D_NSPLIT];
+    TR1_CHECK_ARG(R >= 1 && R <= 64 && B >= 1 && R % B == 0, "decode_step: 1 <= rows <= 64, rows % n_batch == 0");
+    TR1_CHECK_ARG(layer_ptrs && dims && work && logits, "decode_step: null argument");
+    const int64_t qd = nh * hd, kvd = nkv * hd, qkvd = qd + 2 * kvd, T = R / B;
+    const int64_t att_floats = B * tr1_attn_fwd_workspace_floats(T, nh, nkv, hd, nsplit);
+    Carve c{(char*)work, (size_t)work_bytes};
+    void* hA = c.take(R * hid * 2); void* hB = c.take(R * hid * 2);
+    void* qkv = c.take(R * qkvd * 2); void* q = c.take(R * qd * 2); void* o = c.take(R * qd * 2);
+    void* a = c.take(R * inter * 2); void* att = c.take(att_floats * 4);
+    TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");
+    const void* const* lp = (const void* const*)layer_ptrs;    // per layer: ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache, V^T cache
+#define CK(call) do { int e__ = (call); if (e__) return e__; } while (0)
+    CK(tr1_gather_rows(embed, ids, hA, R, hid, stream));
+    void* h = hA; void* h2 = hB;
+    for (int64_t i = 0; i < L; ++i) {
+        const void* const* w = lp + i * 9;
+        CK(tr1_norm_gemm_skinny(h, w[0], w[1], w[2], qkv, R, qkvd, hid, hid, hid, qkvd, eps, 0, stream));
+        CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
+        CK(tr1_attn_fwd(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
+                        scap, stream));
+        CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
+        CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
+        CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
+    }
+    CK(tr1_norm_gemm_skinny(h, final_norm, lm_head, nullptr, logits, R, V, hid, hid, hid, V, eps, 0, stream));
+#undef CK
+    return 0;
+}

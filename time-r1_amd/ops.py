@@ -84,6 +84,29 @@ class HipOps:
         self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), int(glu), self._s())
         return out
 
+    # ---- native decode-step driver ------------------------------------------------------------------------------------
+    def decode_plan(self, layers, hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit):
+        """layers: per decoder layer the 9 tensors (ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache, V^T cache).  Builds the host
+        pointer table + device scratch once per rollout; decode_step then costs one C call per generated token."""
+        import ctypes
+        flat = [t for L in layers for t in L]
+        assert len(flat) == 9 * len(layers)
+        self._chk(*flat)
+        ptrs = (ctypes.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
+        dims = (ctypes.c_int64 * 11)(len(layers), hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit)
+        nbytes = int(self.L.raw("tr1_decode_step_workspace_bytes")(dims))
+        work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        logits = self.empty(rows, vocab)
+        return dict(ptrs=ptrs, ptrs_p=ctypes.cast(ptrs, ctypes.c_void_p), dims=dims, work=work, work_p=work.data_ptr(), nbytes=nbytes,
+                    logits=logits, logits_p=logits.data_ptr(), keep=flat, stream=self._s())
+
+    def decode_step(self, plan, embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p, eps, scale):
+        """All arguments after `plan` are raw device addresses (ints): the caller precomputes row pointers into its step tables.
+        Returns plan["logits"] [rows, vocab] (overwritten every step)."""
+        self.L.call("tr1_decode_step", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p,
+                    plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
+        return plan["logits"]
+
     def gemm_skinny_splitk(self, a, b, ksplit):
         """fp32 partial slabs [ksplit, M, N] of a @ b^T (decode rows; summed by rmsnorm_fwd_parts / decode_qkv_post)."""
         self._chk(a, b)

@@ -36,6 +36,7 @@ class Rollout:
         self.temperature, self.top_k, self.seed, self.stop_at_eos = float(temperature), int(top_k or 0), int(seed), bool(stop_at_eos)
         self._cache = None
         self.calls = 0
+        self.native_decode = True     # one native call per decode step (HipOps); False = op-by-op from the host (tests compare the two)
 
     def _kv(self, B, s_cap):
         t = self.eng.cfg.text
@@ -103,8 +104,26 @@ class Rollout:
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
         R = B * G
         fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set
+        native = fused and self.native_decode and hasattr(ops, "decode_step")
+        if native:
+            # whole decode step enqueued by ONE native call (csrc/decode.hip): the host stays ahead of the GPU, no idle gaps between kernels
+            plan = ops.decode_plan([[arena.w("l%d.%s" % (i, n)) for n in ("ln1", "qkv.w", "qkv.b", "o.w", "ln2", "gu.w", "down.w")] + [cache.k[i], cache.vt[i]]
+                                    for i in range(t.n_layers)], t.hidden, t.n_heads, t.n_kv_heads, hd, t.intermediate, t.vocab_size, R, B, cache.s_cap, nsplit)
+            embed_p, norm_p, lm_p = arena.w("embed").data_ptr(), arena.w("norm").data_ptr(), w_lm.data_ptr()
+            cos_p, sin_p, slot_p, hi_p = cos_all.data_ptr(), sin_all.data_ptr(), abs_slots.data_ptr(), hi_all.data_ptr()
+            pre_p, lo_p = pre_all.data_ptr(), lo_all.data_ptr()
+            ids_buf = ops.zeros(R, dtype=I32)
+            ids_p = ids_buf.data_ptr()
 
         for s in range(C - 1):
+            if native:
+                ids_buf.copy_(tokens_all[:, s])
+                logits = ops.decode_step(plan, embed_p, norm_p, lm_p, ids_p, cos_p + s * R * half * 4, sin_p + s * R * half * 4, slot_p + s * R * 4,
+                                         pre_p, lo_p, hi_p + s * R * 4, t.rms_eps, scale)
+                for b, st in enumerate(per):
+                    ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
+                                      st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+                continue
             ids_s = tokens_all[:, s].contiguous()
             cs, sn = cos_all[s], sin_all[s]
             h = ops.gather_rows(arena.w("embed"), ids_s)
@@ -126,8 +145,11 @@ class Rollout:
                     xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
                     a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
                 h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
-            hn, _, _ = ops.rmsnorm_fwd(h, arena.w("norm"), t.rms_eps, need_rstd=False)
-            logits = ops.gemm_nt(hn, w_lm)
+            if fused:
+                logits = ops.norm_gemm(h, arena.w("norm"), t.rms_eps, w_lm)
+            else:
+                hn, _, _ = ops.rmsnorm_fwd(h, arena.w("norm"), t.rms_eps, need_rstd=False)
+                logits = ops.gemm_nt(hn, w_lm)
             for b, st in enumerate(per):
                 ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
                                   st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)

@@ -119,7 +119,7 @@ def attn_decode():
     pre = torch.full((G,), P, dtype=torch.int32, device="cuda")
     lo = (P + torch.arange(G) * C).int().cuda()
     hi = (lo + step).int()
-    for ns in (1, 2, 4, 8, 14, 28, 57):
+    for ns in [int(x) for x in os.environ.get('TR1_MB_NSPLIT', '1,2,4,8,14,28,57').split(',')]:
         us = timeit(lambda: ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=ns, need_lse=False), reps=100)
         print("nsplit=%2d  %7.1f us" % (ns, us))
 
