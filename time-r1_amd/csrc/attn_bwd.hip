@@ -222,8 +222,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #define DKDV_MAXT 1024
 struct RowMeta { float lse, dlt; int pre, lo, hi; };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles, float* __restrict__ part_k, float* __restrict__ part_v) {
+// NW waves per block, each owning 16 keys (block = 16*NW keys) and sharing the staged 64-query tile.  NW = 8 (D = 64 / 128): the tile is
+// filled by 512 threads, so one staging set is 32 VGPRs and TWO sets fit (two query tiles in flight), the global->LDS traffic per key
+// halves, and the block - alone on its CU with 146 KB of LDS - keeps 8 waves of MFMA work per staged tile instead of 4.
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles, float* __restrict__ part_k, float* __restrict__ part_v) {
+    constexpr int NT = NW * 64, KB = NW * 16;
     constexpr int KSTR = 2 * D + 16;
     constexpr int RB = 64 * KSTR, TB = D * 144, BUF = 2 * RB + 2 * TB + 64 * 5 * 4;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][Q rows | dO rows | Q^T | dO^T | row meta] + tile list
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y, qz = blockIdx.z, QS = gridDim.z;
-    const int kvb0 = blockIdx.x * ATT_KV;
+    const int kvb0 = blockIdx.x * KB;
     const int kv = kvb0 + wave * 16 + u;
     const bool kv_ok = kv < p.n_slots;
     const int64_t nR = (int64_t)p.T * p.group;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
             bool rel = false;
             if (c < n_cand) {
                 const int mp = p.qmeta[qi * 3], ml = p.qmeta[qi * 3 + 1], mh = p.qmeta[qi * 3 + 2];
-                rel = (kvb0 < mp) || (kvb0 + ATT_KV - 1 >= ml && kvb0 <= mh);
+                rel = (kvb0 < mp) || (kvb0 + KB - 1 >= ml && kvb0 <= mh);
             }
             const unsigned long long mask = __ballot(rel);
             if (rel) lds_tiles[count + __popcll(mask & ((1ull << lane) - 1ull))] = qi;
@@ -269,47 +273,58 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
     __syncthreads();
     const int n_my = lds_tiles[DKDV_MAXT];
 
-    TReg<D> rq, rdo, rqt, rdot;
-    RowMeta rm = {INFINITY, 0.f, 0, 1, 0};
-    auto load_tile = [&](int qi) {
+    // PF register sets: the global loads of PF query tiles are in flight while one is computed.  The block is alone on its CU (146 KB
+    // of LDS), so with one set each iteration is an exposed L2/HBM round trip (measured: 2.7 ms per call, 7B config 3, NW = 4).
+    constexpr int PF = 1;     // a second staging set does not fit: the 8-wave form runs 2 waves/SIMD = 256 VGPRs each (compiler spills at PF = 2)
+    struct QTileRegs { TReg<D, NT> rq, rdo, rqt, rdot; RowMeta rm; };
+    QTileRegs rg[PF];
+    auto load_tile = [&](QTileRegs& r, int qi) {
         const int64_t Rq0 = (int64_t)qi * 64;
-        prows_load<D>(rq, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
-        prows_load<D>(rdo, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
-        T_load<D>(rqt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
-        T_load<D>(rdot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
+        prows_load<D, NT>(r.rq, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
+        prows_load<D, NT>(r.rdo, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
+        T_load<D, NT>(r.rqt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
+        T_load<D, NT>(r.rdot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
         if (threadIdx.x < 64) {
             const int64_t R = Rq0 + threadIdx.x;
-            rm = RowMeta{INFINITY, 0.f, 0, 1, 0};
+            r.rm = RowMeta{INFINITY, 0.f, 0, 1, 0};
             if (R < nR) {
                 const int t = (int)(R / p.group), hq = (int)(R - (int64_t)t * p.group);
                 const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + t;
                 const float l0 = p.lse[si];
-                rm.lse = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
-                rm.dlt = p.delta[si]; rm.pre = p.pre[t]; rm.lo = p.lo[t]; rm.hi = p.hi[t];
+                r.rm.lse = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
+                r.rm.dlt = p.delta[si]; r.rm.pre = p.pre[t]; r.rm.lo = p.lo[t]; r.rm.hi = p.hi[t];
             }
         }
     };
-    auto store_tile = [&](int qi, char* buf) {
+    auto store_tile = [&](const QTileRegs& r, int qi, char* buf) {
         const int64_t Rq0 = (int64_t)qi * 64;
-        rows_store<D>(rq, buf, Rq0, nR, p.d_real);
-        rows_store<D>(rdo, buf + RB, Rq0, nR, p.d_real);
-        T_store<D>(rqt, buf + 2 * RB, Rq0, nR, p.d_real);
-        T_store<D>(rdot, buf + 2 * RB + TB, Rq0, nR, p.d_real);
+        rows_store<D, NT>(r.rq, buf, Rq0, nR, p.d_real);
+        rows_store<D, NT>(r.rdo, buf + RB, Rq0, nR, p.d_real);
+        T_store<D, NT>(r.rqt, buf + 2 * RB, Rq0, nR, p.d_real);
+        T_store<D, NT>(r.rdot, buf + 2 * RB + TB, Rq0, nR, p.d_real);
         if (threadIdx.x < 64) {
             float* mf = reinterpret_cast<float*>(buf + 2 * RB + 2 * TB);
             int* mi = reinterpret_cast<int*>(mf + 128);
-            mf[threadIdx.x] = rm.lse; mf[64 + threadIdx.x] = rm.dlt;
-            mi[threadIdx.x] = rm.pre; mi[64 + threadIdx.x] = rm.lo; mi[128 + threadIdx.x] = rm.hi;
+            mf[threadIdx.x] = r.rm.lse; mf[64 + threadIdx.x] = r.rm.dlt;
+            mi[threadIdx.x] = r.rm.pre; mi[64 + threadIdx.x] = r.rm.lo; mi[128 + threadIdx.x] = r.rm.hi;
         }
     };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        rg[j].rm = RowMeta{INFINITY, 0.f, 0, 1, 0};
+        if (j < n_my) load_tile(rg[j], lds_tiles[j]);
+    }
     if (n_my > 0) {
-        load_tile(lds_tiles[0]);
-        store_tile(lds_tiles[0], dyn_lds);
-        if (n_my > 1) load_tile(lds_tiles[1]);
+        store_tile(rg[0], lds_tiles[0], dyn_lds);
+        if (PF < n_my) load_tile(rg[0], lds_tiles[PF]);
     }
     __syncthreads();
 
-    for (int it = 0; it < n_my; ++it) {
+    for (int it0 = 0; it0 < n_my; it0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int it = it0 + j;
+        if (it >= n_my) break;
         const char* buf = dyn_lds + (it & 1) * BUF;
         const char* lds_q = buf;
         const char* lds_do = buf + RB;
@@ -366,10 +381,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p, int n_
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
         }
         if (it + 1 < n_my) {
-            store_tile(lds_tiles[it + 1], dyn_lds + ((it + 1) & 1) * BUF);
-            if (it + 2 < n_my) load_tile(lds_tiles[it + 2]);
+            store_tile(rg[(j + 1) % PF], lds_tiles[it + 1], dyn_lds + ((it + 1) & 1) * BUF);
+            if (it + 1 + PF < n_my) load_tile(rg[(j + 1) % PF], lds_tiles[it + 1 + PF]);
         }
         __syncthreads();
+    }
     }
     // lane holds dK^T/dV^T[d = dt*16 + g*4 + r][kv]
     if (kv_ok) {
@@ -419,9 +435,11 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const f
     }
 }
 
-static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots) {
+static int dkdv_keys_per_block(int d_pad) { return (d_pad == 64 || d_pad == 128) ? 128 : 64; }   // 8-wave blocks where 8*D/512 is integral
+
+static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) {
     const int64_t n_qtiles = (T * group + 63) / 64;
-    const int64_t kvblocks = ((n_slots + ATT_KV - 1) / ATT_KV) * n_kv;
+    const int64_t kvblocks = ((n_slots + kb - 1) / kb) * n_kv;
     int64_t qs = (1024 + kvblocks - 1) / kvblocks;
     if (qs > 8) qs = 8;
     if (qs > n_qtiles) qs = n_qtiles;
@@ -435,16 +453,18 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     const int64_t nR = (int64_t)p.T * p.group;
     const int n_qtiles = (int)((nR + 63) / 64);
     constexpr int KSTR = 2 * D + 16;
+    constexpr int NW = (D == 64 || D == 128) ? 8 : 4;
+    constexpr int KB = NW * 16;
     const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR + D * 144) + 64;
     const size_t dyn_kv = 2 * (2 * 64 * KSTR + 2 * D * 144 + 64 * 5 * 4) + (DKDV_MAXT + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
-    const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots);
+    const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots, KB);
     const int64_t kvd = (int64_t)p.n_kv * p.d_real;
     float *pk = nullptr, *pv = nullptr;
     if (QS > 1) {
@@ -452,7 +472,7 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
         pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
     }
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<D>, dim3((unsigned)((p.n_slots + ATT_KV - 1) / ATT_KV), p.n_kv, QS), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)((p.n_slots + KB - 1) / KB), p.n_kv, QS), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
     if (QS > 1) {
         const float scale = p.scale_log2 * 0.6931471805599453f;
         hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(tr1_grid_1d(p.n_slots * kvd / 4, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
@@ -463,7 +483,7 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
 
 extern "C" int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim) {
     if (n_kv <= 0 || T <= 0) return 0;
-    const int QS = dkdv_qsplit(T, (int)(n_heads / n_kv), (int)n_kv, n_slots);
+    const int QS = dkdv_qsplit(T, (int)(n_heads / n_kv), (int)n_kv, n_slots, dkdv_keys_per_block((int)((head_dim + 31) / 32 * 32)));
     return QS > 1 ? 2 * (int64_t)QS * n_slots * n_kv * head_dim : 0;
 }
 

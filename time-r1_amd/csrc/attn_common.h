@@ -167,16 +167,17 @@ TR1_DEV void tile_store_lds(const TileRegs<D>& r, char* lds_k, char* lds_vt, int
 }
 
 // ---- generic single-tile versions of the split staging (used by the backward kernels) -------------------------------------
-template <int D>
-struct TReg { u32x4_t v[D / 32]; };
+// NT = threads of the block (256 or 512); a 64 x D tile is 8*D 16-byte chunks, 8*D/NT per thread.
+template <int D, int NT = 256>
+struct TReg { u32x4_t v[8 * D / NT]; };
 
 // row-major rows [row0, row0+64) x D of src (leading dim ld, column offset col0); clamped addresses, masks applied at store time
-template <int D>
-TR1_DEV void rows_load(TReg<D>& r, const bf16_t* src, int64_t ld, int64_t col0, int64_t row0, int64_t nvalid, int d_real) {
+template <int D, int NT = 256>
+TR1_DEV void rows_load(TReg<D, NT>& r, const bf16_t* src, int64_t ld, int64_t col0, int64_t row0, int64_t nvalid, int d_real) {
     constexpr int CH = D / 8;
 #pragma unroll
-    for (int j = 0; j < D / 32; ++j) {
-        const int idx = threadIdx.x + j * 256;
+    for (int j = 0; j < 8 * D / NT; ++j) {
+        const int idx = threadIdx.x + j * NT;
         const int row = idx / CH, c = idx - row * CH;
         int64_t rr = row0 + row; if (rr > nvalid - 1) rr = nvalid - 1;
         const int cc = (c * 8 < d_real) ? c * 8 : 0;
@@ -184,12 +185,12 @@ TR1_DEV void rows_load(TReg<D>& r, const bf16_t* src, int64_t ld, int64_t col0, 
     }
 }
 // GQA-packed query rows R = R0 + row -> token R/group, head kvh*group + R%group
-template <int D>
-TR1_DEV void prows_load(TReg<D>& r, const bf16_t* src, int64_t ld, int kvh, int group, int64_t R0, int64_t nR, int d_real) {
+template <int D, int NT = 256>
+TR1_DEV void prows_load(TReg<D, NT>& r, const bf16_t* src, int64_t ld, int kvh, int group, int64_t R0, int64_t nR, int d_real) {
     constexpr int CH = D / 8;
 #pragma unroll
-    for (int j = 0; j < D / 32; ++j) {
-        const int idx = threadIdx.x + j * 256;
+    for (int j = 0; j < 8 * D / NT; ++j) {
+        const int idx = threadIdx.x + j * NT;
         const int row = idx / CH, c = idx - row * CH;
         int64_t R = R0 + row; if (R > nR - 1) R = nR - 1;
         const int64_t t = R / group; const int hq = (int)(R - t * group);
@@ -197,36 +198,36 @@ TR1_DEV void prows_load(TReg<D>& r, const bf16_t* src, int64_t ld, int kvh, int 
         r.v[j] = *reinterpret_cast<const u32x4_t*>(src + t * ld + (int64_t)(kvh * group + hq) * d_real + cc);
     }
 }
-template <int D>
-TR1_DEV void rows_store(const TReg<D>& r, char* lds, int64_t row0, int64_t nvalid, int d_real) {
+template <int D, int NT = 256>
+TR1_DEV void rows_store(const TReg<D, NT>& r, char* lds, int64_t row0, int64_t nvalid, int d_real) {
     constexpr int CH = D / 8;
     constexpr int STRIDE = 2 * D + 16;
     const u32x4_t zero = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < D / 32; ++j) {
-        const int idx = threadIdx.x + j * 256;
+    for (int j = 0; j < 8 * D / NT; ++j) {
+        const int idx = threadIdx.x + j * NT;
         const int row = idx / CH, c = idx - row * CH;
         const bool ok = (row0 + row < nvalid) && (c * 8 < d_real);
         *reinterpret_cast<u32x4_t*>(lds + row * STRIDE + c * 16) = ok ? r.v[j] : zero;
     }
 }
 // transposed source [n_kv*d_real, ldT], columns [col0, col0+64)
-template <int D>
-TR1_DEV void T_load(TReg<D>& r, const bf16_t* srcT, int64_t ldT, int kvh, int64_t col0, int64_t nvalid, int d_real) {
+template <int D, int NT = 256>
+TR1_DEV void T_load(TReg<D, NT>& r, const bf16_t* srcT, int64_t ldT, int kvh, int64_t col0, int64_t nvalid, int d_real) {
     const int64_t last_chunk = ((nvalid - 1) >> 3) << 3;
 #pragma unroll
-    for (int j = 0; j < D / 32; ++j) {
-        const int idx = threadIdx.x + j * 256;
+    for (int j = 0; j < 8 * D / NT; ++j) {
+        const int idx = threadIdx.x + j * NT;
         int d = idx >> 3; if (d >= d_real) d = d_real - 1;
         int64_t col = col0 + (idx & 7) * 8; if (col > last_chunk) col = last_chunk;
         r.v[j] = *reinterpret_cast<const u32x4_t*>(srcT + ((int64_t)kvh * d_real + d) * ldT + col);
     }
 }
-template <int D>
-TR1_DEV void T_store(const TReg<D>& r, char* lds, int64_t col0, int64_t nvalid, int d_real) {
+template <int D, int NT = 256>
+TR1_DEV void T_store(const TReg<D, NT>& r, char* lds, int64_t col0, int64_t nvalid, int d_real) {
 #pragma unroll
-    for (int j = 0; j < D / 32; ++j) {
-        const int idx = threadIdx.x + j * 256;
+    for (int j = 0; j < 8 * D / NT; ++j) {
+        const int idx = threadIdx.x + j * NT;
         const int d = idx >> 3, c2 = idx & 7;
         const int64_t col = col0 + c2 * 8;
         u32x4_t v = r.v[j];
