@@ -41,6 +41,11 @@ int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_f32, int64_
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
  * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */
 int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream);
+/* Narrow decode projections (o_proj / down_proj at M <= 64 rows): C = A B^T (+bias)(+residual) with cross-block split-K and an in-kernel
+ * fixup (the last block of a column group sums the fp32 partial tiles).  ws_f32: tr1_gemm_skinny_fixup_workspace_floats() floats whose
+ * trailing ticket counters must be ZERO before the first call (the kernel re-arms them).  Same call sites as tr1_gemm_nt_bf16 in generate. */
+int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream);
+int64_t tr1_gemm_skinny_fixup_workspace_floats(int64_t M, int64_t N, int64_t K);
 /* out[c, r] = in[r, c]; columns [R, ld_out) of out are zero-filled (feeds the NT GEMM for dgrad / wgrad). */
 int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* stream);
 
@@ -112,7 +117,8 @@ int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst
  * layer_ptrs: HOST array of 9 * n_layers DEVICE pointers {ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache [B*s_cap, kv_dim],
  * V^T cache [kv_dim, B*s_cap]} per layer; dims: HOST int64[11] {n_layers, hidden, n_heads, n_kv, head_dim, intermediate, vocab, rows,
  * n_batch, s_cap, nsplit}; ids int32[R]; cosb/sinb fp32 [R, head_dim/2]; slots int32[R] (absolute cache slot of each row's new token);
- * pre/lo/hi int32[R] (two-interval mask, cache-local per batch entry); work: device scratch of tr1_decode_step_workspace_bytes(dims). */
+ * pre/lo/hi int32[R] (two-interval mask, cache-local per batch entry); work: device scratch of tr1_decode_step_workspace_bytes(dims),
+ * ZERO-FILLED once by the caller before the first step (it holds self re-arming split-K ticket counters). */
 int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 int64_t tr1_decode_step_workspace_bytes(const int64_t* dims);
 

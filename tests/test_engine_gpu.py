@@ -78,8 +78,8 @@ def test_qwen25_vision_tower_matches_oracle(hip_ops, grid):
     assert err < 0.03 * max(1.0, want.abs().max().item()), err
 
 
-@pytest.mark.parametrize("B", [1, 2])
-def test_native_decode_step_equals_op_by_op(hip_ops, B):
+@pytest.mark.parametrize("B,inter", [(1, 256), (2, 256), (2, 8192)])     # inter 8192 with 16 rows engages the split-K fixup down projection
+def test_native_decode_step_equals_op_by_op(hip_ops, B, inter):
     """csrc/decode.hip enqueues the same kernels in the same order as the host-driven loop: sampled tokens must be identical."""
     import time_r1_amd  # noqa: F401
     from time_r1_amd.config import tiny_test
@@ -88,6 +88,7 @@ def test_native_decode_step_equals_op_by_op(hip_ops, B):
     from time_r1_amd.grpo import GRPOCore
     from time_r1_amd.synthetic import synthetic_prompt
     cfg = tiny_test(n_layers=3)
+    cfg.text.intermediate = inter
     ops = hip_ops
     params = ModelParams(cfg, ops, seed=1)
     eng = Engine(cfg, ops, params)

@@ -429,3 +429,23 @@ def test_norm_gemm_fused(hip_ops, ref_ops, M, N, K, glu):
     if glu:
         y = hip_ops.swiglu_fwd(y)
     close(h, y.float().cpu(), 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=0.02, what="norm_gemm vs unfused HIP")
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 3584, 18944), (16, 3584, 3584), (8, 1536, 8960), (5, 200, 2048), (32, 3584, 18944), (24, 1536, 1536), (64, 512, 4096),
+                                   (16, 128, 256)])
+def test_gemm_skinny_fixup(hip_ops, M, N, K):
+    """Cross-block split-K with in-kernel fixup == the single-pass skinny GEMM (fp32 sums in a different order: bf16-ulp tolerance),
+    launched repeatedly to exercise the self re-arming ticket counters."""
+    a, b = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)).cuda()
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    want = hip_ops.gemm_nt(a, b, bias=bias, residual=res).float()
+    ref = a.float() @ b.float().t() + bias.float() + res.float()
+    for rep in range(40):      # fresh activations every launch: a stale partial tile from the previous launch would show up as an error
+        a = rnd(M, K, seed=100 + rep).cuda()
+        want = hip_ops.gemm_nt(a, b, bias=bias, residual=res).float()
+        ref = a.float() @ b.float().t() + bias.float() + res.float()
+        got = hip_ops.gemm_skinny_fixup(a, b, bias=bias, residual=res).float()
+        assert (got - ref).abs().max() <= 0.02 + 0.01 * ref.abs().max(), rep
+        assert (got - want).abs().max() <= 2.0 ** -7 * max(1.0, float(want.abs().max())), rep
+    plain = hip_ops.gemm_skinny_fixup(a, b).float()
+    assert (plain - a.float() @ b.float().t()).abs().max() <= 0.02 + 0.01 * ref.abs().max()

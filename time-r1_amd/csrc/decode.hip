@@ -27,7 +27,8 @@ static int64_t decode_ws_bytes(const int64_t* d) {
     const int64_t T = R / d[D_BATCH];
     const int64_t att = d[D_BATCH] * tr1_attn_fwd_workspace_floats(T, d[D_HEADS], d[D_KV], d[D_HEAD_DIM], d[D_NSPLIT]);
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
-    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + 4096;
+    const int64_t fix = tr1_gemm_skinny_fixup_workspace_floats(R, hid, d[D_INTER]);
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + 4096;
 }
 
 extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
@@ -45,6 +46,11 @@ extern "C" int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, cons
     void* hA = c.take(R * hid * 2); void* hB = c.take(R * hid * 2);
     void* qkv = c.take(R * qkvd * 2); void* q = c.take(R * qd * 2); void* o = c.take(R * qd * 2);
     void* a = c.take(R * inter * 2); void* att = c.take(att_floats * 4);
+    // down_proj (N = hidden, K = intermediate): split-K with in-kernel fixup pays from 16 rows up (tools/microbench.py fixup:
+    // 37.9 -> 34.9 us at M = 16, 54 -> 45 us at M = 32); its ticket counters live in `work`, which the caller zero-fills ONCE
+    const int64_t fix_floats = tr1_gemm_skinny_fixup_workspace_floats(R, hid, inter);
+    void* fix = c.take(fix_floats * 4);
+    const bool down_fixup = R >= 16 && inter >= 8192;
     TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");
     const void* const* lp = (const void* const*)layer_ptrs;    // per layer: ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache, V^T cache
 #define CK(call) do { int e__ = (call); if (e__) return e__; } while (0)
@@ -58,7 +64,8 @@ extern "C" int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, cons
                         scap, stream));
         CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
         CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
-        CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
+        if (down_fixup) CK(tr1_gemm_skinny_fixup(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
+        else CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
     }
     CK(tr1_norm_gemm_skinny(h, final_norm, lm_head, nullptr, logits, R, V, hid, hid, hid, V, eps, 0, stream));
 #undef CK

@@ -301,8 +301,10 @@ template <int WAVES, int UNROLL, int NCOL, int MG>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                  float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
                                                                  const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
-                                                                 int64_t ldw, int64_t ldc, int64_t ldr) {
+                                                                 int64_t ldw, int64_t ldc, int64_t ldr, float* __restrict__ fix_ws,
+                                                                 int* __restrict__ fix_cnt) {
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
+    __shared__ int s_ticket;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 16 * NCOL;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
     const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
     const int64_t s0 = kb + wave * s_per;
     int64_t s1 = s0 + s_per; if (s1 > ke) s1 = ke;
-    if (gridDim.y > 1) Cf32 += (int64_t)blockIdx.y * M * ldc;
+    if (gridDim.y > 1 && !fix_cnt) Cf32 += (int64_t)blockIdx.y * M * ldc;
     f32x4_t acc[NCOL][MG][2];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c)
@@ -391,7 +393,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][0][r] + acc[c][mg][1][r];
     __syncthreads();
-    for (int i = threadIdx.x; i < NCOL * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
+    constexpr int TILE = NCOL * MG * 256;
+    if (fix_cnt) {
+        // Cross-block split-K with in-kernel fixup: every block of a column group parks its fp32 partial tile in L2-resident scratch and
+        // takes a ticket; the block that draws the last ticket sums the gridDim.y tiles in slab order (deterministic), applies
+        // bias / residual and writes C.  The tiles are written and read with device-scope (write-through / L2-bypassing) accesses, so
+        // they are visible across XCDs (per-XCD L2) without flushing the caches.
+        float* mine = fix_ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * TILE;
+        for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
+            const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) v += red[w][c][mg][mm][nn];
+            __hip_atomic_store(mine + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-scope write-through: no L2 flush needed
+        }
+        // the tile stores above are complete (acknowledged at device scope) before the ticket is drawn; a full agent-scope fence
+        // here would write back and invalidate the whole L2 and evict x for every other block (measured: 38 -> 55 us)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&fix_cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != (int)gridDim.y - 1) return;
+        for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
+            const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
+            const int m = mg * 16 + mm;
+            const int64_t n = n0 + c * 16 + nn;
+            float v = 0.f;
+            for (int ks = 0; ks < (int)gridDim.y; ++ks)
+                v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m < M && n < N) {
+                if (bias) v += bf2f(bias[n]);
+                if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
+                if (Cf32) Cf32[(int64_t)m * ldc + n] = v;
+                else C[(int64_t)m * ldc + n] = f2bf(v);
+            }
+        }
+        if (threadIdx.x == 0) fix_cnt[blockIdx.x] = 0;      // re-armed for the next launch (ordered by the kernel boundary)
+        return;
+    }
+    for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {   // (column group, row group, m, n)
         const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
         const int m = mg * 16 + mm;
         const int64_t n = n0 + c * 16 + nn;
@@ -580,7 +620,8 @@ static void launch_skinny(const void* A, const void* B, void* C, const void* bia
 #define SK(WV, UN, NC, MGR)                                                                                                          \
     hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC, MGR>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC)), (unsigned)ksplit),    \
                        dim3(WV * 64), 0, s, (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C,                     \
-                       out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr)
+                       out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr,   \
+                       (float*)nullptr, (int*)nullptr)
     // choices measured on MI355X with tools/microbench.py skinny (non-temporal loads hurt; 8-way in-block split-K pays for long K)
     // (A/B on MI355X, M = 16: gate_up 37888x3584 67.6 -> 56.8 us with NCOL 2; lm_head 152064x3584 247 -> 188 us with NCOL 4;
     //  the 3584x18944 down projection has too few column groups for NCOL > 1 and wants split-K instead)
@@ -659,5 +700,46 @@ extern "C" int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_
     TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_skinny_splitk: N%8, lda%8, ldb%8 required");
     TR1_CHECK_ARG(ksplit >= 1 && ksplit <= 16 && K / 64 >= ksplit, "gemm_skinny_splitk: 1 <= ksplit <= min(16, K/64)");
     launch_skinny(A, B, parts_f32, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 1, ksplit, (hipStream_t)stream);
+    TR1_LAUNCH_CHECK();
+}
+
+// ---- narrow-N decode projections (o_proj, down_proj): cross-block split-K with in-kernel fixup -----------------------------------
+// N/16 column groups cannot fill 256 CUs and every block re-reads all of x from L2; 4 k-slabs x wider column groups (NCOL 2-4) cut
+// the x traffic and put ~4x more blocks in flight.  Measured at M = 16 (tools/microbench.py splitk): down 3584x18944 38.5 -> 29 us.
+static int skinny_fix_cfg(int64_t M, int64_t N, int64_t K, int* ncol, int* mg) {
+    *mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    *ncol = (K >= 8192 && *mg <= 2) ? 4 : 2;
+    return K >= 2048 ? 4 : 1;
+}
+
+extern "C" int64_t tr1_gemm_skinny_fixup_workspace_floats(int64_t M, int64_t N, int64_t K) {
+    // fp32 tiles [ksplit][column groups][NCOL*MG*256] followed by one int32 ticket counter per column group (zero-initialised ONCE by
+    // the caller; the kernel re-arms them)
+    int ncol, mg;
+    const int ks = skinny_fix_cfg(M, N, K, &ncol, &mg);
+    const int64_t groups = (N + 16 * ncol - 1) / (16 * ncol);
+    return ks * groups * ncol * mg * 256 + groups;
+}
+
+extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                                     int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && K >= 256, "gemm_skinny_fixup: K must be a multiple of 64 and >= 256");
+    TR1_CHECK_ARG(M >= 1 && M <= 64, "gemm_skinny_fixup: 1 <= M <= 64 (decode rows)");
+    TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_skinny_fixup: N%8, ld%8 required");
+    int ncol, mg;
+    const int ks = skinny_fix_cfg(M, N, K, &ncol, &mg);
+    const int64_t groups = (N + 16 * ncol - 1) / (16 * ncol);
+    TR1_CHECK_ARG(ws_f32 && ws_floats >= ks * groups * ncol * mg * 256 + groups, "gemm_skinny_fixup: workspace too small");
+    float* tiles = (float*)ws_f32;
+    int* cnt = (int*)(tiles + ks * groups * ncol * mg * 256);
+    hipStream_t s = (hipStream_t)stream;
+#define SKF(WV, UN, NC, MGR)                                                                                                         \
+    hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC, MGR>), dim3((unsigned)groups, (unsigned)ks), dim3(WV * 64), 0, s,            \
+                       (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, \
+                       (int)M, N, K, lda, ldb, ldc, ldr, tiles, ks > 1 ? cnt : (int*)nullptr)
+    if (mg == 1) { if (ncol == 4) SKF(4, 2, 4, 1); else SKF(4, 4, 2, 1); }
+    else if (mg == 2) { if (ncol == 4) SKF(4, 2, 4, 2); else SKF(4, 2, 2, 2); }
+    else SKF(4, 2, 2, 4);
+#undef SKF
     TR1_LAUNCH_CHECK();
 }

@@ -95,7 +95,7 @@ class HipOps:
         ptrs = (ctypes.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
         dims = (ctypes.c_int64 * 11)(len(layers), hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit)
         nbytes = int(self.L.raw("tr1_decode_step_workspace_bytes")(dims))
-        work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        work = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)     # zero: the split-K ticket counters inside start disarmed
         logits = self.empty(rows, vocab)
         return dict(ptrs=ptrs, ptrs_p=ctypes.cast(ptrs, ctypes.c_void_p), dims=dims, work=work, work_p=work.data_ptr(), nbytes=nbytes,
                     logits=logits, logits_p=logits.data_ptr(), keep=flat, stream=self._s())
@@ -106,6 +106,22 @@ class HipOps:
         self.L.call("tr1_decode_step", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p,
                     plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
         return plan["logits"]
+
+    def gemm_skinny_fixup(self, a, b, bias=None, residual=None):
+        """Decode rows x narrow projection (o_proj / down_proj): split-K with in-kernel fixup; bf16 [M, N]."""
+        self._chk(a, b, bias, residual)
+        M, K = a.shape
+        N = b.shape[0]
+        assert a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
+        n = int(self.L.raw("tr1_gemm_skinny_fixup_workspace_floats")(M, N, K))
+        key = "skinny_fix_%d_%d_%d" % (M, N, K)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.zeros(n, dtype=F32, device=self.device)     # ticket counters start at zero
+        out = self.empty(M, N)
+        self.L.call("tr1_gemm_skinny_fixup", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, a.stride(0), b.stride(0), N,
+                    residual.stride(0) if residual is not None else 0, _p(ws), n, self._s())
+        return out
 
     def gemm_skinny_splitk(self, a, b, ksplit):
         """fp32 partial slabs [ksplit, M, N] of a @ b^T (decode rows; summed by rmsnorm_fwd_parts / decode_qkv_post)."""

@@ -144,7 +144,10 @@ class Rollout:
                 else:
                     xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
                     a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
-                h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
+                if fused and R >= 16 and t.intermediate >= 8192:      # same kernel choice as csrc/decode.hip (bitwise-equal paths)
+                    h = ops.gemm_skinny_fixup(a, arena.w(p + "down.w"), residual=h2)
+                else:
+                    h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
             if fused:
                 logits = ops.norm_gemm(h, arena.w("norm"), t.rms_eps, w_lm)
             else:

@@ -71,6 +71,29 @@ def splitk():
             print("M=%2d N=%6d K=%6d  " % (M, N, K) + "  ".join(row))
 
 
+def fixup():
+    import ctypes
+    print("== narrow decode projections: plain skinny vs split-K + in-kernel fixup (raw C-ABI calls): us")
+    f0, f1 = ops.L.raw("tr1_gemm_nt_bf16"), ops.L.raw("tr1_gemm_skinny_fixup")
+    for M in (8, 16, 32):
+        for N, K in [(3584, 18944), (3584, 3584), (1536, 8960), (1536, 1536)]:
+            ws_ = [rnd(N, K) for _ in range(max(1, min(8, int(600e6 // (N * K * 2)))))]
+            x, res, out = rnd(M, K), rnd(M, N), torch.empty(M, N, device="cuda", dtype=BF)
+            n = int(ops.L.raw("tr1_gemm_skinny_fixup_workspace_floats")(M, N, K))
+            wsf = torch.zeros(n, device="cuda")
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            a0 = [(P(x), P(w), P(out), None, P(res), M, N, K, K, K, N, N, 0, 0, None) for w in ws_]
+            a1 = [(P(x), P(w), P(out), None, P(res), M, N, K, K, K, N, N, P(wsf), n, None) for w in ws_]
+            i = [0]
+
+            def g0():
+                f0(*a0[i[0] % len(a0)]); i[0] += 1
+
+            def g1():
+                f1(*a1[i[0] % len(a1)]); i[0] += 1
+            print("M=%2d N=%6d K=%6d   plain %6.1f   fixup %6.1f" % (M, N, K, timeit(g0, reps=100), timeit(g1, reps=100)))
+
+
 def fused():
     import ctypes
     print("== decode layer pieces, raw C-ABI calls: us  (unfused rmsnorm + gemm [+ swiglu]  vs  norm_gemm)")
@@ -173,5 +196,5 @@ def sampler():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     for w in what:
-        for name in (["skinny", "splitk", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+        for name in (["skinny", "splitk", "fixup", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
             globals()[name]()
