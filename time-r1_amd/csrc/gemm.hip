@@ -293,6 +293,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 // step, so a 16-lane group covers one full 128-byte line per row; the k-order inside the MFMA is permuted the same
 // way for x (any k permutation is legal as long as A and B agree).
 // ------------------------------------------------------------------------------------------------------------------
+// Optional block-timeline probe (tools/probe_skinny.hip compiles this file with -DTR1_PROBE): wall_clock64() at block entry, after
+// the k loop and at block exit, 4 slots per block.  Not compiled into the library.
+#ifdef TR1_PROBE
+__device__ unsigned long long* tr1_probe = nullptr;
+#define TR1_PROBE_AT(slot) do { if (tr1_probe && threadIdx.x == 0) tr1_probe[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TR1_PROBE_AT(slot) do { } while (0)
+#endif
+
 // NCOL: 16-column groups per wave.  The x (activation) fragment is loaded once per k-step and reused for NCOL weight fragments, so
 // the L2 traffic for x drops from 1x to 1/NCOL of the weight stream (matters at M = 16, where x is as large as a block's W slab).
 // MG: 16-row groups of x (M <= 16*MG): every weight fragment fetched from HBM feeds MG MFMAs, so batching more rollout rows into one
@@ -305,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
                                                                  int* __restrict__ fix_cnt) {
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ int s_ticket;
+    TR1_PROBE_AT(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 16 * NCOL;
@@ -315,13 +325,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
         int64_t wrow = n0 + c * 16 + u; if (wrow >= N) wrow = N - 1;
         wp[c] = W + wrow * ldw + g * 8;
     }
-    bool xlive[MG];                                // rows >= M of the MFMA B operand are padding: no loads issued for them
+    // rows >= M of the MFMA B operand are padding: they re-read row M-1 (unconditional loads keep the k loop branch-free, so the
+    // compiler can count the loads in flight instead of draining them with vmcnt(0)); their output columns are never stored
     const bf16_t* xp[MG];
 #pragma unroll
-    for (int mg = 0; mg < MG; ++mg) {
-        xlive[mg] = mg * 16 + u < M;
-        xp[mg] = X + (int64_t)(xlive[mg] ? mg * 16 + u : (M - 1)) * ldx + g * 8;
-    }
+    for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (int64_t)(mg * 16 + u < M ? mg * 16 + u : (M - 1)) * ldx + g * 8;
     // gridDim.y > 1: cross-block split-K - block (x, y) covers k-steps [kb, ke) and writes its raw fp32 partial tile to slab y of Cf32;
     // the consumer kernel (rmsnorm / decode_qkv_post) sums the slabs while it reads them (no extra pass, deterministic order)
     const int64_t nsteps_all = K / 64;
@@ -338,53 +346,48 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
     for (int c = 0; c < NCOL; ++c)
 #pragma unroll
         for (int mg = 0; mg < MG; ++mg) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-    const bf16x8_t zf = zero_frag8();
+    // Rotating software pipeline over UNROLL k-step buffers: a buffer is refilled (next k-step, UNROLL ahead) right after its MFMAs are
+    // issued.  Measured neutral against the batch form (issue UNROLL steps, drain, repeat): hipcc still drains the queue once per trip
+    // (s_waitcnt vmcnt(1)/vmcnt(0) at the loop header), and the N sweep of tools/probe_skinny.hip shows the kernel already at
+    // t = 7 us + bytes / 5.4-5.8 TB/s, i.e. within ~15 % of what this access pattern streams at any size.
+    bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2];
+#define SK_LOAD(q, st)                                                                                   \
+    do {                                                                                                 \
+        const int64_t k__ = (st) * 64;                                                                   \
+        _Pragma("unroll") for (int c = 0; c < NCOL; ++c) {                                               \
+            wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__);                               \
+            wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__ + 32);                          \
+        }                                                                                                \
+        _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                              \
+            xa[q][mg][0] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__);                             \
+            xa[q][mg][1] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__ + 32);                        \
+        }                                                                                                \
+    } while (0)
+#define SK_MFMA(q)                                                                                                            \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < NCOL; ++c)                                                                      \
+            _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                                               \
+                acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], xa[q][mg][0], acc[c][mg][0], 0, 0, 0);   \
+                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], xa[q][mg][1], acc[c][mg][1], 0, 0, 0);   \
+            }                                                                                                                 \
+    } while (0)
     int64_t s = s0;
-    for (; s + UNROLL <= s1; s += UNROLL) {
-        bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2];
 #pragma unroll
-        for (int q = 0; q < UNROLL; ++q) {
-            const int64_t k = (s + q) * 64;
+    for (int q = 0; q < UNROLL; ++q)
+        if (s0 + q < s1) SK_LOAD(q, s0 + q);
+    for (; s + 2 * UNROLL <= s1; s += UNROLL) {          // steady state: branch-free
 #pragma unroll
-            for (int c = 0; c < NCOL; ++c) {
-                wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
-                wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
-            }
-#pragma unroll
-            for (int mg = 0; mg < MG; ++mg) {
-                xa[q][mg][0] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf;
-                xa[q][mg][1] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < UNROLL; ++q)
-#pragma unroll
-            for (int c = 0; c < NCOL; ++c)
-#pragma unroll
-                for (int mg = 0; mg < MG; ++mg) {
-                    acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], xa[q][mg][0], acc[c][mg][0], 0, 0, 0);
-                    acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], xa[q][mg][1], acc[c][mg][1], 0, 0, 0);
-                }
+        for (int q = 0; q < UNROLL; ++q) { SK_MFMA(q); SK_LOAD(q, s + q + UNROLL); }
     }
-    for (; s < s1; ++s) {
-        const int64_t k = s * 64;
-        bf16x8_t x0[MG], x1[MG];
 #pragma unroll
-        for (int mg = 0; mg < MG; ++mg) {
-            x0[mg] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf;
-            x1[mg] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf;
-        }
+    for (int q = 0; q < UNROLL; ++q)
+        if (s + q < s1) { SK_MFMA(q); if (s + q + UNROLL < s1) SK_LOAD(q, s + q + UNROLL); }
+    s += UNROLL;
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
-            const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
-#pragma unroll
-            for (int mg = 0; mg < MG; ++mg) {
-                acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0[mg], acc[c][mg][0], 0, 0, 0);
-                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[mg], acc[c][mg][1], 0, 0, 0);
-            }
-        }
-    }
+    for (int q = 0; q < UNROLL; ++q)
+        if (s + q < s1) SK_MFMA(q);
+#undef SK_LOAD
+#undef SK_MFMA
     // D[row = n index (g*4+r)][col = m (u)]
 #pragma unroll
     for (int c = 0; c < NCOL; ++c)
@@ -392,7 +395,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
         for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][0][r] + acc[c][mg][1][r];
+    TR1_PROBE_AT(1);
     __syncthreads();
+    TR1_PROBE_AT(2);
     constexpr int TILE = NCOL * MG * 256;
     if (fix_cnt) {
         // Cross-block split-K with in-kernel fixup: every block of a column group parks its fp32 partial tile in L2-resident scratch and
@@ -487,13 +492,9 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
         if (GLU && c == 1) wrow += up_off;
         wp[c] = W + wrow * ldw + g * 8;
     }
-    bool xlive[MG];
-    const bf16_t* xp[MG];
+    const bf16_t* xp[MG];      // rows >= M re-read row M-1 (see gemm_skinny_kernel); their outputs are never stored
 #pragma unroll
-    for (int mg = 0; mg < MG; ++mg) {
-        xlive[mg] = mg * 16 + u < M;
-        xp[mg] = X + (int64_t)(xlive[mg] ? mg * 16 + u : (M - 1)) * ldx + g * 8;
-    }
+    for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (int64_t)(mg * 16 + u < M ? mg * 16 + u : (M - 1)) * ldx + g * 8;
     const bf16_t* lp = lnw + g * 8;
     const int64_t nsteps = K / 64;
     const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
@@ -507,59 +508,50 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     }
-    const bf16x8_t zf = zero_frag8();
+    // rotating software pipeline over UNROLL k-step buffers (see gemm_skinny_kernel)
+    bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2], la[UNROLL][2];
+#define NG_LOAD(q, st)                                                                                   \
+    do {                                                                                                 \
+        const int64_t k__ = (st) * 64;                                                                   \
+        _Pragma("unroll") for (int c = 0; c < NCOL; ++c) {                                               \
+            wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__);                               \
+            wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__ + 32);                          \
+        }                                                                                                \
+        _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                              \
+            xa[q][mg][0] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__);                             \
+            xa[q][mg][1] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__ + 32);                        \
+        }                                                                                                \
+        la[q][0] = *reinterpret_cast<const bf16x8_t*>(lp + k__);                                         \
+        la[q][1] = *reinterpret_cast<const bf16x8_t*>(lp + k__ + 32);                                    \
+    } while (0)
+#define NG_MFMA(q)                                                                                                            \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                                                   \
+            const bf16x8_t x0__ = scale_frag_sumsq(xa[q][mg][0], la[q][0], ss[mg]);                                           \
+            const bf16x8_t x1__ = scale_frag_sumsq(xa[q][mg][1], la[q][1], ss[mg]);                                           \
+            _Pragma("unroll") for (int c = 0; c < NCOL; ++c) {                                                                \
+                acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], x0__, acc[c][mg][0], 0, 0, 0);           \
+                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], x1__, acc[c][mg][1], 0, 0, 0);           \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
     int64_t s = s0;
-    for (; s + UNROLL <= s1; s += UNROLL) {
-        bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2], la[UNROLL][2];
 #pragma unroll
-        for (int q = 0; q < UNROLL; ++q) {
-            const int64_t k = (s + q) * 64;
+    for (int q = 0; q < UNROLL; ++q)
+        if (s0 + q < s1) NG_LOAD(q, s0 + q);
+    for (; s + 2 * UNROLL <= s1; s += UNROLL) {
 #pragma unroll
-            for (int c = 0; c < NCOL; ++c) {
-                wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
-                wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
-            }
-#pragma unroll
-            for (int mg = 0; mg < MG; ++mg) {
-                xa[q][mg][0] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf;
-                xa[q][mg][1] = xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf;
-            }
-            la[q][0] = *reinterpret_cast<const bf16x8_t*>(lp + k);
-            la[q][1] = *reinterpret_cast<const bf16x8_t*>(lp + k + 32);
-        }
-#pragma unroll
-        for (int q = 0; q < UNROLL; ++q)
-#pragma unroll
-            for (int mg = 0; mg < MG; ++mg) {
-                const bf16x8_t x0 = scale_frag_sumsq(xa[q][mg][0], la[q][0], ss[mg]);
-                const bf16x8_t x1 = scale_frag_sumsq(xa[q][mg][1], la[q][1], ss[mg]);
-#pragma unroll
-                for (int c = 0; c < NCOL; ++c) {
-                    acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], x0, acc[c][mg][0], 0, 0, 0);
-                    acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], x1, acc[c][mg][1], 0, 0, 0);
-                }
-            }
+        for (int q = 0; q < UNROLL; ++q) { NG_MFMA(q); NG_LOAD(q, s + q + UNROLL); }
     }
-    for (; s < s1; ++s) {
-        const int64_t k = s * 64;
-        const bf16x8_t l0 = *reinterpret_cast<const bf16x8_t*>(lp + k), l1 = *reinterpret_cast<const bf16x8_t*>(lp + k + 32);
-        bf16x8_t w0[NCOL], w1[NCOL];
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            w0[c] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k);
-            w1[c] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k + 32);
-        }
+    for (int q = 0; q < UNROLL; ++q)
+        if (s + q < s1) { NG_MFMA(q); if (s + q + UNROLL < s1) NG_LOAD(q, s + q + UNROLL); }
+    s += UNROLL;
 #pragma unroll
-        for (int mg = 0; mg < MG; ++mg) {
-            const bf16x8_t x0 = scale_frag_sumsq(xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k) : zf, l0, ss[mg]);
-            const bf16x8_t x1 = scale_frag_sumsq(xlive[mg] ? *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + 32) : zf, l1, ss[mg]);
-#pragma unroll
-            for (int c = 0; c < NCOL; ++c) {
-                acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[c], x0, acc[c][mg][0], 0, 0, 0);
-                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[c], x1, acc[c][mg][1], 0, 0, 0);
-            }
-        }
-    }
+    for (int q = 0; q < UNROLL; ++q)
+        if (s + q < s1) NG_MFMA(q);
+#undef NG_LOAD
+#undef NG_MFMA
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg) {     // lanes u, u+16, u+32, u+48 hold disjoint k chunks of row u
         float v = ss[mg];
@@ -627,6 +619,31 @@ static void launch_skinny(const void* A, const void* B, void* C, const void* bia
     //  the 3584x18944 down projection has too few column groups for NCOL > 1 and wants split-K instead)
     const int ncol = force_ncol > 0 ? force_ncol : (N >= 100000 ? 4 : (N >= 4096 && ksplit == 1 ? 2 : 1));
     const bool longk = K / ksplit >= 8192;
+#ifdef TR1_PROBE
+    {   // experiment hook (probe build only): TR1_SKINNY_CFG=<waves><unroll><ncol>, e.g. 482
+        const char* e = getenv("TR1_SKINNY_CFG");
+        const int cfg = e ? atoi(e) : 0;
+        if (M <= 16 && cfg) {
+            switch (cfg) {
+                case 482: SK(4, 8, 2, 1); return;
+                case 481: SK(4, 8, 1, 1); return;
+                case 842: SK(8, 4, 2, 1); return;
+                case 822: SK(8, 2, 2, 1); return;
+                case 422: SK(4, 2, 2, 1); return;
+                case 242: SK(2, 4, 2, 1); return;
+                case 282: SK(2, 8, 2, 1); return;
+                case 442: SK(4, 4, 2, 1); return;
+                case 444: SK(4, 4, 4, 1); return;
+                case 424: SK(4, 2, 4, 1); return;
+                case 284: SK(2, 8, 4, 1); return;
+                case 244: SK(2, 4, 4, 1); return;
+                case 144: SK(1, 4, 4, 1); return;
+                case 184: SK(1, 8, 4, 1); return;
+                default: break;
+            }
+        }
+    }
+#endif
     if (M <= 16) {
         if (longk) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2, 1); else SK(8, 4, 1, 1); }
         else if (ncol == 4) SK(4, 2, 4, 1);
