@@ -122,6 +122,17 @@ def instrument_gemms(ops):
     rec = []
     orig = ops.gemm_nt
 
+    orig_fx = ops.gemm_skinny_fixup
+
+    def timed_fx(a, b, bias=None, residual=None):               # decode down projection (split-K + in-kernel fixup): same weight stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_fx(a, b, bias=bias, residual=residual)
+        e1.record()
+        rec.append((True, a.shape[0], b.shape[0], a.shape[1], e0, e1))
+        return r
+    ops.gemm_skinny_fixup = timed_fx
+
     def timed(a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
         M, K = a.shape
         N = b.shape[0]
@@ -144,7 +155,7 @@ def instrument_gemms(ops):
         return r
     ops.gemm_nt = timed
     ops.norm_gemm = timed_ng
-    return rec, (orig, orig_ng)
+    return rec, (orig, orig_ng, orig_fx)
 
 
 def cpu_baseline(args, budget_note=True):
@@ -298,10 +309,14 @@ def main():
     if not args.no_roofline:
         # every rank runs the extra window (it contains the gradient all-reduce); only rank 0 records events
         rec, orig = instrument_gemms(ops) if rank == 0 else ([], None)
+        # the timed windows drive decode through ONE native call per step (csrc/decode.hip); for this window the same kernels are launched
+        # op by op from the host so that every GEMM launch can be bracketed by its own pair of HIP events
+        wl.core.roll.native_decode = False
         wl.window()
         torch.cuda.synchronize()
+        wl.core.roll.native_decode = True
         if rank == 0:
-            ops.gemm_nt, ops.norm_gemm = orig
+            ops.gemm_nt, ops.norm_gemm, ops.gemm_skinny_fixup = orig
     if rank == 0 and not args.no_roofline:
         nstep = float(args.ga)
         big_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if not s)
@@ -321,9 +336,14 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if args.model == "qwen2-vl-7b" and args.G == 8 and args.ga == 2:
-                hbm["traffic"] = pmc["gemm_skinny_kernel"]["fetch_bytes_per_launch_corrected"]
+                def fam(*names):      # launch-weighted mean over the kernel families that make up one roofline entry
+                    n = sum(pmc[k]["launches"] for k in names if k in pmc)
+                    return sum(pmc[k]["launches"] * pmc[k]["fetch_bytes_per_launch_corrected"] for k in names if k in pmc) / max(n, 1)
+                hbm["traffic"] = fam("gemm_skinny_kernel", "norm_gemm_skinny_kernel")
                 hbm["algorithmic_bytes_per_launch"] = sk_by / max(sk_n, 1)
-                hbm["traffic_source"] = "profiles/r01_pmc_traffic.json"
+                mfma["traffic"] = fam("gemm_nt_kernel", "gemm_nt256_kernel")
+                mfma["algorithmic_flops_per_launch"] = big_fl / max(big_n, 1)
+                hbm["traffic_source"] = mfma["traffic_source"] = "profiles/r01_pmc_traffic.json"
         except Exception:
             pass
         dominant, other = (mfma, hbm) if big_ms >= sk_ms else (hbm, mfma)
