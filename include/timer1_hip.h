@@ -32,11 +32,6 @@ int tr1_device_info(int device, char* arch, int64_t arch_len, int64_t* n_cu, int
  * K % 64 == 0 (pad), N % 8 == 0.  out_f32: C is fp32; accumulate (fp32 only): C += result (weight-gradient accumulation).
  * M <= 16 dispatches the HBM-streaming skinny kernel used by rollout decode. */
 int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream);
-/* Decode-regime GEMM with cross-block split-K: parts_f32[ks, M, N] = A[M, k-range ks] * B[N, k-range ks]^T (fp32, no bias/residual).
- * For the narrow projections of a decode step (o_proj, down_proj, qkv: N/16 column groups cannot fill 256 CUs) - the slabs are summed by the
- * consumer kernel (tr1_rmsnorm_fwd_parts / tr1_decode_qkv_post with n_parts), so the reduction costs no extra pass.  Same call sites as
- * tr1_gemm_nt_bf16 inside generate (timer1_trainer.py:568-573). */
-int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int ksplit, void* stream);
 /* Decode-step fusion (M <= 64 rows): out = rmsnorm(x; lnw, eps) @ W[N,K]^T (+ bias), the norm folded into the GEMM's operand load
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
  * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */

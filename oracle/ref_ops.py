@@ -91,7 +91,14 @@ class RefOps:
         return out
 
     # ---- norms (ref: Qwen2RMSNorm TF:96-110; nn.LayerNorm)
-    def rmsnorm_fwd(self, x, w, eps, residual=None, need_rstd=True):
+    def rmsnorm_fwd(self, x, w, eps, residual=None, need_rstd=True, out=None, rstd_out=None):
+        if out is not None or rstd_out is not None:
+            y, rstd, xsum = self.rmsnorm_fwd(x, w, eps, residual=residual, need_rstd=need_rstd)
+            if out is not None:
+                out.copy_(y); y = out
+            if rstd_out is not None and rstd is not None:
+                rstd_out.copy_(rstd); rstd = rstd_out
+            return y, rstd, xsum
         xsum = None
         if residual is not None:
             xsum = self._a(x.float() + residual.float())
@@ -136,10 +143,14 @@ class RefOps:
         y = self.gemm_nt(xn, w, bias=bias)
         return self.swiglu_fwd(y) if glu else y
 
-    def swiglu_fwd(self, gu):
+    def swiglu_fwd(self, gu, out=None):
         i = gu.shape[1] // 2
         g, u = gu[:, :i].float(), gu[:, i:].float()
-        return self._a(self._a(torch.nn.functional.silu(g)).float() * u)
+        r = self._a(self._a(torch.nn.functional.silu(g)).float() * u)
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
 
     def swiglu_bwd(self, dout, gu):
         i = gu.shape[1] // 2

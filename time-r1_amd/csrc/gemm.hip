@@ -330,8 +330,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
     const bf16_t* xp[MG];
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (int64_t)(mg * 16 + u < M ? mg * 16 + u : (M - 1)) * ldx + g * 8;
-    // gridDim.y > 1: cross-block split-K - block (x, y) covers k-steps [kb, ke) and writes its raw fp32 partial tile to slab y of Cf32;
-    // the consumer kernel (rmsnorm / decode_qkv_post) sums the slabs while it reads them (no extra pass, deterministic order)
+    // gridDim.y > 1: cross-block split-K - block (x, y) covers k-steps [kb, ke); the partial tiles are merged by the in-kernel fixup below
     const int64_t nsteps_all = K / 64;
     const int64_t per_split = (nsteps_all + gridDim.y - 1) / gridDim.y;
     const int64_t kb = (int64_t)blockIdx.y * per_split;
@@ -340,7 +339,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
     const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
     const int64_t s0 = kb + wave * s_per;
     int64_t s1 = s0 + s_per; if (s1 > ke) s1 = ke;
-    if (gridDim.y > 1 && !fix_cnt) Cf32 += (int64_t)blockIdx.y * M * ldc;
     f32x4_t acc[NCOL][MG][2];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c)
@@ -604,7 +602,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     TR1_LAUNCH_CHECK();
 }
 
-// Launch of the decode-regime kernel.  ksplit > 1: C is fp32 [ksplit, M, ldc] partial slabs (no bias / residual).
+// Launch of the decode-regime kernel (single pass over K; the split-K + fixup form is launched by tr1_gemm_skinny_fixup).
 static void launch_skinny(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                           int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int ksplit, hipStream_t s) {
     static int force_ncol = -1;
@@ -707,16 +705,6 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     if (out_f32) { if (accumulate) LAUNCH(true, true); else LAUNCH(true, false); }
     else LAUNCH(false, false);
 #undef LAUNCH
-    TR1_LAUNCH_CHECK();
-}
-
-extern "C" int tr1_gemm_skinny_splitk(const void* A, const void* B, void* parts_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                                      int ksplit, void* stream) {
-    TR1_CHECK_ARG(K % BK == 0 && K >= 256, "gemm_skinny_splitk: K must be a multiple of 64 and >= 256");
-    TR1_CHECK_ARG(M >= 1 && M <= 64, "gemm_skinny_splitk: 1 <= M <= 64 (decode rows)");
-    TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_skinny_splitk: N%8, lda%8, ldb%8 required");
-    TR1_CHECK_ARG(ksplit >= 1 && ksplit <= 16 && K / 64 >= ksplit, "gemm_skinny_splitk: 1 <= ksplit <= min(16, K/64)");
-    launch_skinny(A, B, parts_f32, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 1, ksplit, (hipStream_t)stream);
     TR1_LAUNCH_CHECK();
 }
 

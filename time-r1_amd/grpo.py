@@ -125,7 +125,8 @@ class GRPOCore:
             pctx, kv = pf
             hc = ops.gather_rows(tr.w("embed"), st.ids_packed[P:].contiguous())
             cmask = [m[P:].contiguous() for m in st.masks]
-            hLc, cctx = eng.llm_fwd(tr, hc, st.cos[P:].contiguous(), st.sin[P:].contiguous(), cmask, save=True, kv_cache=kv, row0=P)
+            hLc, cctx = eng.llm_fwd(tr, hc, st.cos[P:].contiguous(), st.sin[P:].contiguous(), cmask, save=True, kv_cache=kv, row0=P,
+                                    bufs=pctx.get("bufs"))
             st.llm_ctx = eng.merge_ctx(pctx, cctx, kv, st.masks, st.cos, st.sin, M)
             # the head only needs the last prompt row (it predicts every group's first completion token) and the completion rows
             hL = ops.zeros(M, hLc.shape[1])

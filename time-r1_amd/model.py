@@ -150,11 +150,36 @@ class Engine:
             self.ops.scatter_rows(vid_embeds, vid_rows, h)
         return h
 
-    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0):
+    SAVED = ("h", "xn", "qkv", "q", "o", "h2", "xn2", "gu", "a")
+
+    def alloc_ctx_bufs(self, total_rows, slot=0):
+        """Saved-activation buffers for a packed sequence of `total_rows` rows that is run in two pieces (prompt rows during the rollout
+        prefill, completion rows in the update's continuation forward): both pieces write their rows in place, so the backward gets
+        [M, .] tensors without a concatenation pass (that pass cost ~25 GB of copies per 7B micro-step).
+        The buffers are owned by the engine and recycled: `slot` = index of the prompt inside the accumulation window; a slot is free
+        again once that prompt's backward has been enqueued (same stream), and it only grows (no allocator churn of 24 GB blocks)."""
+        ops, t = self.ops, self.cfg.text
+        pool = self.__dict__.setdefault("_ctx_pool", {})
+        ent = pool.get(slot)
+        if ent is None or ent[0] < total_rows:
+            pool[slot] = None          # release the smaller set before allocating the larger one
+            cap = (total_rows + 255) // 256 * 256
+            cols = dict(h=t.hidden, xn=t.hidden, qkv=t.qkv_dim, q=t.q_dim, o=t.q_dim, h2=t.hidden, xn2=t.hidden, gu=2 * t.intermediate, a=t.intermediate)
+            full = []
+            for _ in range(t.n_layers):
+                L = {k: ops.empty(cap, c) for k, c in cols.items()}
+                L["rstd1"] = ops.empty(cap, dtype=F32)
+                L["rstd2"] = ops.empty(cap, dtype=F32)
+                full.append(L)
+            ent = pool[slot] = (cap, full)
+        return [{k: v[:total_rows] for k, v in L.items()} for L in ent[1]]
+
+    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0, bufs=None):
         """Decoder stack over a packed sequence of M rows. masks = (pre, lo, hi) int32 [M] over slots == rows.
         kv_cache: optional list of (K [S_cap, kv_dim], VT [kv_dim, S_cap]) to be filled (rollout prefill).
         row0 > 0 ("continuation"): h holds only rows [row0, row0+M) of the packed sequence; their K/V are written to cache slots
         [row0, row0+M) and attention runs over slots [0, row0+M) - the prefix K/V of rows [0,row0) must already be in kv_cache.
+        bufs (alloc_ctx_bufs): saved activations are written into rows [row0, row0+M) of these buffers instead of fresh tensors.
         Returns (h_out, ctx) where ctx holds the saved activations when save=True."""
         ops, t = self.ops, self.cfg.text
         M = h.shape[0]
@@ -163,11 +188,18 @@ class Engine:
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
         scale = hd ** -0.5
         layers = []
+        inplace = save and bufs is not None
+
+        def dst(i, key):
+            return bufs[i][key][row0:S] if inplace else None
+        if inplace:
+            bufs[0]["h"][row0:S].copy_(h)
+            h = bufs[0]["h"][row0:S]
         for i in range(t.n_layers):
             p = "l%d." % i
-            xn, rstd1, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=save)
-            qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
-            q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cos, sin)
+            xn, rstd1, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=save, out=dst(i, "xn"), rstd_out=dst(i, "rstd1"))
+            qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"), out=dst(i, "qkv"))
+            q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cos, sin, out=dst(i, "q"))
             if kv_cache is not None:
                 kc, vtc = kv_cache[i]
                 k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin, out=kc[row0:S])
@@ -181,27 +213,29 @@ class Engine:
                 k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin)
                 vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd)
                 k_all = k
-            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save)
-            h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
-            xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save)
-            gu = ops.gemm_nt(xn2, arena.w(p + "gu.w"))
-            a = ops.swiglu_fwd(gu)
-            h_out = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
+            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save, out=dst(i, "o"))
+            h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h, out=dst(i, "h2"))
+            xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save, out=dst(i, "xn2"), rstd_out=dst(i, "rstd2"))
+            gu = ops.gemm_nt(xn2, arena.w(p + "gu.w"), out=dst(i, "gu"))
+            a = ops.swiglu_fwd(gu, out=dst(i, "a"))
+            h_out = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2, out=dst(i + 1, "h") if inplace and i + 1 < t.n_layers else None)
             if save:
                 layers.append(dict(h=h, rstd1=rstd1, xn=xn, qkv=qkv, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
             h = h_out
-        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin, h_last=h) if save else None
+        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin, h_last=h, bufs=bufs if inplace else None) if save else None
         return h, ctx
 
     @staticmethod
     def merge_ctx(ctx_a, ctx_b, kv_cache, masks, cos, sin, M):
         """Stitch the saved activations of a prefix forward (rows [0,P)) and its continuation (rows [P,M)) into the [M, .] form
-        llm_bwd expects. K comes from the cache (rows [0,M) in packed order); lse is [n_heads, rows] so it is joined along dim 1."""
+        llm_bwd expects. K comes from the cache (rows [0,M) in packed order); lse is [n_heads, rows] so it is joined along dim 1.
+        When both pieces wrote into shared buffers (alloc_ctx_bufs) nothing but lse is copied."""
         layers = []
+        shared = ctx_a.get("bufs") is not None and ctx_a.get("bufs") is ctx_b.get("bufs")
         for i, (a, b) in enumerate(zip(ctx_a["layers"], ctx_b["layers"])):
             L = {}
             for key in ("h", "xn", "qkv", "q", "o", "h2", "xn2", "gu", "a", "rstd1", "rstd2"):
-                L[key] = torch.cat([a[key], b[key]], 0)
+                L[key] = ctx_a["bufs"][i][key][:M] if shared else torch.cat([a[key], b[key]], 0)
             L["lse"] = torch.cat([a["lse"], b["lse"]], 1).contiguous()
             L["k"] = kv_cache[i][0][:M]
             layers.append(L)

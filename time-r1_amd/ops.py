@@ -123,16 +123,6 @@ class HipOps:
                     residual.stride(0) if residual is not None else 0, _p(ws), n, self._s())
         return out
 
-    def gemm_skinny_splitk(self, a, b, ksplit):
-        """fp32 partial slabs [ksplit, M, N] of a @ b^T (decode rows; summed by rmsnorm_fwd_parts / decode_qkv_post)."""
-        self._chk(a, b)
-        M, K = a.shape
-        N = b.shape[0]
-        assert a.stride(1) == 1 and b.stride(1) == 1 and b.shape[1] == K
-        parts = self.empty(ksplit, M, N, dtype=F32)
-        self.L.call("tr1_gemm_skinny_splitk", _p(a), _p(b), _p(parts), M, N, K, a.stride(0), b.stride(0), ksplit, self._s())
-        return parts
-
     def transpose(self, x, pad_to=64, out=None):
         """x[R,C] -> [C, Rpad] with zero-filled padding columns (Rpad = R rounded up to pad_to)."""
         self._chk(x)
@@ -145,12 +135,13 @@ class HipOps:
         return out
 
     # ---- norms ----------------------------------------------------------------------------------------------------
-    def rmsnorm_fwd(self, x, w, eps, residual=None, need_rstd=True):
+    def rmsnorm_fwd(self, x, w, eps, residual=None, need_rstd=True, out=None, rstd_out=None):
         self._chk(x, w, residual)
         rows, cols = x.shape
         assert x.is_contiguous() and (residual is None or residual.is_contiguous())
-        y = self.empty(rows, cols)
-        rstd = self.empty(rows, dtype=F32) if need_rstd else None
+        y = out if out is not None else self.empty(rows, cols)
+        assert y.is_contiguous() and y.shape == (rows, cols)
+        rstd = (rstd_out if rstd_out is not None else self.empty(rows, dtype=F32)) if need_rstd else None
         xsum = self.empty(rows, cols) if residual is not None else None
         self.L.call("tr1_rmsnorm_fwd", _p(x), _p(residual), _p(w), _p(y), _p(xsum), _p(rstd), rows, cols, float(eps), self._s())
         return y, rstd, xsum
@@ -184,11 +175,13 @@ class HipOps:
         return dx
 
     # ---- activations ----------------------------------------------------------------------------------------------
-    def swiglu_fwd(self, gu):
+    def swiglu_fwd(self, gu, out=None):
         self._chk(gu)
         rows, two_i = gu.shape
         assert gu.is_contiguous()
-        out = self.empty(rows, two_i // 2)
+        if out is None:
+            out = self.empty(rows, two_i // 2)
+        assert out.is_contiguous() and out.shape == (rows, two_i // 2)
         self.L.call("tr1_swiglu_fwd", _p(gu), _p(out), rows, two_i // 2, self._s())
         return out
 

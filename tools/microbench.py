@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel micro-benchmarks on one MI355X (HIP events on the launch stream). Usage: python tools/microbench.py <what> [...]
-   what: skinny | gemm | attn_decode | attn_train | small | sampler | all"""
+   what: skinny | fixup | fused | gemm | attn_decode | attn_train | small | sampler | all"""
 import os
 import sys
 
@@ -47,28 +47,6 @@ def skinny():
                 i[0] += 1
             us = timeit(f, reps=40)
             print("M=%2d N=%6d K=%6d  %8.1f us  %7.1f GB/s" % (M, N, K, us, (N * K * 2 + M * K * 2 + M * N * 2) / us / 1e3))
-
-
-def splitk():
-    """Raw C-ABI calls with pre-built arguments (the HipOps wrapper + allocator cost ~9 us per call, above the kernels measured here)."""
-    import ctypes
-    fn = ops.L.raw("tr1_gemm_skinny_splitk")
-    print("== decode GEMM split-K partials: us")
-    for M in (8, 16, 32):
-        for N, K in [(3584, 18944), (3584, 3584), (4608, 3584), (1536, 8960), (2048, 1536)]:
-            ws = [rnd(N, K) for _ in range(max(1, min(8, int(600e6 // (N * K * 2)))))]
-            x = rnd(M, K)
-            parts = torch.empty(16, M, N, device="cuda")
-            row = []
-            for ks in (1, 2, 3, 4, 6, 8):
-                argl = [(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(parts.data_ptr()), M, N, K, K, K, ks, None) for w in ws]
-                i = [0]
-
-                def f():
-                    fn(*argl[i[0] % len(argl)])
-                    i[0] += 1
-                row.append("ks%d %6.1f" % (ks, timeit(f, reps=100)))
-            print("M=%2d N=%6d K=%6d  " % (M, N, K) + "  ".join(row))
 
 
 def fixup():
@@ -196,5 +174,5 @@ def sampler():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     for w in what:
-        for name in (["skinny", "splitk", "fixup", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+        for name in (["skinny", "fixup", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
             globals()[name]()
