@@ -8,8 +8,17 @@
 //   CB = 1, PF = 3: split-KV decode.  A decode block sees only 2-3 tiles, so its time is a chain of memory latencies: with PF = 3
 //                   register sets all of its tiles are in flight at once (one latency instead of three), and 16 rows per wave keep
 //                   all four waves busy for the 56 packed rows of G = 8 x group 7.
+// optional block-timeline probe (tools/probe_attn.hip, -DTR1_PROBE); not compiled into the library
+#ifdef TR1_PROBE
+__device__ unsigned long long* tr1_probe = nullptr;
+#define TR1_PROBE_AT(slot) do { if (tr1_probe && threadIdx.x == 0) tr1_probe[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TR1_PROBE_AT(slot) do { } while (0)
+#endif
+
 template <int D, int CB, int PF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+    TR1_PROBE_AT(0);
     constexpr int KSTR = 2 * D + 16;
     {   // batched launch (decode over several prompts' caches): blockIdx.y = b * n_kv + kvh
         const int b = blockIdx.y / p.n_kv;
@@ -49,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
     const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
+    TR1_PROBE_AT(1);
     // a wave whose 32 rows are all out of range (decode: 56 live rows in a 128-row tile) only helps staging
     const bool wave_active = __builtin_amdgcn_readfirstlane((int)(R0 < nR)) != 0;
 
@@ -81,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         if (PF < n_my) tile_load_regs<D>(rg[0], p.K, p.k_ld, p.VT, p.vt_ld, kvh, TILE_KV0(PF), p.n_slots, p.d_real);
     }
     __syncthreads();
+    TR1_PROBE_AT(2);
 
     for (int it0 = 0; it0 < n_my; it0 += PF) {
 #pragma unroll
@@ -105,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                     for (int cb = 0; cb < CB; ++cb) s[kt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[cb][ks], s[kt][cb], 0, 0, 0);
                 }
             }
+            if (it == 0) TR1_PROBE_AT(5);     // QK^T of the first tile issued
             bf16x8_t pf[2][CB];
             // Tiles that every row of this wave sees completely (all shared-prefix tiles of completion rows, everything below the
             // diagonal of prompt rows) skip the per-element visibility test - a wave-uniform branch.
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 pf[0][cb] = pack_frag(s[0][cb], s[1][cb]);
                 pf[1][cb] = pack_frag(s[2][cb], s[3][cb]);
             }
+            if (it == 0) TR1_PROBE_AT(6);     // softmax of the first tile done
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) {
 #pragma unroll
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 }
             }
         }
+        if (it == 0) TR1_PROBE_AT(7);         // PV of the first tile issued
         if (it + 1 < n_my) {
             char* nk = dyn_lds + ((it + 1) & 1) * BUF;
             tile_store_lds<D>(rg[(j + 1) % PF], nk, nk + KBYTES, TILE_KV0(it + 1), p.n_slots, p.d_real);
@@ -176,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
 #undef TILE_KV0
 
+    TR1_PROBE_AT(3);
     // ---- epilogue. Lane holds O^T[d = dt*16 + g*4 + r][q = u].
     if (p.nsplit == 1) {
 #pragma unroll
@@ -207,6 +222,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             if (g == 0) { p.mpart[slot] = m[cb]; p.lpart[slot] = l[cb]; }
         }
     }
+    TR1_PROBE_AT(4);
+    // (An in-kernel merge of the split-KV partials by the last-arriving block was tried and dropped: on ONE CU the merge is a chain of
+    //  ~nsplit dependent load rounds, 38-80 us against 7.5 us for the separate 56-block combine launch below.)
 }
 
 // Merge split-KV partials. Block = 256 threads = 8 packed rows x 32 lanes; each lane owns D/32 groups of 4 features.
