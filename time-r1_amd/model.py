@@ -23,6 +23,8 @@ F32 = torch.float32
 class Engine:
     def __init__(self, cfg: ModelConfig, ops, params: ModelParams):
         self.cfg, self.ops, self.params = cfg, ops, params
+        self.overlap_wgrad = True
+        self._side = None
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
@@ -32,6 +34,26 @@ class Engine:
         dyt = ops.transpose(dy)          # [N, Mp]
         xt = ops.transpose(x)            # [K, Mp]
         ops.gemm_nt(dyt, xt, out_f32=True, out=gw, accumulate=True)
+
+    # Weight gradients of the decoder layers on a second HIP stream: wgrad (dy^T x) and dgrad (dy W) of a Linear only share their input,
+    # so the two GEMM chains run concurrently and each fills the CUs the other leaves idle in its last, partially filled round of tiles
+    # (M = 5074 rows against 128/256-row tiles: 1.5-2.2 rounds per GEMM).
+    def _side_stream(self):
+        if not getattr(self.ops, "device", None) or torch.device(self.ops.device).type != "cuda" or not self.overlap_wgrad:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.ops.device)
+        return self._side
+
+    def _wgrad_async(self, dy, x, gw, side):
+        if side is None:
+            return self._wgrad(dy, x, gw)
+        main = torch.cuda.current_stream(self.ops.device)
+        side.wait_stream(main)                         # dy (and every earlier write of gw) is ordered before the side work
+        with torch.cuda.stream(side):
+            self._wgrad(dy, x, gw)
+        dy.record_stream(side)                         # keep the caching allocator from recycling them under the side stream
+        x.record_stream(side)
 
     def _dgrad(self, dy, w):
         """dx[M,K] = dy[M,N] @ w[N,K]"""
@@ -250,19 +272,20 @@ class Engine:
         cos, sin = ctx["cos"], ctx["sin"]
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
         scale = hd ** -0.5
+        side = self._side_stream()
         for i in reversed(range(t.n_layers)):
             p = "l%d." % i
             L = ctx["layers"][i]
             M = dh.shape[0]
             # h_out = a @ Wd^T + h2
-            self._wgrad(dh, L["a"], tr.g(p + "down.w"))
+            self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), side)
             da = self._dgrad(dh, tr.w(p + "down.w"))
             dgu = ops.swiglu_bwd(da, L["gu"])
-            self._wgrad(dgu, L["xn2"], tr.g(p + "gu.w"))
+            self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), side)
             dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"))
             dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))
             # h2 = o @ Wo^T + h
-            self._wgrad(dh2, L["o"], tr.g(p + "o.w"))
+            self._wgrad_async(dh2, L["o"], tr.g(p + "o.w"), side)
             do = self._dgrad(dh2, tr.w(p + "o.w"))
             dqkv = ops.empty(M, t.qkv_dim)
             v = L["qkv"][:, qd + kvd:]
@@ -271,12 +294,16 @@ class Engine:
             ops.rope_apply(dq, t.n_heads, hd, cos, sin, backward=True, out=dqkv[:, :qd])
             ops.rope_apply(dk, t.n_kv_heads, hd, cos, sin, backward=True, out=dqkv[:, qd:qd + kvd])
             ops.colsum_accum(dqkv, tr.g(p + "qkv.b"))
-            self._wgrad(dqkv, L["xn"], tr.g(p + "qkv.w"))
+            self._wgrad_async(dqkv, L["xn"], tr.g(p + "qkv.w"), side)
             dxn = self._dgrad(dqkv, tr.w(p + "qkv.w"))
             dh = ops.rmsnorm_bwd(dxn, L["h"], tr.w(p + "ln1"), L["rstd1"], dres=dh2, dw=tr.g(p + "ln1"))
             ctx["layers"][i] = None  # release this layer's activations
             if on_layer_done is not None:
+                if side is not None:
+                    torch.cuda.current_stream(self.ops.device).wait_stream(side)     # this layer's weight gradients are final
                 on_layer_done(i)
+        if side is not None:
+            torch.cuda.current_stream(self.ops.device).wait_stream(side)
         return dh
 
     def embed_bwd(self, dh0, ids_for_grad, vid_rows=None):
