@@ -175,6 +175,34 @@ def test_saved_directory_loads_back_and_into_transformers(case, tmp_path):
     assert not missing.missing_keys and not missing.unexpected_keys
 
 
+def test_host_prefetch_thread_does_not_change_training(tmp_path):
+    """Host preprocessing on the prefetch thread vs inline: identical weights after two optimizer steps, and the
+    worker really ran ahead (its calls happen on another thread)."""
+    import threading
+    fx = load_case("grpo_beta")
+    masters, threads = [], []
+    for depth in (0, 3):
+        cfg, tr = make_trainer(fx, ga=2, dataloader_prefetch=depth)
+        tr.args.output_dir = str(tmp_path / ("pf%d" % depth))
+        tr.args.num_train_epochs = 1
+        tr.args.learning_rate = 1e-4
+        tr.train_dataset = _dataset(fx, 4)
+        seen = set()
+        orig = tr._host_prepare
+
+        def spy(inputs, orig=orig, seen=seen):
+            seen.add(threading.current_thread().name)
+            return orig(inputs)
+        tr._host_prepare = spy
+        tr.train()
+        assert tr.state.global_step == 2
+        masters.append(tr.params.train.master.clone())
+        threads.append(seen)
+    assert torch.equal(masters[0], masters[1])
+    assert threads[0] == {threading.current_thread().name}
+    assert all(n.startswith("tr1-prefetch") for n in threads[1])
+
+
 def test_gpu_video_preprocess_path_equals_processor_path():
     """uint8 frames through ops.video_preprocess (fused kernel on the GPU, its oracle here) == frames through the processor's pixel path."""
     fx = load_case("grpo_beta")

@@ -79,6 +79,7 @@ class GRPOConfig:
     rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
     grad_wire_dtype: str = "bf16"           # data-parallel gradient all-reduce wire format ("bf16" | "fp32")
     gpu_video_preprocess: bool = False      # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path
+    dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
     learning_rate: float = 1e-6
@@ -315,8 +316,10 @@ class TimeR1_Trainer:
             self.core.rollout(ctx["st"])
         return self._step_finish(ctx)
 
-    def _step_prepare(self, inputs):
-        """Host preprocessing + vision tower for one micro-step (one prompt: reference facts :524, :548-551)."""
+    def _host_prepare(self, inputs):
+        """Host half of a micro-step's preparation (no GPU work): chat template, video decode / frame sampling / resize (or only the size
+        plan when the pixels are produced on the GPU), processor call.  Runs inline or on the prefetch thread (decode and
+        resize leave the step's critical path)."""
         example = inputs[0]
         prompts = [self.make_conversation_video(ex) for ex in inputs]
         prompts_text = [self.processing_class.apply_chat_template(p, tokenize=False, add_generation_prompt=True) for p in prompts]
@@ -326,18 +329,28 @@ class TimeR1_Trainer:
             ele = {"total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}
             T, _, H, W = frames.shape
             th, tw = VP.video_target_size(ele, T, H, W)
+            return dict(prompts=prompts, text=prompts_text, gpu_frames=frames.contiguous(), target=(th, tw))
+        video_inputs, fps_inputs = self._video_inputs(example)
+        prompt_inputs = self.processing_class(text=[prompts_text[0]], images=None, videos=[video_inputs[0]], fps=[fps_inputs[0]], padding=True,
+                                              return_tensors="pt", padding_side="left", add_special_tokens=False)
+        return dict(prompts=prompts, text=prompts_text, ids=np.asarray(prompt_inputs["input_ids"]).reshape(-1),
+                    pixels=prompt_inputs["pixel_values_videos"], grid=np.asarray(prompt_inputs["video_grid_thw"]))
+
+    def _step_prepare(self, inputs):
+        """Host preprocessing + vision tower for one micro-step (one prompt: reference facts :524, :548-551)."""
+        example = inputs[0]
+        hp = example.pop("_host_prepared", None) if isinstance(example, dict) else None
+        hp = hp.result() if hp is not None else self._host_prepare(inputs)
+        prompts, prompts_text = hp["prompts"], hp["text"]
+        if "gpu_frames" in hp:
             v = self.cfg.vision
-            pixels, grid = self.ops.video_preprocess(frames.to(self.ops.device).contiguous(), (th, tw), v.patch_dim_padded, v.patch_size,
+            pixels, grid = self.ops.video_preprocess(hp["gpu_frames"].to(self.ops.device), hp["target"], v.patch_dim_padded, v.patch_size,
                                                      v.temporal_patch_size, v.spatial_merge_size)
             n_tok = grid[0] * grid[1] * grid[2] // v.merge_unit
             ids = np.asarray(self._prompt_ids(prompts_text[0], n_tok)).reshape(-1)
             st = self.core.prepare(ids, pixels, np.asarray([grid]))
         else:
-            video_inputs, fps_inputs = self._video_inputs(example)
-            prompt_inputs = self.processing_class(text=[prompts_text[0]], images=None, videos=[video_inputs[0]], fps=[fps_inputs[0]], padding=True,
-                                                  return_tensors="pt", padding_side="left", add_special_tokens=False)
-            ids = np.asarray(prompt_inputs["input_ids"]).reshape(-1)
-            st = self.core.prepare(ids, prompt_inputs["pixel_values_videos"], np.asarray(prompt_inputs["video_grid_thw"]))
+            st = self.core.prepare(hp["ids"], hp["pixels"], hp["grid"])
         forced = example.get("_forced_completion_ids")       # test hook: teacher-forced completions instead of sampling
         if forced is not None:
             from .positions import PackedLayout
@@ -445,6 +458,38 @@ class TimeR1_Trainer:
             return base * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
         return base * max(0.0, 1.0 - prog)     # linear (HF default)
 
+    def _prefetching(self, loader, skip=0):
+        """Iterate `loader` while a worker thread runs _host_prepare for the next `dataloader_prefetch` batches (video decode / resize /
+        tokenisation overlap the GPU step; results travel with the batch under the private key `_host_prepared`)."""
+        import collections
+        import itertools
+        depth = int(getattr(self.args, "dataloader_prefetch", 0) or 0)
+        it = itertools.islice(iter(loader), skip, None)
+        if depth <= 0:
+            yield from it
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tr1-prefetch")
+        q = collections.deque()
+
+        def fill():
+            while len(q) < depth:
+                try:
+                    b = next(it)
+                except StopIteration:
+                    return
+                b = [dict(ex) for ex in b]                # private copy: the future is attached to the row
+                b[0]["_host_prepared"] = pool.submit(self._host_prepare, b)
+                q.append(b)
+        try:
+            fill()
+            while q:
+                b = q.popleft()
+                fill()
+                yield b
+        finally:
+            pool.shutdown(wait=False, cancel_futures=True)
+
     def training_step(self, inputs):
         return self.compute_loss(self.params, inputs)
 
@@ -471,10 +516,9 @@ class TimeR1_Trainer:
         epoch = 0
         while not self.control.should_training_stop and self.state.global_step < self.state.max_steps:
             window = []
-            for batch in loader:
-                if micro_seen < skip_micro:       # resume: replay the sampler, skip consumed batches
-                    micro_seen += 1
-                    continue
+            to_skip = max(0, skip_micro - micro_seen)      # resume: replay the sampler, skip consumed batches (before any prefetch work)
+            micro_seen += min(to_skip, len(loader))
+            for batch in self._prefetching(loader, to_skip):
                 micro_seen += 1
                 window.append(batch)
                 if len(window) < ga:
