@@ -79,7 +79,7 @@ class HipOps:
         self._chk(x, lnw, w, bias)
         M, K = x.shape
         N = w.shape[0] // 2 if glu else w.shape[0]
-        assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and lnw.numel() == K and M <= 64
+        assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and lnw.numel() == K
         out = self.empty(M, N)
         self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), int(glu), self._s())
         return out
