@@ -55,6 +55,8 @@ class Workload:
         self.ref = self.params.train.clone_weights_only() if args.beta != 0.0 else None
         self.core = GRPOCore(self.eng, self.ref, args.G, args.C, beta=args.beta, use_grpo=not args.clip_loss, temperature=1.0, top_k=50,
                              seed=1234 + rank, rope_index_mode="hf4")
+        if args.rollout_fp8:
+            self.core.roll.weight_dtype = "fp8"
         from time_r1_amd.optim import AdamWFlat
         self.opt = AdamWFlat(self.params, ops, lr=1e-6, dp=DataParallel())
         grid = GRIDS[args.frames] if args.model != "tiny" else (2, 4, 6)
@@ -249,6 +251,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
+    ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only)")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: all-reduce the gradient arena after backward instead of during it")
     args = ap.parse_args()
 
@@ -303,7 +306,8 @@ def main():
             "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step" % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta,
                                                                                     "ppo-clip" if args.clip_loss else "grpo", args.ga),
-                       "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga},
+                       "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
+                       "rollout_weight_dtype": "fp8-e4m3 (sampling policy only)" if args.rollout_fp8 else "bf16"},
         }
     # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step
     if not args.no_roofline:

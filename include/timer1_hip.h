@@ -105,6 +105,15 @@ int tr1_decode_qkv_post(const void* qkv, int64_t ld, const void* cosb, const voi
 /* KV-cache append: dst[slots[t], :] = src[t, :] */
 int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const void* slots, int64_t T, int64_t cols, void* stream);
 
+/* ---- fp8 weight storage for the rollout (BASELINE config "fp8 weights") --------------------------------------------------------------- */
+/* Per-row symmetric quantisation to OCP fp8 e4m3: scale[n] = amax_n / 448 (1 for a zero row), q = rne(w * 448 / amax_n).  Run once per
+ * optimizer step on the decoder matrices; only the SAMPLING policy of generate (timer1_trainer.py:568-573) reads the fp8 copy. */
+int tr1_quantize_fp8_rows(const void* w_bf16, int64_t ldw, void* q_fp8, int64_t ldq, void* scale_f32, int64_t N, int64_t K, void* stream);
+/* Decode rows (M <= 64) against fp8 weights, dequantised to bf16 in registers (W8A16): out = act(x) W^T * scale (+bias)(+residual).
+ * lnw != NULL folds rmsnorm(x; lnw, eps) into the operand load; glu != 0: W_fp8 is [2N, K] (gate rows then up rows), out = silu(gate)*up.
+ * Same call sites as tr1_gemm_nt_bf16 / tr1_norm_gemm_skinny inside generate.  K % 128 == 0. */
+int tr1_gemm_skinny_w8(const void* x, const void* lnw, const void* W_fp8, const void* wscale, const void* bias, const void* residual, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, float eps, int glu, void* stream);
+
 /* ---- native decode-step driver ------------------------------------------------------------------------------------------------ */
 /* One call enqueues a whole rollout decode step for R <= 64 rows: embed gather -> n_layers x {norm+qkv, rope + KV append, split-KV attention,
  * o_proj + residual, norm + gate/up + SwiGLU, down_proj + residual} -> final norm + lm_head -> logits[R, vocab] (bf16).
@@ -116,6 +125,9 @@ int tr1_scatter_slots(const void* src, int64_t ld_src, void* dst, int64_t ld_dst
  * ZERO-FILLED once by the caller before the first step (it holds self re-arming split-K ticket counters). */
 int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 int64_t tr1_decode_step_workspace_bytes(const int64_t* dims);
+/* Same step with fp8 weights (tr1_quantize_fp8_rows): 13 pointers per layer {ln1, qkv.q, qkv.b, o.q, ln2, gu.q, down.q, K cache, V^T cache,
+ * qkv.scale, o.scale, gu.scale, down.scale}; lm_head_fp8 / lm_head_scale likewise.  Embedding, norms, biases, KV cache stay bf16. */
+int tr1_decode_step_w8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 
 /* ---- video preprocessing (SURVEY 8f "next" row 1) ------------------------------------------------------------------------ */
 /* ref: torchvision resize(BICUBIC, antialias) at src/utils/vision_process.py:467-472 + Qwen2VLVideoProcessor rescale/normalize/patchify

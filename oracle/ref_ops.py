@@ -138,6 +138,33 @@ class RefOps:
         return self._a(dx)
 
     # ---- activations (ref: TF:459-466 SwiGLU; TF:277-290 GELU; TF:293-301 quick_gelu)
+    def quantize_fp8_rows(self, w, q=None, scale=None):
+        """Per-row symmetric OCP e4m3 quantisation, same arithmetic as csrc/gemm_w8.hip (fp32: inv = 448 / amax, q = rne(w * inv))."""
+        wf = w.float()
+        amax = wf.abs().amax(1)
+        ok = amax > 0
+        c448 = torch.full_like(amax, 448.0)
+        inv = torch.where(ok, c448 / amax, torch.ones_like(amax))      # tensor / tensor: correctly rounded (scalar / tensor is rcp * scalar in torch)
+        sc = torch.where(ok, amax / c448, torch.ones_like(amax))
+        qq = (wf * inv[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+        if q is not None:
+            q.copy_(qq); qq = q
+        if scale is not None:
+            scale.copy_(sc); sc = scale
+        return qq, sc
+
+    def gemm_w8(self, x, q, scale, lnw=None, eps=1e-6, bias=None, residual=None, glu=False):
+        wd = q.view(torch.float8_e4m3fn).float()            # exactly representable in bf16: the kernel's register dequantisation is lossless
+        if lnw is not None:
+            x, _, _ = self.rmsnorm_fwd(x, lnw, eps, need_rstd=False)
+        y = (x.float() @ wd.t()) * scale.float()[None, :]
+        if bias is not None:
+            y = y + bias.float()
+        if residual is not None:
+            y = y + residual.float()
+        y = self._a(y)
+        return self.swiglu_fwd(y) if glu else y
+
     def norm_gemm(self, x, lnw, eps, w, bias=None, glu=False):
         xn, _, _ = self.rmsnorm_fwd(x, lnw, eps, need_rstd=False)
         y = self.gemm_nt(xn, w, bias=bias)

@@ -412,7 +412,7 @@ def test_video_preprocess_fused(hip_ops, ref_ops, T, H, W, Ho, Wo):
     assert float((err > 0.009).float().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("M,N,K,glu", [(8, 512, 256, False), (16, 4608, 3584, False), (5, 72, 320, False), (16, 1024, 3584, True), (13, 200, 512, True),
+@pytest.mark.parametrize("M,N,K,glu", [(8, 512, 256, False), (16, 4608, 3584, False), (16, 100032, 256, False), (32, 100096, 320, False), (5, 72, 320, False), (16, 1024, 3584, True), (13, 200, 512, True),
                                        (32, 4608, 3584, False), (24, 1024, 1536, True), (64, 512, 3584, False), (40, 136, 832, True)])
 def test_norm_gemm_fused(hip_ops, ref_ops, M, N, K, glu):
     """rmsnorm folded into the decode GEMM (and SwiGLU into its epilogue) vs the unfused oracle composition."""
@@ -449,3 +449,37 @@ def test_gemm_skinny_fixup(hip_ops, M, N, K):
         assert (got - want).abs().max() <= 2.0 ** -7 * max(1.0, float(want.abs().max())), rep
     plain = hip_ops.gemm_skinny_fixup(a, b).float()
     assert (plain - a.float() @ b.float().t()).abs().max() <= 0.02 + 0.01 * ref.abs().max()
+
+
+@pytest.mark.parametrize("N,K", [(64, 128), (200, 3584), (37, 18944), (16, 256)])
+def test_quantize_fp8_rows_bit_exact(hip_ops, ref_ops, N, K):
+    """Row-wise e4m3 quantiser: codes and scales equal torch's float8_e4m3fn cast of the same fp32 products (integer/byte work: bit exact)."""
+    w = rnd(N, K, seed=11, scale=0.05)
+    w[3 % N] = 0                                    # an all-zero row: scale 1, codes 0
+    w[5 % N, 7] = 3.0                               # an outlier that sets the row scale
+    q, sc = hip_ops.quantize_fp8_rows(w.cuda())
+    rq, rsc = ref_ops.quantize_fp8_rows(w.float())
+    assert torch.equal(sc.cpu(), rsc)
+    assert torch.equal(q.cpu(), rq)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(16, 4608, 3584, "norm"), (8, 512, 256, "plain"), (16, 3584, 18944, "res"), (16, 1024, 3584, "glu"),
+                                        (32, 4608, 3584, "norm"), (24, 512, 1536, "glu"), (64, 512, 3584, "res"), (5, 72, 384, "plain"), (40, 136, 1024, "glu")])
+def test_gemm_w8(hip_ops, ref_ops, M, N, K, mode):
+    """fp8-weight decode GEMM (register dequantisation, bf16 MFMA) vs the oracle on the SAME quantised weights."""
+    glu = mode == "glu"
+    x = rnd(M, K, seed=1, scale=2.0 if mode in ("norm", "glu") else 1.0)
+    w = rnd(2 * N if glu else N, K, seed=3, scale=1.5 / math.sqrt(K) if glu else 0.1)
+    lnw = (1.0 + 0.1 * rnd(K, seed=2).float()).to(BF16) if mode in ("norm", "glu") else None
+    bias = rnd(N, seed=4) if mode in ("norm", "plain") else None
+    res = rnd(M, N, seed=5) if mode == "res" else None
+    q, sc = hip_ops.quantize_fp8_rows(w.cuda())
+    c = lambda t: None if t is None else t.cuda()
+    f = lambda t: None if t is None else t.float()
+    h = hip_ops.gemm_w8(x.cuda(), q, sc, lnw=c(lnw), eps=1e-6, bias=c(bias), residual=c(res), glu=glu)
+    r = ref_ops.gemm_w8(x.float(), q.cpu(), sc.cpu(), lnw=f(lnw), eps=1e-6, bias=f(bias), residual=f(res), glu=glu)
+    close(h, r, 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=0.02, what="gemm_w8 %s" % mode)
+    # the quantisation itself: within the e4m3 step of the bf16 GEMM (3 mantissa bits -> ~3 % rms per weight, averaged over K)
+    if mode == "plain":
+        full = x.float() @ w.float().t() + bias.float()
+        assert (h.float().cpu() - full).norm() / full.norm() < 0.05

@@ -471,17 +471,17 @@ TR1_DEV bf16x8_t scale_frag_sumsq(bf16x8_t x, bf16x8_t w, float& ss) {
     return __builtin_bit_cast(bf16x8_t, o);
 }
 
-template <int WAVES, int UNROLL, int MG, bool GLU>
+template <int WAVES, int UNROLL, int MG, bool GLU, int NCOL = 2>
 __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
                                                                       const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                       const bf16_t* __restrict__ bias, int M, int64_t N, int64_t K, int64_t ldx,
                                                                       int64_t ldw, int64_t ldc, float eps, int64_t up_off) {
-    constexpr int NCOL = 2;
+    static_assert(!GLU || NCOL == 2, "GLU pairs one gate and one up column group");
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ float ssred[WAVES][MG][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * (GLU ? 16 : 32);
+    const int64_t n0 = (int64_t)blockIdx.x * (GLU ? 16 : 16 * NCOL);
     const bf16_t* wp[NCOL];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
@@ -597,6 +597,13 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
                        dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W, (bf16_t*)out, (const bf16_t*)bias, \
                        (int)M, N, K, ldx, ldw, ldc, eps, N)
     if (glu) { if (M <= 16) NG(4, 4, 1, true); else if (M <= 32) NG(4, 2, 2, true); else NG(4, 2, 4, true); }
+    else if (N >= 100000 && M <= 32) {      // lm_head: 4 column groups per block halve the re-reads of x (228 -> ~195 us at M = 16)
+#define NG4(UN, MGR)                                                                                                                 \
+    hipLaunchKernelGGL((norm_gemm_skinny_kernel<4, UN, MGR, false, 4>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, (const bf16_t*)x,    \
+                       (const bf16_t*)lnw, (const bf16_t*)W, (bf16_t*)out, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, ldc, eps, N)
+        if (M <= 16) NG4(2, 1); else NG4(2, 2);
+#undef NG4
+    }
     else     { if (M <= 16) NG(4, 4, 1, false); else if (M <= 32) NG(4, 2, 2, false); else NG(4, 2, 4, false); }
 #undef NG
     TR1_LAUNCH_CHECK();

@@ -1,0 +1,250 @@
+// FP8 (OCP e4m3) weight storage for the rollout's decode GEMMs (BASELINE config "fp8 weights"): the decode step is bound by streaming the
+// weights from HBM, so halving their bytes is worth more than any arithmetic.  Weights are quantised per output row
+// (scale[n] = amax_n / 448) once per optimizer step; the decode kernels read 16 fp8 per lane (one 16-byte load), convert them to bf16 in
+// registers (v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32, ~20 % of the VALU at the HBM-bound rate) and run the same bf16 MFMA tiles against bf16
+// activations (W8A16): activations keep their precision, the row scale is applied to the fp32 accumulator in the epilogue.
+// Only the SAMPLING policy is quantised - log-probs, KL and the update use the bf16 weights.
+//
+// Kernel structure = gemm_skinny_kernel / norm_gemm_skinny_kernel (gemm.hip) with a 128-element k-step:
+//   lane (u, g) of a 16-row weight fragment loads W[row u][k0 + h*64 + g*16 .. +16] (h = 0, 1) and splits it into two bf16x8 MFMA operands
+//   (bytes 0-7, bytes 8-15); the activation fragments are loaded from the same k positions, so any k permutation cancels.
+#include "tr1_common.h"
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+TR1_DEV void fp8x16_to_bf16(u32x4_t q, bf16x8_t& lo, bf16x8_t& hi) {
+    u32x4_t a, b;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {        // dwords 0,1 -> lo (k 0..7); dwords 2,3 -> hi (k 8..15)
+        const f32x2_t p0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[w], false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[w], true);
+        a[2 * w] = pack2bf(p0[0], p0[1]); a[2 * w + 1] = pack2bf(p1[0], p1[1]);
+        const f32x2_t r0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[2 + w], false), r1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)q[2 + w], true);
+        b[2 * w] = pack2bf(r0[0], r0[1]); b[2 * w + 1] = pack2bf(r1[0], r1[1]);
+    }
+    lo = __builtin_bit_cast(bf16x8_t, a); hi = __builtin_bit_cast(bf16x8_t, b);
+}
+
+TR1_DEV float silu_w8(float x) { return x / (1.f + __expf(-x)); }
+TR1_DEV bf16x8_t scale_frag_sumsq_w8(bf16x8_t x, bf16x8_t w, float& ss) {
+    const u32x4_t xu = __builtin_bit_cast(u32x4_t, x), wu = __builtin_bit_cast(u32x4_t, w);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = bflo(xu[e]), b = bfhi(xu[e]);
+        ss = fmaf(a, a, fmaf(b, b, ss));
+        o[e] = pack2bf(a * bflo(wu[e]), b * bfhi(wu[e]));
+    }
+    return __builtin_bit_cast(bf16x8_t, o);
+}
+
+// out[M, N] = act(x)[M, K] * dequant(W)[N, K]^T (* wscale[n]) (+ bias) (+ residual);  NORM: act = rmsnorm(.; lnw) folded in;  GLU: W holds
+// gate rows then up rows (up_off apart) and out = silu(gate) * up.
+template <int WAVES, int UNROLL, int NCOL, int MG, bool NORM, bool GLU>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
+                                                                    const unsigned char* __restrict__ W, const float* __restrict__ wscale,
+                                                                    bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
+                                                                    const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
+                                                                    int64_t ldw, int64_t ldc, int64_t ldr, float eps, int64_t up_off) {
+    static_assert(!GLU || NCOL % 2 == 0, "GLU: NCOL/2 gate column groups + the matching NCOL/2 up groups");
+    constexpr int NOUT = GLU ? NCOL / 2 : NCOL;          // output column groups per block
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
+    __shared__ float ssred[WAVES][MG][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16 * NOUT;
+    const unsigned char* wp[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        int64_t wrow = n0 + (c % NOUT) * 16 + u;
+        if (wrow >= N) wrow = N - 1;
+        if (GLU && c >= NOUT) wrow += up_off;
+        wp[c] = W + wrow * ldw + g * 16;
+    }
+    const bf16_t* xp[MG];      // rows >= M re-read row M-1; their outputs are never stored
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (int64_t)(mg * 16 + u < M ? mg * 16 + u : (M - 1)) * ldx + g * 16;
+    const bf16_t* lp = NORM ? lnw + g * 16 : nullptr;
+    const int64_t nsteps = K / 128;
+    const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
+    const int64_t s0 = wave * s_per;
+    int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
+    f32x4_t acc[NCOL][MG];
+    float ss[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        ss[mg] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[c][mg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t s = s0; s < s1; s += UNROLL) {
+        u32x4_t wq[UNROLL][NCOL][2];
+        bf16x8_t xa[UNROLL][MG][2][2], la[UNROLL][2][2];
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            const int64_t st = s + q < s1 ? s + q : s1 - 1;          // surplus buffers of the last trip re-read the final step (unused)
+            const int64_t k = st * 128;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) wq[q][c][h] = *reinterpret_cast<const u32x4_t*>(wp[c] + k + h * 64);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    xa[q][mg][h][0] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + h * 64);
+                    xa[q][mg][h][1] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k + h * 64 + 8);
+                }
+                if (NORM) {
+                    la[q][h][0] = *reinterpret_cast<const bf16x8_t*>(lp + k + h * 64);
+                    la[q][h][1] = *reinterpret_cast<const bf16x8_t*>(lp + k + h * 64 + 8);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            if (s + q < s1) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8_t xf[MG][2];
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            xf[mg][j] = NORM ? scale_frag_sumsq_w8(xa[q][mg][h][j], la[q][h][j], ss[mg]) : xa[q][mg][h][j];
+#pragma unroll
+                    for (int c = 0; c < NCOL; ++c) {
+                        bf16x8_t w0, w1;
+                        fp8x16_to_bf16(wq[q][c][h], w0, w1);
+#pragma unroll
+                        for (int mg = 0; mg < MG; ++mg) {
+                            acc[c][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xf[mg][0], acc[c][mg], 0, 0, 0);
+                            acc[c][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xf[mg][1], acc[c][mg], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        if (NORM) {
+            float v = ss[mg];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) ssred[wave][mg][u] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][r];
+    }
+    __syncthreads();
+    const float inv_k = 1.f / (float)K;
+    for (int i = threadIdx.x; i < NOUT * MG * 256; i += WAVES * 64) {   // (output column group, row group, m, n)
+        const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
+        const int m = mg * 16 + mm;
+        const int64_t n = n0 + c * 16 + nn;
+        if (m < M && n < N) {
+            float sq = 0.f, v = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                if (NORM) sq += ssred[w][mg][mm];
+                v += red[w][c][mg][mm][nn];
+                if (GLU) v2 += red[w][NOUT + c][mg][mm][nn];
+            }
+            const float rstd = NORM ? rsqrtf(sq * inv_k + eps) : 1.f;
+            v *= rstd * wscale[n];
+            if (GLU) {
+                const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd * wscale[up_off + n]));
+                C[(int64_t)m * ldc + n] = f2bf(bf2f(f2bf(silu_w8(gt))) * up);
+            } else {
+                if (bias) v += bf2f(bias[n]);
+                if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
+                C[(int64_t)m * ldc + n] = f2bf(v);
+            }
+        }
+    }
+}
+
+// Per-row symmetric quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = fp8_e4m3(w * (448 / amax_n)), round to nearest even.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ w, unsigned char* __restrict__ q, float* __restrict__ scale,
+                                                             int64_t K, int64_t ldw, int64_t ldq) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const bf16_t* src = w + row * ldw;
+    float amax = 0.f;
+    for (int64_t k = threadIdx.x * 8; k < K; k += 256 * 8) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bflo(v[e])), fabsf(bfhi(v[e]))));
+    }
+    amax = block_max(amax, red);
+    // correctly rounded divisions (hipcc's default fp32 '/' is a 2.5-ulp reciprocal sequence): codes must be reproducible bit for bit
+    const float inv = amax > 0.f ? __fdiv_rn(448.0f, amax) : 1.0f;
+    if (threadIdx.x == 0) scale[row] = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;
+    unsigned char* dst = q + row * ldq;
+    for (int64_t k = threadIdx.x * 8; k < K; k += 256 * 8) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + k);
+        int lo = 0, hi = 0;            // v_cvt_pk_fp8_f32: round to nearest even, two codes per instruction
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bflo(v[0]) * inv, bfhi(v[0]) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bflo(v[1]) * inv, bfhi(v[1]) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bflo(v[2]) * inv, bfhi(v[2]) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bflo(v[3]) * inv, bfhi(v[3]) * inv, hi, true);
+        u32x2_t o = {(unsigned)lo, (unsigned)hi};
+        *reinterpret_cast<u32x2_t*>(dst + k) = o;
+    }
+}
+
+extern "C" int tr1_quantize_fp8_rows(const void* w_bf16, int64_t ldw, void* q_fp8, int64_t ldq, void* scale_f32, int64_t N, int64_t K, void* stream) {
+    TR1_CHECK_ARG(K % 8 == 0 && ldw % 8 == 0 && ldq % 8 == 0, "quantize_fp8_rows: K and leading dimensions must be multiples of 8");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_bf16, (unsigned char*)q_fp8,
+                       (float*)scale_f32, K, ldw, ldq);
+    TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_gemm_skinny_w8(const void* x, const void* lnw, const void* W_fp8, const void* wscale, const void* bias, const void* residual,
+                                  void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, float eps,
+                                  int glu, void* stream) {
+    TR1_CHECK_ARG(K % 128 == 0 && K >= 128, "gemm_skinny_w8: K must be a positive multiple of 128");
+    TR1_CHECK_ARG(M >= 1 && M <= 64, "gemm_skinny_w8: 1 <= M <= 64 (decode rows)");
+    TR1_CHECK_ARG(N % 8 == 0 && ldx % 8 == 0 && ldw % 16 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_skinny_w8: N%8, ldx%8, ldw%16, ldc%8");
+    TR1_CHECK_ARG(!glu || (lnw && !bias && !residual), "gemm_skinny_w8: the GLU form is norm + gate/up only");
+    hipStream_t s = (hipStream_t)stream;
+    const int mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+#define W8(WV, UN, NC, MGR, NRM, GL)                                                                                                       \
+    hipLaunchKernelGGL((gemm_skinny_w8_kernel<WV, UN, NC, MGR, NRM, GL>), dim3((unsigned)((N + (GL ? 8 * NC : 16 * NC) - 1) / (GL ? 8 * NC : 16 * NC))), \
+                       dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, (const unsigned char*)W_fp8, (const float*)wscale,       \
+                       (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, ldx, ldw, ldc, ldr, eps, N)
+#define W8_MG(WV, UN, NC, NRM, GL)                                                         \
+    do { if (mg == 1) W8(WV, UN, NC, 1, NRM, GL); else if (mg == 2) W8(WV, UN, NC, 2, NRM, GL); else W8(WV, 1, NC, 4, NRM, GL); } while (0)
+    {   // tuning hook for tools/microbench.py w8: TR1_W8_CFG=<waves><unroll><ncol> (M <= 16 only)
+        static int cfg = -1;
+        if (cfg < 0) { const char* e = getenv("TR1_W8_CFG"); cfg = e ? atoi(e) : 0; }
+        if (cfg && !glu && M <= 16) {
+            const bool nrm = lnw != nullptr;
+#define W8C(WV, UN, NC) do { if (nrm) W8(WV, UN, NC, 1, true, false); else W8(WV, UN, NC, 1, false, false); TR1_LAUNCH_CHECK(); } while (0)
+            switch (cfg) {
+                case 442: W8C(4, 4, 2);
+                case 424: W8C(4, 2, 4);
+                case 444: W8C(4, 4, 4);
+                case 822: W8C(8, 2, 2);
+                case 824: W8C(8, 2, 4);
+                case 814: W8C(8, 1, 4);
+                case 842: W8C(8, 4, 2);
+                case 441: W8C(4, 4, 1);
+                case 841: W8C(8, 4, 1);
+                default: break;
+            }
+#undef W8C
+        }
+    }
+    // column groups per block: the activations are re-read from L2 by every block, and with fp8 weights they are as many bytes as a
+    // 2-group weight slab - 4 groups halve that traffic (measured, M = 16: lm_head 168 -> 140 us)
+    if (glu) { if (mg == 1) W8(4, 2, 4, 1, true, true); else if (mg == 2) W8(4, 2, 4, 2, true, true); else W8(4, 1, 2, 4, true, true); }
+    else if (lnw && N >= 100000) { if (mg == 1) W8(4, 2, 4, 1, true, false); else if (mg == 2) W8(4, 2, 4, 2, true, false); else W8(4, 1, 2, 4, true, false); }
+    else if (lnw) W8_MG(4, 2, 2, true, false);
+    else if (K >= 8192) W8_MG(8, 2, 1, false, false);
+    else W8_MG(4, 2, 1, false, false);
+#undef W8_MG
+#undef W8
+    TR1_LAUNCH_CHECK();
+}

@@ -84,27 +84,57 @@ class HipOps:
         self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), int(glu), self._s())
         return out
 
+    # ---- fp8 weight storage (rollout only) -------------------------------------------------------------------------------
+    def quantize_fp8_rows(self, w, q=None, scale=None):
+        """bf16 [N, K] -> (fp8 e4m3 bytes uint8 [N, K], fp32 row scales [N]); q/scale may be preallocated views."""
+        self._chk(w)
+        N, K = w.shape
+        assert w.stride(1) == 1
+        if q is None:
+            q = torch.empty(N, K, dtype=torch.uint8, device=self.device)
+        if scale is None:
+            scale = self.empty(N, dtype=F32)
+        assert q.dtype == torch.uint8 and q.shape == (N, K) and q.stride(1) == 1 and scale.dtype == F32 and scale.numel() == N
+        self.L.call("tr1_quantize_fp8_rows", _p(w), w.stride(0), _p(q), q.stride(0), _p(scale), N, K, self._s())
+        return q, scale
+
+    def gemm_w8(self, x, q, scale, lnw=None, eps=1e-6, bias=None, residual=None, glu=False):
+        """Decode rows x fp8 weights (W8A16): act(x) @ dequant(q)^T * scale (+bias)(+residual); lnw folds rmsnorm in; glu: silu(gate)*up."""
+        self._chk(x, lnw, bias, residual)
+        M, K = x.shape
+        N = q.shape[0] // 2 if glu else q.shape[0]
+        assert q.dtype == torch.uint8 and q.shape[1] == K and x.stride(1) == 1 and q.stride(1) == 1 and scale.dtype == F32
+        out = self.empty(M, N)
+        self.L.call("tr1_gemm_skinny_w8", _p(x), _p(lnw), _p(q), _p(scale), _p(bias), _p(residual), _p(out), M, N, K, x.stride(0), q.stride(0), N,
+                    residual.stride(0) if residual is not None else 0, float(eps), int(glu), self._s())
+        return out
+
     # ---- native decode-step driver ------------------------------------------------------------------------------------
     def decode_plan(self, layers, hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit):
         """layers: per decoder layer the 9 tensors (ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache, V^T cache).  Builds the host
         pointer table + device scratch once per rollout; decode_step then costs one C call per generated token."""
         import ctypes
         flat = [t for L in layers for t in L]
-        assert len(flat) == 9 * len(layers)
-        self._chk(*flat)
+        per = len(flat) // max(len(layers), 1)
+        assert per in (9, 13) and len(flat) == per * len(layers)      # 13 = fp8 matrices + their row scales (decode_step_w8)
         ptrs = (ctypes.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
         dims = (ctypes.c_int64 * 11)(len(layers), hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit)
         nbytes = int(self.L.raw("tr1_decode_step_workspace_bytes")(dims))
         work = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)     # zero: the split-K ticket counters inside start disarmed
         logits = self.empty(rows, vocab)
         return dict(ptrs=ptrs, ptrs_p=ctypes.cast(ptrs, ctypes.c_void_p), dims=dims, work=work, work_p=work.data_ptr(), nbytes=nbytes,
-                    logits=logits, logits_p=logits.data_ptr(), keep=flat, stream=self._s())
+                    logits=logits, logits_p=logits.data_ptr(), keep=flat, stream=self._s(), w8=per == 13)
 
     def decode_step(self, plan, embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p, eps, scale):
         """All arguments after `plan` are raw device addresses (ints): the caller precomputes row pointers into its step tables.
         Returns plan["logits"] [rows, vocab] (overwritten every step)."""
-        self.L.call("tr1_decode_step", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p,
-                    plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
+        if plan["w8"]:
+            lm_q, lm_s = lm_head_p                  # (fp8 codes address, row scales address)
+            self.L.call("tr1_decode_step_w8", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_q, lm_s, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p,
+                        hi_p, plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
+        else:
+            self.L.call("tr1_decode_step", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p,
+                        plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
         return plan["logits"]
 
     def gemm_skinny_fixup(self, a, b, bias=None, residual=None):

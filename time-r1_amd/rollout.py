@@ -37,6 +37,8 @@ class Rollout:
         self._cache = None
         self.calls = 0
         self.native_decode = True     # one native call per decode step (HipOps); False = op-by-op from the host (tests compare the two)
+        self.weight_dtype = "bf16"    # "fp8": decode GEMMs read an e4m3 copy of the decoder matrices + lm_head (row scales), re-quantised per call
+        self._w8 = None
 
     def _kv(self, B, s_cap):
         t = self.eng.cfg.text
@@ -45,6 +47,23 @@ class Rollout:
             self._cache = None      # release before re-allocating
             c = self._cache = KVCache(self.eng.ops, t.n_layers, t.kv_dim, s_cap, B)
         return c
+
+    MATS = ("qkv.w", "o.w", "gu.w", "down.w")
+
+    def _quantize(self, arena, w_lm):
+        """fp8 copies of the decode weights for THIS rollout (the weights change every optimizer step).  Only the sampling policy sees
+        them: prefill, log-probs and the update keep bf16.  Buffers are allocated once and reused."""
+        ops, t = self.eng.ops, self.eng.cfg.text
+        if self._w8 is None:
+            shapes = {"qkv.w": (t.qkv_dim, t.hidden), "o.w": (t.hidden, t.q_dim), "gu.w": (2 * t.intermediate, t.hidden), "down.w": (t.hidden, t.intermediate)}
+            self._w8 = dict(layers=[{n: (torch.empty(*shapes[n], dtype=torch.uint8, device=ops.device), ops.empty(shapes[n][0], dtype=torch.float32))
+                                     for n in self.MATS} for _ in range(t.n_layers)],
+                            lm=(torch.empty(*w_lm.shape, dtype=torch.uint8, device=ops.device), ops.empty(w_lm.shape[0], dtype=torch.float32)))
+        for i, L in enumerate(self._w8["layers"]):
+            for n in self.MATS:
+                ops.quantize_fp8_rows(arena.w("l%d.%s" % (i, n)), q=L[n][0], scale=L[n][1])
+        ops.quantize_fp8_rows(w_lm, q=self._w8["lm"][0], scale=self._w8["lm"][1])
+        return self._w8
 
     def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta, save_prefill=False):
         """One prompt. prompt_ids: int32 device tensor [P]; prompt_pos3: numpy [3, P]; returns (tokens int32 [G, C] on device, layout)."""
@@ -107,11 +126,22 @@ class Rollout:
         R = B * G
         fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set
         native = fused and self.native_decode and hasattr(ops, "decode_step")
+        w8 = None
+        if self.weight_dtype == "fp8":
+            assert fused and t.hidden % 128 == 0 and t.intermediate % 128 == 0 and t.q_dim % 128 == 0, "fp8 decode: <= 64 rows, K % 128 == 0"
+            w8 = self._quantize(arena, w_lm)
         if native:
             # whole decode step enqueued by ONE native call (csrc/decode.hip): the host stays ahead of the GPU, no idle gaps between kernels
-            plan = ops.decode_plan([[arena.w("l%d.%s" % (i, n)) for n in ("ln1", "qkv.w", "qkv.b", "o.w", "ln2", "gu.w", "down.w")] + [cache.k[i], cache.vt[i]]
-                                    for i in range(t.n_layers)], t.hidden, t.n_heads, t.n_kv_heads, hd, t.intermediate, t.vocab_size, R, B, cache.s_cap, nsplit)
-            embed_p, norm_p, lm_p = arena.w("embed").data_ptr(), arena.w("norm").data_ptr(), w_lm.data_ptr()
+            def layer_tensors(i):
+                if w8 is None:
+                    return [arena.w("l%d.%s" % (i, n)) for n in ("ln1", "qkv.w", "qkv.b", "o.w", "ln2", "gu.w", "down.w")] + [cache.k[i], cache.vt[i]]
+                Q = w8["layers"][i]
+                return [arena.w("l%d.ln1" % i), Q["qkv.w"][0], arena.w("l%d.qkv.b" % i), Q["o.w"][0], arena.w("l%d.ln2" % i), Q["gu.w"][0], Q["down.w"][0],
+                        cache.k[i], cache.vt[i], Q["qkv.w"][1], Q["o.w"][1], Q["gu.w"][1], Q["down.w"][1]]
+            plan = ops.decode_plan([layer_tensors(i) for i in range(t.n_layers)], t.hidden, t.n_heads, t.n_kv_heads, hd, t.intermediate, t.vocab_size,
+                                   R, B, cache.s_cap, nsplit)
+            embed_p, norm_p = arena.w("embed").data_ptr(), arena.w("norm").data_ptr()
+            lm_p = w_lm.data_ptr() if w8 is None else (w8["lm"][0].data_ptr(), w8["lm"][1].data_ptr())
             cos_p, sin_p, slot_p, hi_p = cos_all.data_ptr(), sin_all.data_ptr(), abs_slots.data_ptr(), hi_all.data_ptr()
             pre_p, lo_p = pre_all.data_ptr(), lo_all.data_ptr()
             ids_buf = ops.zeros(R, dtype=I32)
@@ -131,7 +161,10 @@ class Rollout:
             h = ops.gather_rows(arena.w("embed"), ids_s)
             for i in range(t.n_layers):
                 p = "l%d." % i
-                if fused:      # rmsnorm folded into the projection's operand load (one launch instead of two)
+                Q = w8["layers"][i] if w8 is not None else None
+                if Q is not None:
+                    qkv = ops.gemm_w8(h, Q["qkv.w"][0], Q["qkv.w"][1], lnw=arena.w(p + "ln1"), eps=t.rms_eps, bias=arena.w(p + "qkv.b"))
+                elif fused:      # rmsnorm folded into the projection's operand load (one launch instead of two)
                     qkv = ops.norm_gemm(h, arena.w(p + "ln1"), t.rms_eps, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
                 else:
                     xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
@@ -140,6 +173,11 @@ class Rollout:
                 # one launch for all prompts of the window: problem b = rows [b*G,(b+1)*G) over cache slots [b*s_cap, (b+1)*s_cap)
                 o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
                                     nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap)
+                if Q is not None:
+                    h2 = ops.gemm_w8(o, Q["o.w"][0], Q["o.w"][1], residual=h)
+                    a = ops.gemm_w8(h2, Q["gu.w"][0], Q["gu.w"][1], lnw=arena.w(p + "ln2"), eps=t.rms_eps, glu=True)
+                    h = ops.gemm_w8(a, Q["down.w"][0], Q["down.w"][1], residual=h2)
+                    continue
                 h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
                 if fused:      # rmsnorm -> gate/up projection -> SwiGLU in one launch; the [R, 2I] intermediate never reaches HBM
                     a = ops.norm_gemm(h2, arena.w(p + "ln2"), t.rms_eps, arena.w(p + "gu.w"), glu=True)
@@ -150,7 +188,9 @@ class Rollout:
                     h = ops.gemm_skinny_fixup(a, arena.w(p + "down.w"), residual=h2)
                 else:
                     h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
-            if fused:
+            if w8 is not None:
+                logits = ops.gemm_w8(h, w8["lm"][0], w8["lm"][1], lnw=arena.w("norm"), eps=t.rms_eps)
+            elif fused:
                 logits = ops.norm_gemm(h, arena.w("norm"), t.rms_eps, w_lm)
             else:
                 hn, _, _ = ops.rmsnorm_fwd(h, arena.w("norm"), t.rms_eps, need_rstd=False)

@@ -79,6 +79,8 @@ class GRPOConfig:
     rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
     grad_wire_dtype: str = "bf16"           # data-parallel gradient all-reduce wire format ("bf16" | "fp32")
     gpu_video_preprocess: bool = False      # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path
+    rollout_weight_dtype: str = "bf16"      # "fp8": the SAMPLING policy reads e4m3 copies of the decoder matrices (row scales, re-quantised every window);
+                                            # log-probs, KL and the update keep bf16 weights (BASELINE config "fp8 weights")
     dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
@@ -265,6 +267,7 @@ class TimeR1_Trainer:
         self.core = GRPOCore(self.engine, self.ref_model, self.num_generations, self.max_completion_length, beta=self.beta,
                              use_grpo=self.use_grpo, temperature=args.temperature, top_k=args.top_k, seed=args.seed + 1000 * self.dp.rank,
                              rope_index_mode=args.rope_index_mode, stop_at_eos=args.stop_at_eos)
+        self.core.roll.weight_dtype = getattr(args, "rollout_weight_dtype", "bf16")
         if optimizers[0] is not None:
             raise NotImplementedError("custom torch optimizers are not supported; the engine owns a fused AdamW over its flat arena")
         self.optimizer = AdamWFlat(self.params, ops, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,

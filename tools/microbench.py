@@ -72,6 +72,37 @@ def fixup():
             print("M=%2d N=%6d K=%6d   plain %6.1f   fixup %6.1f" % (M, N, K, timeit(g0, reps=100), timeit(g1, reps=100)))
 
 
+def w8():
+    import ctypes
+    print("== decode GEMMs with fp8 weights (W8A16) vs bf16, raw C-ABI calls: us")
+    f8, fb, fn = ops.L.raw("tr1_gemm_skinny_w8"), ops.L.raw("tr1_gemm_nt_bf16"), ops.L.raw("tr1_norm_gemm_skinny")
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    for M in (16, 32):
+        for N, K, mode in [(4608, 3584, "norm"), (3584, 3584, "res"), (18944, 3584, "glu"), (3584, 18944, "res"), (152064, 3584, "norm")]:
+            nw = 2 * N if mode == "glu" else N
+            nc = max(1, min(6, int(600e6 // (nw * K))))
+            ws_ = [rnd(nw, K) for _ in range(nc)]
+            qs = [ops.quantize_fp8_rows(w) for w in ws_]
+            x, lnw, res, out = rnd(M, K), rnd(K), rnd(M, N), torch.empty(M, N, device="cuda", dtype=BF)
+            a8 = [(P(x), P(lnw) if mode != "res" else None, P(q), P(sc), None, P(res) if mode == "res" else None, P(out), M, N, K, K, K, N, N, 1e-6,
+                   int(mode == "glu"), None) for q, sc in qs]
+            if mode == "res":
+                ab = [(P(x), P(w), P(out), None, P(res), M, N, K, K, K, N, N, 0, 0, None) for w in ws_]
+                fbase = fb
+            else:
+                ab = [(P(x), P(lnw), P(w), None, P(out), M, N, K, K, K, N, 1e-6, int(mode == "glu"), None) for w in ws_]
+                fbase = fn
+            i = [0]
+
+            def g8():
+                f8(*a8[i[0] % len(a8)]); i[0] += 1
+
+            def gb():
+                fbase(*ab[i[0] % len(ab)]); i[0] += 1
+            tb, t8 = timeit(gb, reps=60), timeit(g8, reps=60)
+            print("M=%2d N=%6d K=%6d %-4s  bf16 %7.1f  fp8 %7.1f   (fp8 %.2f TB/s)" % (M, N, K, mode, tb, t8, nw * K / t8 / 1e6))
+
+
 def fused():
     import ctypes
     print("== decode layer pieces, raw C-ABI calls: us  (unfused rmsnorm + gemm [+ swiglu]  vs  norm_gemm)")
@@ -174,5 +205,5 @@ def sampler():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     for w in what:
-        for name in (["skinny", "fixup", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+        for name in (["skinny", "fixup", "w8", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
             globals()[name]()
