@@ -316,9 +316,11 @@ def main():
         # the timed windows drive decode through ONE native call per step (csrc/decode.hip); for this window the same kernels are launched
         # op by op from the host so that every GEMM launch can be bracketed by its own pair of HIP events
         wl.core.roll.native_decode = False
-        wl.window()
+        wl.eng.overlap_wgrad = False        # ... and the weight-gradient GEMMs stay on the main stream: a launch timed while another GEMM
+        wl.window()                         # shares the GPU would be charged the other kernel's time
         torch.cuda.synchronize()
         wl.core.roll.native_decode = True
+        wl.eng.overlap_wgrad = True
         if rank == 0:
             ops.gemm_nt, ops.norm_gemm, ops.gemm_skinny_fixup = orig
     if rank == 0 and not args.no_roofline:
