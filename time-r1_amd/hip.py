@@ -45,6 +45,9 @@ class _Lib:
             raise HipError(
                 "libtimer1_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "- there is no CPU fallback for the HIP path." % LIB_PATH)
+        # torch first: it ships its own libamdhip64 (same soname as /opt/rocm's).  Whichever copy is loaded first serves the whole process,
+        # and device tensors only interoperate with the kernels when both sides share torch's runtime ("no ROCm-capable device" otherwise).
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.decls = parse_header()
         for name, (ret, args) in self.decls.items():
