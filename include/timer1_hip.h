@@ -36,6 +36,10 @@ int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, co
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
  * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */
 int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream);
+/* Decode rows: input_layernorm -> fused q/k/v projection -> M-RoPE -> KV-cache append in ONE launch (tr1_norm_gemm_skinny + tr1_decode_qkv_post):
+ * roped q -> q_out[M, n_heads*hd]; roped k -> kcache[slots[m], :]; v -> vtcache[:, slots[m]].  Wqkv: [(n_heads + 2 n_kv)*hd, K] (q | k | v rows).
+ * ref: Qwen2VLAttention.forward TF:521-556 + DynamicCache.update inside generate (timer1_trainer.py:568-573).  head_dim % 32 == 0. */
+int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* stream);
 /* Narrow decode projections (o_proj / down_proj at M <= 64 rows): C = A B^T (+bias)(+residual) with cross-block split-K and an in-kernel
  * fixup (the last block of a column group sums the fp32 partial tiles).  ws_f32: tr1_gemm_skinny_fixup_workspace_floats() floats whose
  * trailing ticket counters must be ZERO before the first call (the kernel re-arms them).  Same call sites as tr1_gemm_nt_bf16 in generate. */

@@ -138,6 +138,10 @@ class RefOps:
         return self._a(dx)
 
     # ---- activations (ref: TF:459-466 SwiGLU; TF:277-290 GELU; TF:293-301 quick_gelu)
+    def norm_gemm_qkv(self, x, lnw, eps, wqkv, bias, cos, sin, kcache, vtcache, slots, n_heads, n_kv, head_dim):
+        qkv = self.norm_gemm(x, lnw, eps, wqkv, bias=bias)
+        return self.decode_qkv_post(qkv, cos, sin, kcache, vtcache, slots, n_heads, n_kv, head_dim)
+
     def quantize_fp8_rows(self, w, q=None, scale=None):
         """Per-row symmetric OCP e4m3 quantisation, same arithmetic as csrc/gemm_w8.hip (fp32: inv = 448 / amax, q = rne(w * inv))."""
         wf = w.float()

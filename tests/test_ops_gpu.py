@@ -483,3 +483,34 @@ def test_gemm_w8(hip_ops, ref_ops, M, N, K, mode):
     if mode == "plain":
         full = x.float() @ w.float().t() + bias.float()
         assert (h.float().cpu() - full).norm() / full.norm() < 0.05
+
+
+@pytest.mark.parametrize("R,nh,nkv,hd,K", [(16, 28, 4, 128, 3584), (8, 4, 2, 32, 128), (32, 12, 2, 128, 1536), (5, 4, 1, 64, 256), (64, 4, 2, 32, 128)])
+def test_norm_gemm_qkv_fused(hip_ops, ref_ops, R, nh, nkv, hd, K):
+    """rmsnorm -> qkv projection -> M-RoPE -> KV append in one launch == the two-kernel path (norm_gemm + decode_qkv_post), bit for bit,
+    and == the oracle composition within bf16 tolerance."""
+    N = (nh + 2 * nkv) * hd
+    x, lnw = rnd(R, K, seed=1, scale=2.0), (1.0 + 0.1 * rnd(K, seed=2).float()).to(BF16)
+    w, b = rnd(N, K, seed=3, scale=1.0 / math.sqrt(K)), rnd(N, seed=4)
+    S = 96
+    pos = torch.randint(0, 500, (3, R), generator=torch.Generator().manual_seed(5)).int()
+    sec = {128: (16, 24, 24), 64: (8, 12, 12), 32: (4, 6, 6)}[hd]
+    cos, sin = hip_ops.mrope_table(pos.cuda(), hd, sec, 1e6)
+    slots = torch.randperm(S, generator=torch.Generator().manual_seed(6))[:R].int()
+    kc0, vt0 = rnd(S, nkv * hd, seed=7), rnd(nkv * hd, S, seed=8)
+    outs = []
+    for fused in (True, False):
+        kc, vt = kc0.clone().cuda(), vt0.clone().cuda()
+        if fused:
+            q = hip_ops.norm_gemm_qkv(x.cuda(), lnw.cuda(), 1e-6, w.cuda(), b.cuda(), cos, sin, kc, vt, slots.cuda(), nh, nkv, hd)
+        else:
+            qkv = hip_ops.norm_gemm(x.cuda(), lnw.cuda(), 1e-6, w.cuda(), bias=b.cuda())
+            q = hip_ops.decode_qkv_post(qkv, cos, sin, kc, vt, slots.cuda(), nh, nkv, hd)
+        outs.append((q.cpu(), kc.cpu(), vt.cpu()))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+    kc, vt = kc0.clone().float(), vt0.clone().float()
+    rq = ref_ops.norm_gemm_qkv(x.float(), lnw.float(), 1e-6, w.float(), b.float(), cos.cpu(), sin.cpu(), kc, vt, slots, nh, nkv, hd)
+    close(outs[0][0], rq, 0.05, what="fused qkv: q")
+    close(outs[0][1], kc, 0.05, what="fused qkv: K cache")
+    close(outs[0][2], vt, 0.05, what="fused qkv: V^T cache")

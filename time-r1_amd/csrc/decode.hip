@@ -62,9 +62,16 @@ static int decode_step_impl(bool w8, const void* layer_ptrs, const int64_t* dims
     void* h = hA; void* h2 = hB;
     for (int64_t i = 0; i < L; ++i) {
         const void* const* w = lp + i * stride;
-        if (w8) CK(tr1_gemm_skinny_w8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
-        else CK(tr1_norm_gemm_skinny(h, w[0], w[1], w[2], qkv, R, qkvd, hid, hid, hid, qkvd, eps, 0, stream));
-        CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
+        if (w8) {
+            CK(tr1_gemm_skinny_w8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
+            CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
+        } else if (hd % 32 == 0) {      // norm + q/k/v projection + M-RoPE + KV append in one launch
+            CK(tr1_norm_gemm_qkv(h, w[0], w[1], w[2], cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, hid, hid, hid,
+                                 eps, stream));
+        } else {
+            CK(tr1_norm_gemm_skinny(h, w[0], w[1], w[2], qkv, R, qkvd, hid, hid, hid, qkvd, eps, 0, stream));
+            CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
+        }
         CK(tr1_attn_fwd(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
                         scap, stream));
         if (w8) CK(tr1_gemm_skinny_w8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));

@@ -380,8 +380,11 @@ __global__ void decode_qkv_post_kernel(const bf16_t* __restrict__ qkv, int64_t l
             for (int j = 0; j < 4; ++j) {
                 const float c0 = cp[2 * j], c1 = cp[2 * j + 1], s0 = sp[2 * j], s1 = sp[2 * j + 1];
                 const float a0 = bflo(a[j]), a1 = bfhi(a[j]), b0 = bflo(b[j]), b1 = bfhi(b[j]);
-                oa[j] = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
-                ob[j] = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+                float x0, y0, x1, y1;
+                rope_pair(a0, b0, c0, s0, x0, y0);
+                rope_pair(a1, b1, c1, s1, x1, y1);
+                oa[j] = pack2bf(x0, x1);
+                ob[j] = pack2bf(y0, y1);
             }
             bf16_t* dst = (h < n_heads) ? (q_out + (int64_t)r * ld_q + (int64_t)h * hd + c * 8)
                                         : (kcache + (int64_t)slot * k_ld + (int64_t)(h - n_heads) * hd + c * 8);

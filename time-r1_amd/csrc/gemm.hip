@@ -471,21 +471,25 @@ TR1_DEV bf16x8_t scale_frag_sumsq(bf16x8_t x, bf16x8_t w, float& ss) {
     return __builtin_bit_cast(bf16x8_t, o);
 }
 
-template <int WAVES, int UNROLL, int MG, bool GLU, int NCOL = 2>
+// QKV: the block's two column groups are columns (d, d + hd/2) of one head and the epilogue is qkv_epilogue_store (RoPE + cache append).
+template <int WAVES, int UNROLL, int MG, bool GLU, int NCOL = 2, bool QKV = false>
 __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
                                                                       const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                       const bf16_t* __restrict__ bias, int M, int64_t N, int64_t K, int64_t ldx,
-                                                                      int64_t ldw, int64_t ldc, float eps, int64_t up_off) {
+                                                                      int64_t ldw, int64_t ldc, float eps, int64_t up_off, QkvEpi qe = QkvEpi{}) {
     static_assert(!GLU || NCOL == 2, "GLU pairs one gate and one up column group");
+    static_assert(!QKV || (NCOL == 2 && !GLU), "QKV pairs the two rotate-half column groups of a head");
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ float ssred[WAVES][MG][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * (GLU ? 16 : 16 * NCOL);
+    const int qkv_gph = QKV ? qe.hd >> 5 : 1;                                   // 16-column group pairs per head
+    const int qkv_h = QKV ? (int)blockIdx.x / qkv_gph : 0, qkv_j = QKV ? (int)blockIdx.x % qkv_gph : 0;
+    const int64_t n0 = QKV ? (int64_t)qkv_h * qe.hd + qkv_j * 16 : (int64_t)blockIdx.x * (GLU ? 16 : 16 * NCOL);
     const bf16_t* wp[NCOL];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
-        int64_t wrow = GLU ? n0 + u : n0 + c * 16 + u;
+        int64_t wrow = QKV ? n0 + c * (qe.hd >> 1) + u : (GLU ? n0 + u : n0 + c * 16 + u);
         if (wrow >= N) wrow = N - 1;
         if (GLU && c == 1) wrow += up_off;
         wp[c] = W + wrow * ldw + g * 8;
@@ -563,21 +567,26 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
     }
     __syncthreads();
     const float inv_k = 1.f / (float)K;
-    for (int i = threadIdx.x; i < (GLU ? 1 : NCOL) * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
+    for (int i = threadIdx.x; i < ((GLU || QKV) ? 1 : NCOL) * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
         const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
         const int m = mg * 16 + mm;
         const int64_t n = n0 + c * 16 + nn;
         if (m < M && n < N) {
             float sq = 0.f, v = 0.f, v2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) { sq += ssred[w][mg][mm]; v += red[w][c][mg][mm][nn]; if (GLU) v2 += red[w][1][mg][mm][nn]; }
+            for (int w = 0; w < WAVES; ++w) { sq += ssred[w][mg][mm]; v += red[w][c][mg][mm][nn]; if (GLU || QKV) v2 += red[w][1][mg][mm][nn]; }
             const float rstd = rsqrtf(sq * inv_k + eps);
-            v *= rstd;
-            if (GLU) {      // same rounding points as the unfused path: gate/up rounded to bf16, silu rounded, product rounded
+            v = __fmul_rn(v, rstd);          // explicitly rounded (no fma contraction): the fused-QKV and two-kernel paths agree bit for bit
+            if (QKV) {      // same rounding points as projection -> bf16 qkv buffer -> decode_qkv_post
+                const int64_t nb = n + (qe.hd >> 1);
+                float vb = __fmul_rn(v2, rstd);
+                if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[nb])); }
+                qkv_epilogue_store(qe, m, qkv_h, qkv_j * 16 + nn, bf2f(f2bf(v)), bf2f(f2bf(vb)));
+            } else if (GLU) {      // same rounding points as the unfused path: gate/up rounded to bf16, silu rounded, product rounded
                 const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
                 C[(int64_t)m * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
             } else {
-                if (bias) v += bf2f(bias[n]);
+                if (bias) v = __fadd_rn(v, bf2f(bias[n]));
                 C[(int64_t)m * ldc + n] = f2bf(v);
             }
         }
@@ -606,6 +615,25 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     }
     else     { if (M <= 16) NG(4, 4, 1, false); else if (M <= 32) NG(4, 2, 2, false); else NG(4, 2, 4, false); }
 #undef NG
+    TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out,
+                                 int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M, int64_t n_heads,
+                                 int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && K >= BK, "norm_gemm_qkv: K must be a positive multiple of 64");
+    TR1_CHECK_ARG(M >= 1 && M <= 64, "norm_gemm_qkv: 1 <= M <= 64 (decode rows)");
+    TR1_CHECK_ARG(head_dim % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "norm_gemm_qkv: head_dim % 32, ldx % 8, ldw % 8 required");
+    const int64_t heads = n_heads + 2 * n_kv, N = heads * head_dim;
+    QkvEpi qe{(const float*)cosb, (const float*)sinb, (bf16_t*)q_out, ld_q, (bf16_t*)kcache, k_ld, (bf16_t*)vtcache, vt_ld, (const int*)slots,
+              (int)n_heads, (int)n_kv, (int)head_dim};
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(heads * (head_dim / 32)));
+#define NGQ(UN, MGR)                                                                                                                  \
+    hipLaunchKernelGGL((norm_gemm_skinny_kernel<4, UN, MGR, false, 2, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)lnw,      \
+                       (const bf16_t*)Wqkv, (bf16_t*)nullptr, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)0, qe)
+    if (M <= 16) NGQ(4, 1); else if (M <= 32) NGQ(2, 2); else NGQ(2, 4);
+#undef NGQ
     TR1_LAUNCH_CHECK();
 }
 

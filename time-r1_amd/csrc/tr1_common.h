@@ -87,3 +87,37 @@ static inline int tr1_grid_1d(int64_t work_items, int per_block, int cap = 8192)
     if (g > cap) g = cap;
     return (int)g;
 }
+
+// ---- decode: q/k/v projection epilogue (shared by the bf16 and fp8 decode GEMMs) ---------------------------------------------------
+// The fused QKV kernels give each block the column pair (d, d + hd/2) of one head, so rotate-half RoPE closes inside the block and the
+// results go straight to their consumers: roped q -> q_out, roped k -> K cache row slots[m], v -> V^T cache column slots[m]
+// (= tr1_decode_qkv_post folded into the projection; reference: Qwen2VLAttention.forward TF:521-556 + DynamicCache.update).
+struct QkvEpi {
+    const float* cosb; const float* sinb;            // [R, hd/2] fp32 tables of the rows' positions
+    bf16_t* q_out; int64_t ld_q;
+    bf16_t* kcache; int64_t k_ld;
+    bf16_t* vtcache; int64_t vt_ld;
+    const int* slots;
+    int n_heads, n_kv, hd;
+};
+// rotate-half pair with explicitly rounded products (no fma contraction): the fused and the two-kernel decode paths must agree bit for bit
+TR1_DEV void rope_pair(float a, float b, float c, float s, float& oa, float& ob) {
+    oa = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, s));
+    ob = __fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s));
+}
+// vA / vB: projection outputs (bias included) of row m at columns h*hd + d and h*hd + hd/2 + d, already rounded to bf16 like the unfused path
+TR1_DEV void qkv_epilogue_store(const QkvEpi& e, int m, int h, int d, float vA, float vB) {
+    const int half = e.hd >> 1;
+    if (h < e.n_heads + e.n_kv) {
+        const float c = e.cosb[(int64_t)m * half + d], s = e.sinb[(int64_t)m * half + d];
+        float fa, fb;
+        rope_pair(vA, vB, c, s, fa, fb);
+        const bf16_t oa = f2bf(fa), ob = f2bf(fb);
+        bf16_t* dst = (h < e.n_heads) ? (e.q_out + (int64_t)m * e.ld_q + (int64_t)h * e.hd + d)
+                                      : (e.kcache + (int64_t)e.slots[m] * e.k_ld + (int64_t)(h - e.n_heads) * e.hd + d);
+        dst[0] = oa; dst[half] = ob;
+    } else {
+        bf16_t* col = e.vtcache + ((int64_t)(h - e.n_heads - e.n_kv) * e.hd + d) * e.vt_ld + e.slots[m];
+        col[0] = f2bf(vA); col[(int64_t)half * e.vt_ld] = f2bf(vB);
+    }
+}

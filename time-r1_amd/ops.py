@@ -84,6 +84,17 @@ class HipOps:
         self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), int(glu), self._s())
         return out
 
+    def norm_gemm_qkv(self, x, lnw, eps, wqkv, bias, cos, sin, kcache, vtcache, slots, n_heads, n_kv, head_dim):
+        """Decode rows: rmsnorm -> q/k/v projection -> M-RoPE -> KV-cache append in one launch. Returns roped q [R, n_heads*hd]."""
+        self._chk(x, lnw, wqkv, bias, kcache, vtcache)
+        R, K = x.shape
+        assert slots.dtype == I32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (R, head_dim // 2) and cos.dtype == F32
+        assert wqkv.shape == ((n_heads + 2 * n_kv) * head_dim, K) and x.stride(1) == 1 and wqkv.stride(1) == 1
+        q = self.empty(R, n_heads * head_dim)
+        self.L.call("tr1_norm_gemm_qkv", _p(x), _p(lnw), _p(wqkv), _p(bias), _p(cos), _p(sin), _p(q), _ld(q), _p(kcache), _ld(kcache), _p(vtcache),
+                    _ld(vtcache), _p(slots), R, n_heads, n_kv, head_dim, K, x.stride(0), wqkv.stride(0), float(eps), self._s())
+        return q
+
     # ---- fp8 weight storage (rollout only) -------------------------------------------------------------------------------
     def quantize_fp8_rows(self, w, q=None, scale=None):
         """bf16 [N, K] -> (fp8 e4m3 bytes uint8 [N, K], fp32 row scales [N]); q/scale may be preallocated views."""

@@ -164,12 +164,17 @@ class Rollout:
                 Q = w8["layers"][i] if w8 is not None else None
                 if Q is not None:
                     qkv = ops.gemm_w8(h, Q["qkv.w"][0], Q["qkv.w"][1], lnw=arena.w(p + "ln1"), eps=t.rms_eps, bias=arena.w(p + "qkv.b"))
+                elif fused and hd % 32 == 0:      # rmsnorm + q/k/v projection + M-RoPE + KV append: one launch (same choice as csrc/decode.hip)
+                    qkv = None
+                    q = ops.norm_gemm_qkv(h, arena.w(p + "ln1"), t.rms_eps, arena.w(p + "qkv.w"), arena.w(p + "qkv.b"), cs, sn, cache.k[i], cache.vt[i],
+                                          abs_slots[s], t.n_heads, t.n_kv_heads, hd)
                 elif fused:      # rmsnorm folded into the projection's operand load (one launch instead of two)
                     qkv = ops.norm_gemm(h, arena.w(p + "ln1"), t.rms_eps, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
                 else:
                     xn, _, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=False)
                     qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"))
-                q = ops.decode_qkv_post(qkv, cs, sn, cache.k[i], cache.vt[i], abs_slots[s], t.n_heads, t.n_kv_heads, hd)
+                if qkv is not None:
+                    q = ops.decode_qkv_post(qkv, cs, sn, cache.k[i], cache.vt[i], abs_slots[s], t.n_heads, t.n_kv_heads, hd)
                 # one launch for all prompts of the window: problem b = rows [b*G,(b+1)*G) over cache slots [b*s_cap, (b+1)*s_cap)
                 o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
                                     nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap)
