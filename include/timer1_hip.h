@@ -145,8 +145,10 @@ int tr1_logp_entropy_fwd(const void* logits, int64_t ld, const void* targets, vo
 int tr1_logp_bwd(const void* logits, int64_t ld, const void* targets, const void* lse, const void* dlogp, void* dlogits, int64_t ld_out, int64_t R, int64_t V, void* stream);
 /* ref: timer1_trainer.py:635-639 (k3 KL), :713-737 (both loss branches).  out3 = {loss, mean masked kl, sum mask}. */
 int tr1_grpo_loss(const void* logp, const void* ref_logp, const void* mask, const void* adv, void* dlogp, void* out3, void* row_len, void* row_kl, int64_t G, int64_t C, float beta, int use_grpo, float grad_scale, void* stream);
-/* ref: model.generate(do_sample=True, temperature, top_k) at timer1_trainer.py:568-573.  tokens[row*tok_ld + *step_ptr] = draw. */
-int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* stream);
+/* ref: model.generate(do_sample=True, temperature, top_k) at timer1_trainer.py:568-573.  tokens[row*tok_ld + *step_ptr] = draw.
+ * group_rows > 0: rows [b*group_rows, (b+1)*group_rows) belong to prompt b and draw from the stream (seed + b*seed_stride, row % group_rows, step),
+ * so several prompts sampled in one launch get exactly the tokens of one launch per prompt. */
+int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* stream);
 int64_t tr1_sample_workspace_words(int64_t rows);
 
 /* ---- optimizer -------------------------------------------------------------------------------------------------------- */

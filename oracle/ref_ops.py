@@ -398,7 +398,8 @@ class RefOps:
         out3 = torch.stack([loss, klm, m.sum()])
         return dlogp, out3, lens, (kl * m).sum(1)
 
-    def sample_tokens(self, logits, temperature, top_k, seed, step_dev, tokens, finished, eos_id, pad_id, stop_at_eos, u_out=None):
+    def sample_tokens(self, logits, temperature, top_k, seed, step_dev, tokens, finished, eos_id, pad_id, stop_at_eos, u_out=None, group_rows=0,
+                      seed_stride=0):
         rows, V = logits.shape
         step = int(step_dev.item()) if step_dev is not None else 0
         x = logits.float().numpy().astype(np.float32) * np.float32(1.0 / temperature)
@@ -412,7 +413,7 @@ class RefOps:
                 thr = np.partition(xr, V - top_k)[V - top_k]
             keep = xr >= thr
             e = np.where(keep, np.exp((xr - xr.max()).astype(np.float64)), 0.0)
-            u = philox_uniform(int(seed), r, step)
+            u = philox_uniform(int(seed) + (r // group_rows) * int(seed_stride), r % group_rows, step) if group_rows else philox_uniform(int(seed), r, step)
             if u_out is not None:
                 u_out[r] = u
             cdf = np.cumsum(e)

@@ -156,7 +156,7 @@ TR1_DEV float key_logit(unsigned k) { const unsigned b = (k & 0x8000u) ? (k & 0x
 #define SAMP_WS_WORDS (256 + 256 + 8 + SAMP_S)
 
 struct SampleArgs {
-    const bf16_t* logits; int64_t ld; int V; float inv_temp; int top_k; unsigned long long seed; const int* step_ptr; int* tokens; int64_t tok_ld;
+    const bf16_t* logits; int64_t ld; int V; float inv_temp; int top_k; unsigned long long seed; int group_rows; unsigned long long seed_stride; const int* step_ptr; int* tokens; int64_t tok_ld;
     int* finished; int eos_id, pad_id, stop_at_eos; float* u_out; unsigned* ws;
 };
 
@@ -243,8 +243,12 @@ __global__ __launch_bounds__(256) void samp_pick_kernel(SampleArgs a) {
         sthr = samp_threshold(a, ws);
         float Z = 0.f;
         for (int i = 0; i < SAMP_S; ++i) Z += sums[i];
-        unsigned c[4] = {(unsigned)r, (unsigned)step, 0u, 0u};
-        philox4x32_10(c, (unsigned)(a.seed & 0xffffffffu), (unsigned)(a.seed >> 32));
+        // several prompts in one launch: rows [b*group_rows, (b+1)*group_rows) use seed + b*seed_stride and their row index inside the group,
+        // i.e. exactly the stream a separate launch per prompt would draw
+        const int grp = a.group_rows > 0 ? r / a.group_rows : 0;
+        const unsigned long long sd = a.seed + (unsigned long long)grp * a.seed_stride;
+        unsigned c[4] = {(unsigned)(a.group_rows > 0 ? r % a.group_rows : r), (unsigned)step, 0u, 0u};
+        philox4x32_10(c, (unsigned)(sd & 0xffffffffu), (unsigned)(sd >> 32));
         const float uu = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
         if (a.u_out) a.u_out[r] = uu;
         const float target = uu * Z;
@@ -309,14 +313,15 @@ extern "C" int tr1_grpo_loss(const void* logp, const void* ref_logp, const void*
 extern "C" int64_t tr1_sample_workspace_words(int64_t rows) { return rows * SAMP_WS_WORDS; }
 
 extern "C" int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k,
-                                 uint64_t seed, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id,
-                                 int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* stream) {
+                                 uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld,
+                                 void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words,
+                                 void* stream) {
     TR1_CHECK_ARG(temperature > 0.f, "sample: temperature must be > 0");
     TR1_CHECK_ARG(ws_u32 && ws_words >= rows * SAMP_WS_WORDS, "sample: workspace too small (tr1_sample_workspace_words)");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     SampleArgs a;
-    a.logits = (const bf16_t*)logits; a.ld = ld; a.V = (int)V; a.inv_temp = 1.0f / temperature; a.top_k = (int)top_k; a.seed = seed;
+    a.logits = (const bf16_t*)logits; a.ld = ld; a.V = (int)V; a.inv_temp = 1.0f / temperature; a.top_k = (int)top_k; a.seed = seed; a.group_rows = (int)group_rows; a.seed_stride = seed_stride;
     a.step_ptr = (const int*)step_ptr; a.tokens = (int*)tokens; a.tok_ld = tok_ld; a.finished = (int*)finished; a.eos_id = (int)eos_id;
     a.pad_id = (int)pad_id; a.stop_at_eos = stop_at_eos; a.u_out = (float*)u_out; a.ws = (unsigned*)ws_u32;
     hipMemsetAsync(ws_u32, 0, (size_t)rows * SAMP_WS_WORDS * 4, s);

@@ -444,14 +444,15 @@ class HipOps:
                     float(beta), int(bool(use_grpo)), float(grad_scale), self._s())
         return dlogp, out3, row_len, row_kl
 
-    def sample_tokens(self, logits, temperature, top_k, seed, step_dev, tokens, finished, eos_id, pad_id, stop_at_eos, u_out=None):
+    def sample_tokens(self, logits, temperature, top_k, seed, step_dev, tokens, finished, eos_id, pad_id, stop_at_eos, u_out=None, group_rows=0,
+                      seed_stride=0):
         self._chk(logits)
         assert tokens.dtype == I32 and (step_dev is None or step_dev.dtype == I32)
         rows, V = logits.shape
         nws = self.L.raw("tr1_sample_workspace_words")(rows)
         ws = self._workspace("sampler", nws, I32)
         self.L.call("tr1_sample_tokens", _p(logits), _ld(logits), rows, V, float(temperature), int(top_k or 0), int(seed) & (2**64 - 1),
-                    _p(step_dev), _p(tokens), tokens.stride(0), _p(finished), int(eos_id), int(pad_id), int(bool(stop_at_eos)), _p(u_out),
+                    int(group_rows), int(seed_stride) & (2**64 - 1), _p(step_dev), _p(tokens), tokens.stride(0), _p(finished), int(eos_id), int(pad_id), int(bool(stop_at_eos)), _p(u_out),
                     _p(ws), nws, self._s())
 
     # ---- optimizer ------------------------------------------------------------------------------------------------

@@ -152,9 +152,9 @@ class Rollout:
                 ids_buf.copy_(tokens_all[:, s])
                 logits = ops.decode_step(plan, embed_p, norm_p, lm_p, ids_p, cos_p + s * R * half * 4, sin_p + s * R * half * 4, slot_p + s * R * 4,
                                          pre_p, lo_p, hi_p + s * R * 4, t.rms_eps, scale)
-                for b, st in enumerate(per):
-                    ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
-                                      st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+                # all prompts of the window in ONE sampler launch set; every prompt keeps its own Philox stream (seed_b = seed_0 + 7919 b)
+                ops.sample_tokens(logits, self.temperature, self.top_k, per[0]["seed"], steps[s + 1:s + 2], tokens_all, finished_all, cfg.eos_token_id,
+                                  cfg.pad_token_id, self.stop_at_eos, group_rows=G, seed_stride=7919)
                 continue
             ids_s = tokens_all[:, s].contiguous()
             cs, sn = cos_all[s], sin_all[s]
