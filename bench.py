@@ -155,9 +155,19 @@ def instrument_gemms(ops):
         e1.record()
         rec.append((True, x.shape[0], w.shape[0], x.shape[1], e0, e1))
         return r
+    orig_qkv = ops.norm_gemm_qkv
+
+    def timed_qkv(x, lnw, eps, wqkv, *a, **k):                 # decode qkv projection with fused norm / RoPE / KV append: same weight stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_qkv(x, lnw, eps, wqkv, *a, **k)
+        e1.record()
+        rec.append((True, x.shape[0], wqkv.shape[0], x.shape[1], e0, e1))
+        return r
     ops.gemm_nt = timed
     ops.norm_gemm = timed_ng
-    return rec, (orig, orig_ng, orig_fx)
+    ops.norm_gemm_qkv = timed_qkv
+    return rec, (orig, orig_ng, orig_fx, orig_qkv)
 
 
 def cpu_baseline(args, budget_note=True):
@@ -322,7 +332,7 @@ def main():
         wl.core.roll.native_decode = True
         wl.eng.overlap_wgrad = True
         if rank == 0:
-            ops.gemm_nt, ops.norm_gemm, ops.gemm_skinny_fixup = orig
+            ops.gemm_nt, ops.norm_gemm, ops.gemm_skinny_fixup, ops.norm_gemm_qkv = orig
     if rank == 0 and not args.no_roofline:
         nstep = float(args.ga)
         big_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if not s)
