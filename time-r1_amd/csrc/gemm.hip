@@ -161,32 +161,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // ds_read_b128 feeds more MFMAs (12 fragment reads per 32 MFMAs instead of 16) and the HBM/L2 traffic per FLOP halves.
 // Same staging / swizzle / epilogue scheme as gemm_nt_kernel; 128 KiB of LDS (two buffers), one block per CU.
 // ------------------------------------------------------------------------------------------------------------------
-#define BM2 256
 #define BN2 256
-#define TILE2_BYTES (BM2 * BK * 2)  // 32 KiB per operand per buffer
+#define TILE2_BYTES (BN2 * BK * 2)  // 32 KiB: the B operand tile (and the A tile of the 256-row form)
 
-template <bool IS_B>
-TR1_DEV void stage_tile256(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
-                           int wave, int lane) {
+// RT = 16-row MFMA tiles per wave along M: 8 -> 256 x 256 block, 9 -> 288 x 256 block.  The 288-row form exists for the M = 5074 (P + G*C)
+// GEMMs with N = 3584: 18 x 14 = 252 blocks fill the 256 CUs in ONE round at 98 % padding efficiency, where 256 x 256 needs two rounds
+// (280 blocks) and 128 x 128 three (1120 blocks on 512 slots).
+template <bool IS_B, int ROWS>
+TR1_DEV void stage_tile2(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
+                         int wave, int lane) {
+    constexpr int NINST = ROWS / 8;                    // instructions of 8 rows (1 KiB) each
+    constexpr int PER_WAVE = (NINST + 7) / 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wave * 4 + i;                 // 32 instructions of 8 rows each
-        const int row = inst * 8 + (lane >> 3);
-        const int phys = lane & 7;
-        const int logical = phys ^ (IS_B ? keyB(row) : keyA(row));
-        int64_t grow = row0 + row;
-        if (grow >= rows_valid) grow = rows_valid - 1;
-        const bf16_t* src = g + grow * ld + k0 + logical * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wave * PER_WAVE + i;
+        if (inst < NINST) {                            // wave-uniform
+            const int row = inst * 8 + (lane >> 3);
+            const int phys = lane & 7;
+            const int logical = phys ^ (IS_B ? keyB(row) : keyA(row));
+            int64_t grow = row0 + row;
+            if (grow >= rows_valid) grow = rows_valid - 1;
+            const bf16_t* src = g + grow * ld + k0 + logical * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+        }
     }
 }
 
-template <bool OUT_F32, bool ACCUM>
+template <bool OUT_F32, bool ACCUM, int RT>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
                                                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                                                          int64_t ldr, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem2[];  // [buf][A|B], 4 * 32 KiB
+    constexpr int BMX = RT * 32;                       // 2 waves along M
+    constexpr int A_BYTES = BMX * BK * 2, BUF_BYTES = A_BYTES + TILE2_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];  // [buf][A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int nwg = tiles_m * tiles_n;
@@ -202,30 +210,30 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     const int in_group = wgid - group * GROUP_M * tiles_n;
     const int tm = first_m + in_group % gsz;
     const int tn = in_group / gsz;
-    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+    const int64_t m0 = (int64_t)tm * BMX, n0 = (int64_t)tn * BN2;
 
-    f32x4_t acc[8][4];
+    f32x4_t acc[RT][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)(K / BK);
-    stage_tile256<false>(A, lda, m0, M, 0, smem2, wave, lane);
-    stage_tile256<true>(B, ldb, n0, N, 0, smem2 + TILE2_BYTES, wave, lane);
+    stage_tile2<false, BMX>(A, lda, m0, M, 0, smem2, wave, lane);
+    stage_tile2<true, BN2>(B, ldb, n0, N, 0, smem2 + A_BYTES, wave, lane);
     const int u = lane & 15, g = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
-        char* curA = smem2 + (kt & 1) * 2 * TILE2_BYTES;
-        char* curB = curA + TILE2_BYTES;
+        char* curA = smem2 + (kt & 1) * BUF_BYTES;
+        char* curB = curA + A_BYTES;
         if (kt + 1 < nk) {
-            char* nxtA = smem2 + ((kt + 1) & 1) * 2 * TILE2_BYTES;
-            stage_tile256<false>(A, lda, m0, M, (int64_t)(kt + 1) * BK, nxtA, wave, lane);
-            stage_tile256<true>(B, ldb, n0, N, (int64_t)(kt + 1) * BK, nxtA + TILE2_BYTES, wave, lane);
+            char* nxtA = smem2 + ((kt + 1) & 1) * BUF_BYTES;
+            stage_tile2<false, BMX>(A, lda, m0, M, (int64_t)(kt + 1) * BK, nxtA, wave, lane);
+            stage_tile2<true, BN2>(B, ldb, n0, N, (int64_t)(kt + 1) * BK, nxtA + A_BYTES, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t xa[8], wb[4];
+            bf16x8_t xa[RT], wb[4];
             const int chunk = ks * 4 + g;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -233,20 +241,20 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
                 wb[j] = *reinterpret_cast<const bf16x8_t*>(curB + row * 128 + ((chunk ^ keyB(row)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = wm * 128 + i * 16 + u;
+            for (int i = 0; i < RT; ++i) {
+                const int row = wm * (RT * 16) + i * 16 + u;
                 xa[i] = *reinterpret_cast<const bf16x8_t*>(curA + row * 128 + ((chunk ^ keyA(row)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
     }
     const int64_t nbase = n0 + wn * 64 + g * 16;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 16 + u;
+    for (int i = 0; i < RT; ++i) {
+        const int64_t m = m0 + wm * (RT * 16) + i * 16 + u;
         if (m >= M) continue;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -708,26 +716,38 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
         launch_skinny(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_f32, 1, s);
         TR1_LAUNCH_CHECK();
     }
-    {   // large outputs: 256x256 tiles when they still give >= ~2.3 rounds of 256 CUs (tile-count quantisation)
-        static int force256 = -1;
-        if (force256 < 0) { const char* e = getenv("TR1_GEMM_TILE"); force256 = e ? atoi(e) : 0; }
-        const int64_t t2m = (M + BM2 - 1) / BM2, t2n = (N + BN2 - 1) / BN2;
-        const bool big = (force256 == 256) || (force256 == 0 && t2m * t2n >= 600 && M >= 512);
-        if (big && force256 != 128) {
-            const size_t dyn = 4 * TILE2_BYTES;
+    {   // tile choice: CU-rounds x block area / relative efficiency of the structure (tile-count quantisation).
+        // 128x128 runs 2 blocks per CU (512 slots), the 8-wave 256/288-row forms 1 block per CU at ~1.18x the MFMA rate per CU.
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("TR1_GEMM_TILE"); force = e ? atoi(e) : 0; }
+        auto blocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+        auto cost = [&](int64_t bm, int64_t bn, int64_t slots, double eff) {
+            const int64_t t = blocks(bm, bn);
+            return (double)((t + slots - 1) / slots) * (double)slots * (double)(bm * bn) / eff;
+        };
+        const double c128 = cost(BM, BN, 512, 0.85), c256 = cost(256, BN2, 256, 1.0), c288 = cost(288, BN2, 256, 1.0);
+        int rt = 0;
+        if (force == 256) rt = 8; else if (force == 288) rt = 9; else if (force == 128) rt = 0;
+        else if (M >= 512 && N >= 256) rt = (c288 < c256 && c288 < c128) ? 9 : (c256 < c128 ? 8 : 0);
+        if (rt) {
+            const int bmx = rt * 32;
+            const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
+            const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES);
             static bool attr_set = false;
             if (!attr_set) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                const int mx = (int)(2 * (288 * BK * 2 + TILE2_BYTES));
+#define SETA(OF, AC, R) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OF, AC, R>), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+                SETA(false, false, 8); SETA(true, false, 8); SETA(true, true, 8); SETA(false, false, 9); SETA(true, false, 9); SETA(true, true, 9);
+#undef SETA
                 attr_set = true;
             }
             dim3 grid2((unsigned)(t2m * t2n));
-#define LAUNCH2(OF, AC)                                                                                                               \
-    hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
+#define LAUNCH2(OF, AC, R)                                                                                                            \
+    hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
                        (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n)
-            if (out_f32) { if (accumulate) LAUNCH2(true, true); else LAUNCH2(true, false); }
-            else LAUNCH2(false, false);
+#define LAUNCH2R(R) do { if (out_f32) { if (accumulate) LAUNCH2(true, true, R); else LAUNCH2(true, false, R); } else LAUNCH2(false, false, R); } while (0)
+            if (rt == 9) LAUNCH2R(9); else LAUNCH2R(8);
+#undef LAUNCH2R
 #undef LAUNCH2
             TR1_LAUNCH_CHECK();
         }
