@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y;
     const int64_t nR = (int64_t)p.T * p.group;
-    const int64_t R0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t R0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * 128 + wave * 32;      // heaviest query tiles first (see attn_fwd_kernel)
 
     int tq[2], hq[2], pre[2], lo[2], hi[2]; bool valid[2];
     float lse2[2], dlt[2];

@@ -33,7 +33,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y % p.n_kv, split = blockIdx.z;
     const int64_t nR = (int64_t)p.T * p.group;
-    const int64_t R0 = (int64_t)blockIdx.x * (64 * CB) + wave * (16 * CB);
+    // query tiles are walked from the LAST one down: later rows of the packed sequence see more keys (causal prompt rows, then the completion
+    // rows with the whole prefix), so the heaviest blocks are dispatched first and the light ones fill the tail (longest-processing-time order)
+    const int qtile = (int)(gridDim.x - 1 - blockIdx.x);
+    const int64_t R0 = (int64_t)qtile * (64 * CB) + wave * (16 * CB);
 
     int tq[CB], hq[CB], pre[CB], lo[CB], hi[CB]; bool valid[CB];
     int wmaxpre = 0, wminlo = 0x7fffffff, wmaxhi = -1;
