@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 #define BN2 256
 #define TILE2_BYTES (BN2 * BK * 2)  // 32 KiB: the B operand tile (and the A tile of the 256-row form)
 
-// RT = 16-row MFMA tiles per wave along M: 8 -> 256 x 256 block, 9 -> 288 x 256 block.  The 288-row form exists for the M = 5074 (P + G*C)
+// RT = 16-row MFMA tiles per wave along M: 7 / 8 / 9 / 10 -> 224 / 256 / 288 / 320 x 256 block.  The 288-row form exists for the M = 5074 (P + G*C)
 // GEMMs with N = 3584: 18 x 14 = 252 blocks fill the 256 CUs in ONE round at 98 % padding efficiency, where 256 x 256 needs two rounds
 // (280 blocks) and 128 x 128 three (1120 blocks on 512 slots).
 template <bool IS_B, int ROWS>
@@ -726,19 +726,29 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
             const int64_t t = blocks(bm, bn);
             return (double)((t + slots - 1) / slots) * (double)slots * (double)(bm * bn) / eff;
         };
-        const double c128 = cost(BM, BN, 512, 0.85), c256 = cost(256, BN2, 256, 1.0), c288 = cost(288, BN2, 256, 1.0);
         int rt = 0;
-        if (force == 256) rt = 8; else if (force == 288) rt = 9; else if (force == 128) rt = 0;
-        else if (M >= 512 && N >= 256) rt = (c288 < c256 && c288 < c128) ? 9 : (c256 < c128 ? 8 : 0);
+        if (force == 224) rt = 7; else if (force == 256) rt = 8; else if (force == 288) rt = 9; else if (force == 320) rt = 10; else if (force == 128) rt = 0;
+        else if (M >= 512 && N >= 256) {
+            double best = cost(BM, BN, 512, 0.85);
+            // intrinsic efficiency of the 8-wave forms relative to 256 x 256 (more A-fragment reuse per B fragment with taller tiles), measured
+            // on M = 5074, N = 37888, K = 3584 after removing the padding of M: 224: 0.94, 288: 1.02, 320: 1.055
+            static const double eff[4] = {0.94, 1.0, 1.02, 1.055};
+            for (int r = 7; r <= 10; ++r) {
+                const double c = cost(r * 32, BN2, 256, eff[r - 7]);
+                if (c < best) { best = c; rt = r; }
+            }
+        }
         if (rt) {
             const int bmx = rt * 32;
             const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
             const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES);
             static bool attr_set = false;
             if (!attr_set) {
-                const int mx = (int)(2 * (288 * BK * 2 + TILE2_BYTES));
+                const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES));
 #define SETA(OF, AC, R) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OF, AC, R>), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
-                SETA(false, false, 8); SETA(true, false, 8); SETA(true, true, 8); SETA(false, false, 9); SETA(true, false, 9); SETA(true, true, 9);
+#define SETR(R) do { SETA(false, false, R); SETA(true, false, R); SETA(true, true, R); } while (0)
+                SETR(7); SETR(8); SETR(9); SETR(10);
+#undef SETR
 #undef SETA
                 attr_set = true;
             }
@@ -747,7 +757,7 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
                        (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n)
 #define LAUNCH2R(R) do { if (out_f32) { if (accumulate) LAUNCH2(true, true, R); else LAUNCH2(true, false, R); } else LAUNCH2(false, false, R); } while (0)
-            if (rt == 9) LAUNCH2R(9); else LAUNCH2R(8);
+            if (rt == 7) LAUNCH2R(7); else if (rt == 9) LAUNCH2R(9); else if (rt == 10) LAUNCH2R(10); else LAUNCH2R(8);
 #undef LAUNCH2R
 #undef LAUNCH2
             TR1_LAUNCH_CHECK();

@@ -130,7 +130,7 @@ def fused():
 def gemm():
     print("== training GEMM: us, TFLOP/s")
     for M, N, K in [(5074, 4608, 3584), (5074, 3584, 3584), (5074, 37888, 3584), (5074, 3584, 18944), (3474, 37888, 3584), (1600, 152064, 3584),
-                    (3584, 18944, 5120), (37888, 3584, 5120), (13376, 3840, 1280), (13376, 5120, 1280), (13376, 1280, 5120), (4096, 4096, 4096), (8192, 8192, 8192)]:
+                    (1600, 37888, 3584), (1600, 3584, 18944), (1600, 4608, 3584), (3474, 3584, 18944), (3474, 4608, 3584), (3584, 18944, 5120), (37888, 3584, 5120), (13376, 3840, 1280), (13376, 5120, 1280), (13376, 1280, 5120), (4096, 4096, 4096), (8192, 8192, 8192)]:
         a, b = rnd(M, K), rnd(N, K)
         us = timeit(lambda: ops.gemm_nt(a, b), reps=10, warm=2)
         print("M=%6d N=%6d K=%6d  %9.1f us  %7.1f TF" % (M, N, K, us, 2.0 * M * N * K / us / 1e6))
