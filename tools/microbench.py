@@ -103,6 +103,14 @@ def w8():
             print("M=%2d N=%6d K=%6d %-4s  bf16 %7.1f  fp8 %7.1f   (fp8 %.2f TB/s)" % (M, N, K, mode, tb, t8, nw * K / t8 / 1e6))
 
 
+def transpose():
+    print("== transpose (dy^T / x^T / W^T operands of the backward GEMMs): us, TB/s (read + write)")
+    for R, C in [(5074, 37888), (5074, 18944), (5074, 3584), (37888, 3584), (3584, 18944), (4608, 3584)]:
+        x = rnd(R, C)
+        us = timeit(lambda: ops.transpose(x), reps=20, warm=3)
+        print("R=%6d C=%6d  %8.1f us  %5.2f TB/s" % (R, C, us, 2.0 * R * C * 2 / us / 1e6))
+
+
 def fused():
     import ctypes
     print("== decode layer pieces, raw C-ABI calls: us  (unfused rmsnorm + gemm [+ swiglu]  vs  norm_gemm)")
@@ -205,5 +213,5 @@ def sampler():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     for w in what:
-        for name in (["skinny", "fixup", "w8", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+        for name in (["skinny", "fixup", "w8", "transpose", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
             globals()[name]()
