@@ -285,28 +285,51 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
                                                              int64_t ld_out, const int* __restrict__ slots, int64_t T, int n_kv, int group,
                                                              int d, int64_t zero_cols) {
-    __shared__ bf16_t tile[64][66];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];       // [packed row][feature], 144-byte rows
     const int kvh = blockIdx.z;
     const int64_t nR = T * group;
     const int64_t R0 = (int64_t)blockIdx.y * 64; const int d0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // 16-byte accesses on both sides (the scalar form ran at ~1 TB/s): 8 features per lane in, 8 packed rows per lane out
+    const bool vec_in = (ld_in % 8 == 0) && (d % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int64_t R = R0 + ty + i * 4; const int dd = d0 + tx;
-        bf16_t v = 0;
-        if (R < nR && dd < d) { const int64_t t = R / group; const int hq = (int)(R - t * group); v = in[t * ld_in + (int64_t)(kvh * group + hq) * d + dd]; }
-        tile[ty + i * 4][tx] = v;
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int rr = idx >> 3, cc = (idx & 7) * 8;
+        const int64_t R = R0 + rr; const int dd = d0 + cc;
+        u32x4_t v = {0, 0, 0, 0};
+        if (R < nR && dd < d) {
+            const int64_t t = R / group; const int hq = (int)(R - t * group);
+            const bf16_t* src = in + t * ld_in + (int64_t)(kvh * group + hq) * d + dd;
+            if (vec_in && dd + 8 <= d) v = *reinterpret_cast<const u32x4_t*>(src);
+            else {
+                bf16_t e8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) e8[e] = (dd + e < d) ? src[e] : (bf16_t)0;
+                v = (u32x4_t){e8[0] | ((unsigned)e8[1] << 16), e8[2] | ((unsigned)e8[3] << 16), e8[4] | ((unsigned)e8[5] << 16), e8[6] | ((unsigned)e8[7] << 16)};
+            }
+        }
+        *reinterpret_cast<u32x4_t*>(&tile[rr][cc]) = v;
     }
     __syncthreads();
+    const int64_t limit = slots ? nR : (zero_cols > nR ? zero_cols : nR);      // rows >= nR of the tile are zero: they are the padding columns
+    const bool vec_out = !slots && (ld_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int dd = d0 + ty + i * 4; const int64_t R = R0 + tx;
-        if (dd >= d) continue;
-        if (R < nR) {
-            const int64_t col = slots ? (int64_t)slots[R] : R;
-            out[((int64_t)kvh * d + dd) * ld_out + col] = tile[tx][ty + i * 4];
-        } else if (R < zero_cols && !slots) {
-            out[((int64_t)kvh * d + dd) * ld_out + R] = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int cc = idx & 63, rr = (idx >> 6) * 8;
+        const int dd = d0 + cc; const int64_t R = R0 + rr;
+        if (dd >= d || R >= limit) continue;
+        bf16_t e8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e8[e] = tile[rr + e][cc];
+        bf16_t* orow = out + ((int64_t)kvh * d + dd) * ld_out;
+        if (vec_out && R + 8 <= limit) {
+            const u32x4_t v = {e8[0] | ((unsigned)e8[1] << 16), e8[2] | ((unsigned)e8[3] << 16), e8[4] | ((unsigned)e8[5] << 16), e8[6] | ((unsigned)e8[7] << 16)};
+            *reinterpret_cast<u32x4_t*>(orow + R) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (R + e < limit) orow[slots ? (int64_t)slots[R + e] : R + e] = e8[e];
         }
     }
 }
