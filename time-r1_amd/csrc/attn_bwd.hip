@@ -225,11 +225,21 @@ struct RowMeta { float lse, dlt; int pre, lo, hi; };
 // NW waves per block, each owning 16 keys (block = 16*NW keys) and sharing the staged 64-query tile.  NW = 8 (D = 64 / 128): the tile is
 // filled by 512 threads, so one staging set is 32 VGPRs and TWO sets fit (two query tiles in flight), the global->LDS traffic per key
 // halves, and the block - alone on its CU with 146 KB of LDS - keeps 8 waves of MFMA work per staged tile instead of 4.
+// TR (the 8-wave form): Q^T / dO^T fragments are read from the ROW-major tiles with ds_read_b64_tr_b16 (each 16-lane group reads a 4 x 16 block:
+// lane i supplies row i/4, columns 4(i%4)..+3, and receives column i of the block) - no transposed copies in LDS or in global memory, half
+// the staging traffic and registers, which pays for THREE query tiles in flight.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+TR1_DEV u32x2_t lds_read_tr16(const char* p) {
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    return __builtin_bit_cast(u32x2_t, v);
+}
+
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles, float* __restrict__ part_k, float* __restrict__ part_v) {
     constexpr int NT = NW * 64, KB = NW * 16;
+    constexpr bool TR = (NW == 8);
     constexpr int KSTR = 2 * D + 16;
-    constexpr int RB = 64 * KSTR, TB = D * 144, BUF = 2 * RB + 2 * TB + 64 * 5 * 4;
+    constexpr int RB = 64 * KSTR, TB = TR ? 0 : D * 144, BUF = 2 * RB + 2 * TB + 64 * 5 * 4;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][Q rows | dO rows | Q^T | dO^T | row meta] + tile list
     int* lds_tiles = reinterpret_cast<int*>(dyn_lds + 2 * BUF);      // [DKDV_MAXT + 1]
 
@@ -275,15 +285,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
 
     // PF register sets: the global loads of PF query tiles are in flight while one is computed.  The block is alone on its CU (146 KB
     // of LDS), so with one set each iteration is an exposed L2/HBM round trip (measured: 2.7 ms per call, 7B config 3, NW = 4).
-    constexpr int PF = 1;     // a second staging set does not fit: the 8-wave form runs 2 waves/SIMD = 256 VGPRs each (compiler spills at PF = 2)
+    constexpr int PF = TR ? 3 : 1;      // 3 tiles in flight (2 or 4 make hipcc spill heavily at the 256-VGPR cap)
     struct QTileRegs { TReg<D, NT> rq, rdo, rqt, rdot; RowMeta rm; };
     QTileRegs rg[PF];
     auto load_tile = [&](QTileRegs& r, int qi) {
         const int64_t Rq0 = (int64_t)qi * 64;
         prows_load<D, NT>(r.rq, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
         prows_load<D, NT>(r.rdo, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
-        T_load<D, NT>(r.rqt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
-        T_load<D, NT>(r.rdot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
+        if (!TR) {
+            T_load<D, NT>(r.rqt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
+            T_load<D, NT>(r.rdot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
+        }
         if (threadIdx.x < 64) {
             const int64_t R = Rq0 + threadIdx.x;
             r.rm = RowMeta{INFINITY, 0.f, 0, 1, 0};
@@ -300,8 +312,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
         const int64_t Rq0 = (int64_t)qi * 64;
         rows_store<D, NT>(r.rq, buf, Rq0, nR, p.d_real);
         rows_store<D, NT>(r.rdo, buf + RB, Rq0, nR, p.d_real);
-        T_store<D, NT>(r.rqt, buf + 2 * RB, Rq0, nR, p.d_real);
-        T_store<D, NT>(r.rdot, buf + 2 * RB + TB, Rq0, nR, p.d_real);
+        if (!TR) {
+            T_store<D, NT>(r.rqt, buf + 2 * RB, Rq0, nR, p.d_real);
+            T_store<D, NT>(r.rdot, buf + 2 * RB + TB, Rq0, nR, p.d_real);
+        }
         if (threadIdx.x < 64) {
             float* mf = reinterpret_cast<float*>(buf + 2 * RB + 2 * TB);
             int* mi = reinterpret_cast<int*>(mf + 128);
@@ -362,6 +376,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             }
         const bf16x8_t pf0 = pack_frag(pr[0], pr[1]), pf1 = pack_frag(pr[2], pr[3]);
         const bf16x8_t df0 = pack_frag(ds[0], ds[1]), df1 = pack_frag(ds[2], ds[3]);
+        if (TR) {
+            // lane (u, g) of a transposed fragment: rows qb + g*4 + (u >> 2), 8 bytes at feature dt*16 + (u & 3)*4; it receives Q[qb + g*4 + r][dt*16 + u]
+            const char* tq = lds_q + (g * 4 + (u >> 2)) * KSTR + (u & 3) * 8;
+            const char* to = lds_do + (g * 4 + (u >> 2)) * KSTR + (u & 3) * 8;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const bf16x8_t q0 = make_frag(lds_read_tr16(tq + dt * 32), lds_read_tr16(tq + 16 * KSTR + dt * 32));
+                const bf16x8_t o0 = make_frag(lds_read_tr16(to + dt * 32), lds_read_tr16(to + 16 * KSTR + dt * 32));
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0, dk[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const bf16x8_t q1 = make_frag(lds_read_tr16(tq + 32 * KSTR + dt * 32), lds_read_tr16(tq + 48 * KSTR + dt * 32));
+                const bf16x8_t o1 = make_frag(lds_read_tr16(to + 32 * KSTR + dt * 32), lds_read_tr16(to + 48 * KSTR + dt * 32));
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
             const char* bq = lds_qt + (dt * 16 + u) * 144 + g * 8;
@@ -379,6 +412,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             const bf16x8_t o1 = make_frag(*reinterpret_cast<const u32x2_t*>(bo + 64), *reinterpret_cast<const u32x2_t*>(bo + 96));
             dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
+        }
         }
         if (it + 1 < n_my) {
             store_tile(rg[(j + 1) % PF], lds_tiles[it + 1], dyn_lds + ((it + 1) & 1) * BUF);
@@ -456,7 +490,7 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     constexpr int NW = (D == 64 || D == 128) ? 8 : 4;
     constexpr int KB = NW * 16;
     const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR + D * 144) + 64;
-    const size_t dyn_kv = 2 * (2 * 64 * KSTR + 2 * D * 144 + 64 * 5 * 4) + (DKDV_MAXT + 1) * 4;
+    const size_t dyn_kv = 2 * (2 * 64 * KSTR + (NW == 8 ? 0 : 2 * D * 144) + 64 * 5 * 4) + (DKDV_MAXT + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq);
@@ -507,8 +541,11 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     TR1_CHECK_ARG(d_pad == 32 || d_pad == 64 || d_pad == 96 || d_pad == 128, "attention bwd: padded head dim must be 32/64/96/128");
     TR1_CHECK_ARG(head_dim % 8 == 0 && q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && do_ld % 8 == 0 && o_ld % 8 == 0,
                   "attention bwd: dims must be multiples of 8");
-    TR1_CHECK_ARG(kt_ld % 8 == 0 && kt_ld >= n_slots && qt_ld % 8 == 0 && qt_ld >= T * p.group && dot_ld % 8 == 0 && dot_ld >= T * p.group,
-                  "attention bwd: transposed leading dims too small");
+    // Q^T / dO^T are only read by the 4-wave dK/dV form (head dims padded to 32 / 96); the 8-wave form transposes in its LDS reads
+    const bool need_qt = dkdv_keys_per_block(d_pad) == 64;
+    TR1_CHECK_ARG(kt_ld % 8 == 0 && kt_ld >= n_slots, "attention bwd: K^T leading dim too small");
+    TR1_CHECK_ARG(!need_qt || (QT && dOT && qt_ld % 8 == 0 && qt_ld >= T * p.group && dot_ld % 8 == 0 && dot_ld >= T * p.group),
+                  "attention bwd: Q^T / dO^T missing or leading dims too small");
     TR1_CHECK_ARG(dk_ld % 4 == 0 && dv_ld % 4 == 0, "attention bwd: dk/dv leading dims must be multiples of 4");
     if (T == 0 || n_slots == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
