@@ -43,12 +43,21 @@ __global__ void attn_qmeta_kernel(const int* __restrict__ pre, const int* __rest
     if (threadIdx.x == 0) { qmeta[blockIdx.x * 3 + 0] = mp; qmeta[blockIdx.x * 3 + 1] = ml; qmeta[blockIdx.x * 3 + 2] = mh; }
 }
 
+// Transposed MFMA operands straight from a ROW-major LDS tile: ds_read_b64_tr_b16.  Every lane supplies its own 8-byte address; inside a 16-lane
+// group lane i supplies row i/4, columns 4(i%4)..+3 of a 4 x 16 block and receives column i of that block (probed on MI355X).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+TR1_DEV u32x2_t lds_read_tr16(const char* p) {
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    return __builtin_bit_cast(u32x2_t, v);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- dQ
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     constexpr int KSTR = 2 * D + 16;
-    constexpr int RB = ATT_KV * KSTR, TB = D * 144, BUF = 2 * RB + TB;
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][K rows | V rows | K^T] + meta
+    constexpr int RB = ATT_KV * KSTR, BUF = 2 * RB;
+    constexpr int PF = 2;                                             // K/V tiles in flight (register ring)
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][K rows | V rows] + meta; K^T fragments come from the K rows (tr16 reads)
     int* lds_meta = reinterpret_cast<int*>(dyn_lds + 2 * BUF);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y;
@@ -103,29 +112,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 
     const int n_my = tr.n_rel;
     const int64_t kcol = (int64_t)kvh * p.d_real;
-    TReg<D> rk, rv, rkt;
+    struct KVRegs { TReg<D> rk, rv; };
+    KVRegs rg[PF];
+#define DQ_KV0(i) ((int64_t)att_tile_at(tr, (i)) * ATT_KV)
+#define DQ_LOAD(r, i) do { rows_load<D>((r).rk, p.K, p.k_ld, kcol, DQ_KV0(i), p.n_slots, p.d_real); rows_load<D>((r).rv, p.V, p.v_ld, kcol, DQ_KV0(i), p.n_slots, p.d_real); } while (0)
+#define DQ_STORE(r, i, buf) do { rows_store<D>((r).rk, (buf), DQ_KV0(i), p.n_slots, p.d_real); rows_store<D>((r).rv, (buf) + RB, DQ_KV0(i), p.n_slots, p.d_real); } while (0)
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (j < n_my) DQ_LOAD(rg[j], j);
     if (n_my > 0) {
-        const int64_t kv0 = (int64_t)att_tile_at(tr, 0) * ATT_KV;
-        rows_load<D>(rk, p.K, p.k_ld, kcol, kv0, p.n_slots, p.d_real);
-        rows_load<D>(rv, p.V, p.v_ld, kcol, kv0, p.n_slots, p.d_real);
-        T_load<D>(rkt, p.KT, p.kt_ld, kvh, kv0, p.n_slots, p.d_real);
-        rows_store<D>(rk, dyn_lds, kv0, p.n_slots, p.d_real);
-        rows_store<D>(rv, dyn_lds + RB, kv0, p.n_slots, p.d_real);
-        T_store<D>(rkt, dyn_lds + 2 * RB, kv0, p.n_slots, p.d_real);
-        if (n_my > 1) {
-            const int64_t kv1 = (int64_t)att_tile_at(tr, 1) * ATT_KV;
-            rows_load<D>(rk, p.K, p.k_ld, kcol, kv1, p.n_slots, p.d_real);
-            rows_load<D>(rv, p.V, p.v_ld, kcol, kv1, p.n_slots, p.d_real);
-            T_load<D>(rkt, p.KT, p.kt_ld, kvh, kv1, p.n_slots, p.d_real);
-        }
+        DQ_STORE(rg[0], 0, dyn_lds);
+        if (PF < n_my) DQ_LOAD(rg[0], PF);
     }
     __syncthreads();
 
-    for (int it = 0; it < n_my; ++it) {
+    for (int it0 = 0; it0 < n_my; it0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int it = it0 + j;
+        if (it >= n_my) break;
         const int kv0 = att_tile_at(tr, it) * ATT_KV;
         const char* lds_k = dyn_lds + (it & 1) * BUF;
         const char* lds_v = lds_k + RB;
-        const char* lds_kt = lds_k + 2 * RB;
         if (wave_active) {
             f32x4_t s[4][2], dp[4][2];
 #pragma unroll
@@ -179,8 +187,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
                 for (int dt = 0; dt < D / 16; ++dt) {
-                    const char* base = lds_kt + (dt * 16 + u) * 144 + kk * 64 + g * 8;
-                    const bf16x8_t ktf = make_frag(*reinterpret_cast<const u32x2_t*>(base), *reinterpret_cast<const u32x2_t*>(base + 32));
+                    // K^T[d = dt*16 + u][kv = kk*32 + g*4 .. +3 | kk*32 + 16 + g*4 .. +3] from the K rows
+                    const char* base = lds_k + (kk * 32 + g * 4 + (u >> 2)) * KSTR + dt * 32 + (u & 3) * 8;
+                    const bf16x8_t ktf = make_frag(lds_read_tr16(base), lds_read_tr16(base + 16 * KSTR));
                     dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][0], dq[dt][0], 0, 0, 0);
                     dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[kk][1], dq[dt][1], 0, 0, 0);
                 }
@@ -188,19 +197,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         }
         if (it + 1 < n_my) {
             char* nb = dyn_lds + ((it + 1) & 1) * BUF;
-            const int64_t kvn = (int64_t)att_tile_at(tr, it + 1) * ATT_KV;
-            rows_store<D>(rk, nb, kvn, p.n_slots, p.d_real);
-            rows_store<D>(rv, nb + RB, kvn, p.n_slots, p.d_real);
-            T_store<D>(rkt, nb + 2 * RB, kvn, p.n_slots, p.d_real);
-            if (it + 2 < n_my) {
-                const int64_t kv2 = (int64_t)att_tile_at(tr, it + 2) * ATT_KV;
-                rows_load<D>(rk, p.K, p.k_ld, kcol, kv2, p.n_slots, p.d_real);
-                rows_load<D>(rv, p.V, p.v_ld, kcol, kv2, p.n_slots, p.d_real);
-                T_load<D>(rkt, p.KT, p.kt_ld, kvh, kv2, p.n_slots, p.d_real);
-            }
+            DQ_STORE(rg[(j + 1) % PF], it + 1, nb);
+            if (it + 1 + PF < n_my) DQ_LOAD(rg[(j + 1) % PF], it + 1 + PF);
         }
         __syncthreads();
     }
+    }
+#undef DQ_KV0
+#undef DQ_LOAD
+#undef DQ_STORE
     const float scale = p.scale_log2 * 0.6931471805599453f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -228,11 +233,6 @@ struct RowMeta { float lse, dlt; int pre, lo, hi; };
 // TR (the 8-wave form): Q^T / dO^T fragments are read from the ROW-major tiles with ds_read_b64_tr_b16 (each 16-lane group reads a 4 x 16 block:
 // lane i supplies row i/4, columns 4(i%4)..+3, and receives column i of the block) - no transposed copies in LDS or in global memory, half
 // the staging traffic and registers, which pays for THREE query tiles in flight.
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-TR1_DEV u32x2_t lds_read_tr16(const char* p) {
-    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
-    return __builtin_bit_cast(u32x2_t, v);
-}
 
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles, float* __restrict__ part_k, float* __restrict__ part_v) {
@@ -489,7 +489,7 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     constexpr int KSTR = 2 * D + 16;
     constexpr int NW = (D == 64 || D == 128) ? 8 : 4;
     constexpr int KB = NW * 16;
-    const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR + D * 144) + 64;
+    const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR) + 64;
     const size_t dyn_kv = 2 * (2 * 64 * KSTR + (NW == 8 ? 0 : 2 * D * 144) + 64 * 5 * 4) + (DKDV_MAXT + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -543,7 +543,6 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
                   "attention bwd: dims must be multiples of 8");
     // Q^T / dO^T are only read by the 4-wave dK/dV form (head dims padded to 32 / 96); the 8-wave form transposes in its LDS reads
     const bool need_qt = dkdv_keys_per_block(d_pad) == 64;
-    TR1_CHECK_ARG(kt_ld % 8 == 0 && kt_ld >= n_slots, "attention bwd: K^T leading dim too small");
     TR1_CHECK_ARG(!need_qt || (QT && dOT && qt_ld % 8 == 0 && qt_ld >= T * p.group && dot_ld % 8 == 0 && dot_ld >= T * p.group),
                   "attention bwd: Q^T / dO^T missing or leading dims too small");
     TR1_CHECK_ARG(dk_ld % 4 == 0 && dv_ld % 4 == 0, "attention bwd: dk/dv leading dims must be multiples of 4");

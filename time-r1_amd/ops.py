@@ -377,8 +377,7 @@ class HipOps:
         self._chk(q, k, v, o, do)
         T = q.shape[0]
         group = n_heads // n_kv
-        kt = self.pack_transpose(k[:n_slots], n_kv, n_kv, head_dim)
-        qt = dot = None
+        qt = dot = None                                     # the dQ kernel reads its K^T fragments from the K rows (KT argument unused)
         if (head_dim + 31) // 32 * 32 not in (64, 128):     # the 8-wave dK/dV kernel reads Q^T / dO^T straight from the row-major tiles
             qt = self.pack_transpose(q, n_heads, n_kv, head_dim)
             dot = self.pack_transpose(do, n_heads, n_kv, head_dim)
@@ -389,7 +388,7 @@ class HipOps:
         qmeta = self._workspace("attn_qmeta", 3 * ((T * group + 63) // 64), I32)
         nws = self.L.raw("tr1_attn_bwd_workspace_floats")(T, n_heads, n_kv, n_slots, head_dim)
         ws = self._workspace("attn_bwd_part", nws, F32) if nws else None
-        self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(kt), _ld(kt), _p(qt), _ld(qt) if qt is not None else 0, _p(dot), _ld(dot) if dot is not None else 0,
+        self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), None, 0, _p(qt), _ld(qt) if qt is not None else 0, _p(dot), _ld(dot) if dot is not None else 0,
                     _p(o), _ld(o), _p(do), _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(pre), _p(lo),
                     _p(hi), _p(qmeta), _p(ws), nws, T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
         return dq, dk, dv
