@@ -167,6 +167,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // RT = 16-row MFMA tiles per wave along M: 7 / 8 / 9 / 10 -> 224 / 256 / 288 / 320 x 256 block.  The 288-row form exists for the M = 5074 (P + G*C)
 // GEMMs with N = 3584: 18 x 14 = 252 blocks fill the 256 CUs in ONE round at 98 % padding efficiency, where 256 x 256 needs two rounds
 // (280 blocks) and 128 x 128 three (1120 blocks on 512 slots).
+// Epilogue of the 8-wave forms: lane (u, g) owns output row mrow0 + i*16 + u, 16 contiguous columns from ncol0 + g*16.
+template <bool OUT_F32, bool ACCUM, int RT>
+TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                          int64_t M, int64_t N, int64_t ldc, int64_t ldr, int64_t mrow0, int64_t ncol0, int u, int g) {
+    const int64_t nbase = ncol0 + g * 16;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int64_t m = mrow0 + i * 16 + u;
+        if (m >= M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t n = nbase + h * 8;
+            if (n + 8 > N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][h * 2 + (e >> 2)][e & 3];
+            if (bias) {
+                const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(bv[e]); v[2 * e + 1] += bfhi(bv[e]); }
+            }
+            if (residual) {
+                const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
+            }
+            if (OUT_F32) {
+                float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
+                f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                if (ACCUM) {
+                    const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(cp), p1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
+                    o0 += p0; o1 += p1;
+                }
+                *reinterpret_cast<f32x4_t*>(cp) = o0;
+                *reinterpret_cast<f32x4_t*>(cp + 4) = o1;
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(Cv) + m * ldc + n;
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<u32x4_t*>(cp) = o;
+            }
+        }
+    }
+}
+
 template <bool IS_B, int ROWS>
 TR1_DEV void stage_tile2(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
                          int wave, int lane) {
@@ -251,46 +297,159 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
     }
-    const int64_t nbase = n0 + wn * 64 + g * 16;
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int64_t m = m0 + wm * (RT * 16) + i * 16 + u;
-        if (m >= M) continue;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t n = nbase + h * 8;
-            if (n + 8 > N) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[i][h * 2 + (e >> 2)][e & 3];
-            if (bias) {
-                const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(bias + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(bv[e]); v[2 * e + 1] += bfhi(bv[e]); }
-            }
-            if (residual) {
-                const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
-            }
-            if (OUT_F32) {
-                float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
-                f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                if (ACCUM) {
-                    const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(cp), p1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
-                    o0 += p0; o1 += p1;
-                }
-                *reinterpret_cast<f32x4_t*>(cp) = o0;
-                *reinterpret_cast<f32x4_t*>(cp + 4) = o1;
-            } else {
-                bf16_t* cp = reinterpret_cast<bf16_t*>(Cv) + m * ldc + n;
-                u32x4_t o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<u32x4_t*>(cp) = o;
-            }
-        }
+    store_acc256<OUT_F32, ACCUM, RT>(acc, Cv, bias, residual, M, N, ldc, ldr, m0 + wm * (RT * 16), n0 + wn * 64, u, g);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Phased ("ping-pong") form of the 8-wave kernel.  Same block tile, LDS image, swizzle, fragment mapping and epilogue as
+// gemm_nt256_kernel, but the K loop is cut into 4 phases per 64-wide K-tile and the two wave groups (wm = 0 / 1: the two waves
+// that share a SIMD) run one barrier apart, so while one wave of a SIMD issues its MFMAs the other one reads its next fragments
+// from LDS and issues the HBM->LDS DMA for the tiles ahead - the matrix pipe never waits for LDS.
+//   phase q of tile t:  [ds_read the A fragments of M-quarter q (phase 0: also all B fragments);  issue this phase's DMA rounds;
+//                        s_waitcnt lgkmcnt(0)]  s_barrier  [MFMA quarter q x all 4 N fragments x 2 k-steps]  s_barrier
+//   DMA schedule (one "round" = 8 KiB = 64 rows, one global_load_lds per thread; every wave issues the same number of rounds so
+//   the counted vmcnt below means the same thing in every wave):
+//       phases 0, 1 of tile t: the A rounds of tile t+1   (that buffer's A region was last read in phase 3 of tile t-1)
+//       phases 2, 3 of tile t: the 4 B rounds of tile t+2 (tile t's B region is only read in phase 0)
+//   phase 3 waits vmcnt(4) (the B rounds of t+2 stay in flight) BEFORE its first barrier; tile t+1 is first read one phase later.
+//   Every ds_read is retired (lgkmcnt(0)) before the barrier that ends its load section, so a region may be restaged from the next
+//   barrier interval on.  A tiles whose row count is not a multiple of 64 send the surplus half round to a 4 KiB junk area.
+// ------------------------------------------------------------------------------------------------------------------
+#define TR1_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TR1_BARRIER() do { TR1_PIN(); __builtin_amdgcn_s_barrier(); TR1_PIN(); } while (0)
+
+template <bool IS_B, int REGION_ROWS>
+TR1_DEV void stage_round(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_region,
+                         char* junk, int round, int wave, int lane) {
+    const int inst = round * 8 + wave;                                   // 8 rows (1 KiB) per wave-instruction
+    int row = inst * 8 + (lane >> 3);
+    char* dst = lds_region + inst * 1024;
+    if (REGION_ROWS % 64 != 0 && inst * 8 >= REGION_ROWS) { dst = junk + (wave & 3) * 1024; row = REGION_ROWS - 8 + (lane >> 3); }   // wave-uniform
+    const int logical = (lane & 7) ^ (IS_B ? keyB(row) : keyA(row));
+    int64_t grow = row0 + row;
+    if (grow >= rows_valid) grow = rows_valid - 1;
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + grow * ld + k0 + logical * 8), (lptr_t)dst, 16, 0, 0);
+}
+
+template <bool OUT_F32, bool ACCUM, int RT>
+__global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
+                                                        const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                        int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                                        int64_t ldr, int tiles_m, int tiles_n) {
+    constexpr int BMX = RT * 32;
+    constexpr int A_BYTES = BMX * BK * 2, BUF_BYTES = A_BYTES + TILE2_BYTES;
+    constexpr int AR = (BMX + 63) / 64;                // A rounds per K-tile; phases 0 / 1 issue AR0 / AR1 of them
+    constexpr int AR0 = (AR + 1) / 2;
+    constexpr int Q0 = 0, Q1 = (RT + 3) / 4, Q2 = Q1 + (RT + 2) / 4, Q3 = Q2 + (RT + 1) / 4, Q4 = RT;   // M-quarters (m-tile ranges)
+    constexpr int QMAX = Q1 - Q0;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];  // [buf][A | B] + junk
+    char* const junk = smem2 + 2 * BUF_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = tiles_m * tiles_n;
+    int wgid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
+    const int GROUP_M = 4;
+    const int group = wgid / (GROUP_M * tiles_n);
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = wgid - group * GROUP_M * tiles_n;
+    const int tm = first_m + in_group % gsz;
+    const int tn = in_group / gsz;
+    const int64_t m0 = (int64_t)tm * BMX, n0 = (int64_t)tn * BN2;
+
+    f32x4_t acc[RT][4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(K / BK);
+    const int u = lane & 15, g = lane >> 4;
+    // per-lane LDS byte offsets of the fragment reads (k-step 1 = k-step 0 with chunk bit 2 flipped: offset ^ 64)
+    const int a_off = (wm * (RT * 16) + u) * 128 + ((g ^ ((u >> 1) & 7)) << 4);
+    const int b_off = (wn * 64 + (u >> 2) * 16 + (u & 3)) * 128 + ((g ^ (((u >> 2) << 1) | ((u >> 1) & 1))) << 4);
+
+#define STAGE_A(t, r) stage_round<false, BMX>(A, lda, m0, M, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES, junk, (r), wave, lane)
+#define STAGE_B(t, r) stage_round<true, BN2>(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, junk, (r), wave, lane)
+    // prologue: tile 0 complete, B of tile 1 in flight
+#pragma unroll
+    for (int r = 0; r < 4; ++r) STAGE_B(0, r);
+#pragma unroll
+    for (int r = 0; r < AR; ++r) STAGE_A(0, r);
+    if (nk > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) STAGE_B(1, r);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TR1_BARRIER();
+    if (wm == 1) TR1_BARRIER();                        // the second wave group runs one barrier interval behind the first
+
+    bf16x8_t bf[4][2], af[QMAX][2];
+#define LOAD_A(QA, QB) do {                                                                                    \
+        _Pragma("unroll") for (int i = (QA); i < (QB); ++i) {                                                  \
+            af[i - (QA)][0] = *reinterpret_cast<const bf16x8_t*>(curA + a_off + i * 2048);                     \
+            af[i - (QA)][1] = *reinterpret_cast<const bf16x8_t*>(curA + (a_off ^ 64) + i * 2048);              \
+        } } while (0)
+#define COMPUTE(QA, QB) do {                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        TR1_BARRIER();                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+        _Pragma("unroll") for (int i = (QA); i < (QB); ++i)                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i - (QA)][ks], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        TR1_BARRIER();                                                                                         \
+    } while (0)
+
+    for (int t = 0; t < nk; ++t) {
+        const char* curA = smem2 + (t & 1) * BUF_BYTES;
+        const char* curB = curA + A_BYTES;
+        // ---- phase 0: all B fragments + A quarter 0; A rounds [0, AR0) of tile t+1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf[j][0] = *reinterpret_cast<const bf16x8_t*>(curB + b_off + j * 512);
+            bf[j][1] = *reinterpret_cast<const bf16x8_t*>(curB + (b_off ^ 64) + j * 512);
+        }
+        LOAD_A(Q0, Q1);
+        if (t + 1 < nk) {
+#pragma unroll
+            for (int r = 0; r < AR0; ++r) STAGE_A(t + 1, r);
+        }
+        COMPUTE(Q0, Q1);
+        // ---- phase 1: A quarter 1; the remaining A rounds of tile t+1
+        LOAD_A(Q1, Q2);
+        if (t + 1 < nk) {
+#pragma unroll
+            for (int r = AR0; r < AR; ++r) STAGE_A(t + 1, r);
+        }
+        COMPUTE(Q1, Q2);
+        // ---- phase 2: A quarter 2; B rounds 0, 1 of tile t+2 (tile t's B region is free: read in phase 0 only)
+        LOAD_A(Q2, Q3);
+        if (t + 2 < nk) { STAGE_B(t + 2, 0); STAGE_B(t + 2, 1); }
+        COMPUTE(Q2, Q3);
+        // ---- phase 3: A quarter 3; B rounds 2, 3 of tile t+2; tile t+1 must have landed before the next barrier
+        LOAD_A(Q3, Q4);
+        if (t + 2 < nk) {
+            STAGE_B(t + 2, 2); STAGE_B(t + 2, 3);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        COMPUTE(Q3, Q4);
+    }
+    if (wm == 0) TR1_BARRIER();
+#undef LOAD_A
+#undef COMPUTE
+#undef STAGE_A
+#undef STAGE_B
+    store_acc256<OUT_F32, ACCUM, RT>(acc, Cv, bias, residual, M, N, ldc, ldr, m0 + wm * (RT * 16), n0 + wn * 64, u, g);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -741,11 +900,14 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
         if (rt) {
             const int bmx = rt * 32;
             const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
-            const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES);
+            static int phased = -1;                    // TR1_GEMM_PHASED=0 selects the single-barrier form (A/B measurements)
+            if (phased < 0) { const char* e = getenv("TR1_GEMM_PHASED"); phased = e ? atoi(e) : 1; }
+            const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + (phased ? 4096 : 0);
             static bool attr_set = false;
             if (!attr_set) {
-                const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES));
-#define SETA(OF, AC, R) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OF, AC, R>), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+                const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES)) + 4096;
+#define SETA(OF, AC, R) do { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<OF, AC, R>), hipFuncAttributeMaxDynamicSharedMemorySize, mx); \
+                             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<OF, AC, R>), hipFuncAttributeMaxDynamicSharedMemorySize, mx); } while (0)
 #define SETR(R) do { SETA(false, false, R); SETA(true, false, R); SETA(true, true, R); } while (0)
                 SETR(7); SETR(8); SETR(9); SETR(10);
 #undef SETR
@@ -754,8 +916,10 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
             }
             dim3 grid2((unsigned)(t2m * t2n));
 #define LAUNCH2(OF, AC, R)                                                                                                            \
-    hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
-                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n)
+    do { if (phased) hipLaunchKernelGGL((gemm_nt8p_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
+                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n);                                     \
+    else hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
+                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n); } while (0)
 #define LAUNCH2R(R) do { if (out_f32) { if (accumulate) LAUNCH2(true, true, R); else LAUNCH2(true, false, R); } else LAUNCH2(false, false, R); } while (0)
             if (rt == 7) LAUNCH2R(7); else if (rt == 9) LAUNCH2R(9); else if (rt == 10) LAUNCH2R(10); else LAUNCH2R(8);
 #undef LAUNCH2R
