@@ -877,7 +877,7 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
         TR1_LAUNCH_CHECK();
     }
     {   // tile choice: CU-rounds x block area / relative efficiency of the structure (tile-count quantisation).
-        // 128x128 runs 2 blocks per CU (512 slots), the 8-wave 256/288-row forms 1 block per CU at ~1.18x the MFMA rate per CU.
+        // 128x128 runs 2 blocks per CU (512 slots), the phased 8-wave forms 1 block per CU at ~1.25x the MFMA rate per CU.
         static int force = -1;
         if (force < 0) { const char* e = getenv("TR1_GEMM_TILE"); force = e ? atoi(e) : 0; }
         auto blocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
@@ -888,10 +888,11 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
         int rt = 0;
         if (force == 224) rt = 7; else if (force == 256) rt = 8; else if (force == 288) rt = 9; else if (force == 320) rt = 10; else if (force == 128) rt = 0;
         else if (M >= 512 && N >= 256) {
-            double best = cost(BM, BN, 512, 0.85);
-            // intrinsic efficiency of the 8-wave forms relative to 256 x 256 (more A-fragment reuse per B fragment with taller tiles), measured
-            // on M = 5074, N = 37888, K = 3584 after removing the padding of M: 224: 0.94, 288: 1.02, 320: 1.055
-            static const double eff[4] = {0.94, 1.0, 1.02, 1.055};
+            double best = cost(BM, BN, 512, 0.80);
+            // intrinsic efficiency of the phased 8-wave forms relative to 256 x 256 (more A-fragment reuse per B fragment with taller tiles),
+            // measured on M = 37888, N = 3584, K = 5120 and 8192^3 after removing tile-count quantisation: 224: 0.94, 288: 1.025, 320: 1.03;
+            // the 128 x 128 form reaches 0.80 of the 256 x 256 rate per CU (tools/microbench.py gemm with TR1_GEMM_TILE forced)
+            static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
             for (int r = 7; r <= 10; ++r) {
                 const double c = cost(r * 32, BN2, 256, eff[r - 7]);
                 if (c < best) { best = c; rt = r; }
