@@ -781,7 +781,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
         if (M <= 16) NG4(2, 1); else NG4(2, 2);
 #undef NG4
     }
-    else     { if (M <= 16) NG(4, 4, 1, false); else if (M <= 32) NG(4, 2, 2, false); else NG(4, 2, 4, false); }
+    else     { if (M <= 16) NG(8, 2, 1, false); else if (M <= 32) NG(4, 2, 2, false); else NG(4, 2, 4, false); }   // 8 waves: see tr1_norm_gemm_qkv
 #undef NG
     TR1_LAUNCH_CHECK();
 }
@@ -797,10 +797,12 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
               (int)n_heads, (int)n_kv, (int)head_dim};
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(heads * (head_dim / 32)));
-#define NGQ(UN, MGR)                                                                                                                  \
-    hipLaunchKernelGGL((norm_gemm_skinny_kernel<4, UN, MGR, false, 2, true>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)lnw,      \
+    // M <= 16: only heads * hd/32 = 144 blocks (7B) for 256 CUs, so 8 waves per block split K and double the loads in flight per CU
+    // (tools/microbench.py fused, TR1_NG_CFG: 15.8 -> 13.5 us)
+#define NGQ(WV, UN, MGR)                                                                                                              \
+    hipLaunchKernelGGL((norm_gemm_skinny_kernel<WV, UN, MGR, false, 2, true>), grid, dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, \
                        (const bf16_t*)Wqkv, (bf16_t*)nullptr, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)0, qe)
-    if (M <= 16) NGQ(4, 1); else if (M <= 32) NGQ(2, 2); else NGQ(2, 4);
+    if (M <= 16) NGQ(8, 2, 1); else if (M <= 32) NGQ(4, 2, 2); else NGQ(4, 2, 4);
 #undef NGQ
     TR1_LAUNCH_CHECK();
 }
