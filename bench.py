@@ -341,7 +341,7 @@ def main():
         sk_ms = sum(e0.elapsed_time(e1) for s, M, N, K, e0, e1 in rec if s)
         sk_by = sum(2.0 * (N * K + M * K + M * N) for s, M, N, K, e0, e1 in rec if s)
         sk_n = sum(1 for r in rec if r[0])
-        mfma = {"kernel": "gemm_nt_kernel+gemm_nt256_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
+        mfma = {"kernel": "gemm_nt_kernel+gemm_nt8p_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms / nstep, "traffic": None}
         mfma["frac"] = mfma["achieved"] / PEAK_BF16_TFLOPS
         hbm = {"kernel": "gemm_skinny_kernel+norm_gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
@@ -357,7 +357,7 @@ def main():
                     return sum(pmc[k]["launches"] * pmc[k]["fetch_bytes_per_launch_corrected"] for k in names if k in pmc) / max(n, 1)
                 hbm["traffic"] = fam("gemm_skinny_kernel", "norm_gemm_skinny_kernel")
                 hbm["algorithmic_bytes_per_launch"] = sk_by / max(sk_n, 1)
-                mfma["traffic"] = fam("gemm_nt_kernel", "gemm_nt256_kernel")
+                mfma["traffic"] = fam("gemm_nt_kernel", "gemm_nt8p_kernel", "gemm_nt256_kernel")
                 mfma["algorithmic_flops_per_launch"] = big_fl / max(big_n, 1)
                 hbm["traffic_source"] = mfma["traffic_source"] = "profiles/r01_pmc_traffic.json"
         except Exception:
