@@ -52,8 +52,11 @@ int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out,
 /* ref: Qwen2RMSNorm TF:96-110 (fp32 math, cast to bf16 BEFORE the weight multiply).  If residual != NULL the kernel first forms
  * xsum = bf16(x + residual) (the decoder's residual add, TF:559-624), writes it, and normalises xsum.  rstd (fp32[rows]) optional. */
 int tr1_rmsnorm_fwd(const void* x, const void* residual, const void* w, void* y, void* xsum, void* rstd, int64_t rows, int64_t cols, float eps, void* stream);
-/* dx = rmsnorm'(dy) (+ dres if given);  dw_f32[c] += sum_r dy*xhat   (autograd of the above; ref: accelerator.backward, TF trainer.py:1952-1961) */
-int tr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* rstd, const void* dres, void* dx, void* dw_f32, int64_t rows, int64_t cols, void* stream);
+/* dx = rmsnorm'(dy) (+ dres if given);  dw_f32[c] += sum_r dy*xhat   (autograd of the above; ref: accelerator.backward, TF trainer.py:1952-1961).
+ * dw_f32 may be NULL (no weight gradient); otherwise ws_f32 holds tr1_rmsnorm_bwd_workspace_floats() floats of per-block partial rows that a
+ * second kernel adds in a fixed order (no atomics: the gradient is reproducible). */
+int tr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* rstd, const void* dres, void* dx, void* dw_f32, void* ws_f32, int64_t ws_floats, int64_t rows, int64_t cols, void* stream);
+int64_t tr1_rmsnorm_bwd_workspace_floats(int64_t rows, int64_t cols);
 /* ref: nn.LayerNorm(eps=1e-6) in VisionBlock TF:425-449 and PatchMerger.ln_q TF:277-290 */
 int tr1_layernorm_fwd(const void* x, const void* w, const void* b, void* y, void* mean, void* rstd, int64_t rows, int64_t cols, float eps, void* stream);
 int tr1_layernorm_bwd(const void* dy, const void* x, const void* w, const void* mean, const void* rstd, void* dx, void* dw_f32, void* db_f32, int64_t rows, int64_t cols, void* stream);

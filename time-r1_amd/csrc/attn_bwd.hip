@@ -11,21 +11,30 @@
 // gridDim.z blocks (the prefix key blocks see ~all query tiles, the suffix blocks only a few): partial dK/dV go to an fp32
 // workspace and a small reduce kernel sums and rounds them.
 #include "attn_common.h"
+#include <stdlib.h>
 
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, int64_t do_ld, const bf16_t* __restrict__ O, int64_t o_ld,
-                                  float* __restrict__ delta, int T, int n_heads, int d) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= (int64_t)T * n_heads) return;
-    const int t = (int)(i / n_heads), h = (int)(i - (int64_t)t * n_heads);
+// delta[h][t] = sum_d dO[t,h,d] * O[t,h,d].  16 lanes per (t, h) row, 16 bytes per lane: consecutive rows are consecutive in memory, so a
+// wave instruction reads 4 rows = 1 KiB contiguous (was one thread per row: 64 different lines per load, 72 us for 73 MB at config 3).
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, int64_t do_ld, const bf16_t* __restrict__ O, int64_t o_ld,
+                                                         float* __restrict__ delta, int T, int n_heads, int d) {
+    const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    const bool ok = i < (int64_t)T * n_heads;
+    const int t = ok ? (int)(i / n_heads) : 0, h = ok ? (int)(i - (int64_t)t * n_heads) : 0;
     const bf16_t* a = dO + (int64_t)t * do_ld + (int64_t)h * d;
     const bf16_t* b = O + (int64_t)t * o_ld + (int64_t)h * d;
     float s = 0.f;
-    for (int c = 0; c < d; c += 8) {
-        const u32x4_t x = *reinterpret_cast<const u32x4_t*>(a + c), y = *reinterpret_cast<const u32x4_t*>(b + c);
+    if (ok)
+        for (int c = sub * 8; c < d; c += 128) {
+            const u32x4_t x = *reinterpret_cast<const u32x4_t*>(a + c), y = *reinterpret_cast<const u32x4_t*>(b + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += bflo(x[j]) * bflo(y[j]) + bfhi(x[j]) * bfhi(y[j]);
-    }
-    delta[(int64_t)h * T + t] = s;
+            for (int j = 0; j < 4; ++j) s += bflo(x[j]) * bflo(y[j]) + bfhi(x[j]) * bfhi(y[j]);
+        }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if (ok && sub == 0) delta[(int64_t)h * T + t] = s;
 }
 
 // per 64 packed rows: (max pre, min lo, max hi) over rows with a non-empty [lo,hi]
@@ -34,7 +43,7 @@ __global__ void attn_qmeta_kernel(const int* __restrict__ pre, const int* __rest
     const int64_t R = (int64_t)blockIdx.x * 64 + threadIdx.x;
     int mp = 0, ml = 0x7fffffff, mh = -1;
     if (R < (int64_t)T * group) {
-        const int t = (int)(R / group);
+        const int t = (int)((unsigned)R / (unsigned)group);
         mp = pre[t];
         if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; }
     }
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         const int64_t R = R0 + cb * 16 + u;
         valid[cb] = R < nR;
         const int64_t Rc = valid[cb] ? R : nR - 1;
-        tq[cb] = (int)(Rc / p.group); hq[cb] = (int)(Rc - (int64_t)tq[cb] * p.group);
+        att_split_row(p, Rc, tq[cb], hq[cb]);
         pre[cb] = valid[cb] ? p.pre[tq[cb]] : 0;
         lo[cb] = valid[cb] ? p.lo[tq[cb]] : 1;
         hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
@@ -234,20 +243,23 @@ struct RowMeta { float lse, dlt; int pre, lo, hi; };
 // lane i supplies row i/4, columns 4(i%4)..+3, and receives column i of the block) - no transposed copies in LDS or in global memory, half
 // the staging traffic and registers, which pays for THREE query tiles in flight.
 
-template <int D, int NW>
+// KT = 16-key tiles per wave.  <8, 1>: 8 waves x 16 keys; <4, 2>: 4 waves x 32 keys - every Q / dO / Q^T / dO^T fragment read from LDS then
+// feeds two MFMAs, which halves the LDS instructions per MFMA (the 16-key form reads one fragment per MFMA and is LDS-issue bound).
+template <int D, int NW, int KT = 1>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, int n_qtiles, float* __restrict__ part_k, float* __restrict__ part_v) {
-    constexpr int NT = NW * 64, KB = NW * 16;
-    constexpr bool TR = (NW == 8);
+    constexpr int NT = NW * 64, KB = NW * 16 * KT;
+    constexpr bool TR = (NW == 8) || (KT == 2);
     constexpr int KSTR = 2 * D + 16;
-    constexpr int RB = 64 * KSTR, TB = TR ? 0 : D * 144, BUF = 2 * RB + 2 * TB + 64 * 5 * 4;
+    constexpr int RB = 64 * KSTR, TB = TR ? 0 : D * 144, BUF = 2 * RB + 2 * TB + 64 * 5 * 4 + 16;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [2][Q rows | dO rows | Q^T | dO^T | row meta] + tile list
     int* lds_tiles = reinterpret_cast<int*>(dyn_lds + 2 * BUF);      // [DKDV_MAXT + 1]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y, qz = blockIdx.z, QS = gridDim.z;
     const int kvb0 = blockIdx.x * KB;
-    const int kv = kvb0 + wave * 16 + u;
-    const bool kv_ok = kv < p.n_slots;
+    int kv[KT]; bool kv_ok[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { kv[kt] = kvb0 + (wave * KT + kt) * 16 + u; kv_ok[kt] = kv[kt] < p.n_slots; }
     const int64_t nR = (int64_t)p.T * p.group;
 
     // ---- this block's list of relevant query tiles (qi = qz, qz+QS, ...), compacted by wave 0
@@ -267,31 +279,34 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
         }
         if (lane == 0) lds_tiles[DKDV_MAXT] = count;
     }
-    bf16x8_t kf[D / 32], vf[D / 32];
-    {
-        const bf16_t* krow = p.K + (int64_t)(kv_ok ? kv : 0) * p.k_ld + (int64_t)kvh * p.d_real;
-        const bf16_t* vrow = p.V + (int64_t)(kv_ok ? kv : 0) * p.v_ld + (int64_t)kvh * p.d_real;
+    bf16x8_t kf[KT][D / 32], vf[KT][D / 32];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const bf16_t* krow = p.K + (int64_t)(kv_ok[kt] ? kv[kt] : 0) * p.k_ld + (int64_t)kvh * p.d_real;
+        const bf16_t* vrow = p.V + (int64_t)(kv_ok[kt] ? kv[kt] : 0) * p.v_ld + (int64_t)kvh * p.d_real;
 #pragma unroll
         for (int ks = 0; ks < D / 32; ++ks) {
-            kf[ks] = load_row_frag(krow, ks * 32 + g * 8, p.d_real, kv_ok);
-            vf[ks] = load_row_frag(vrow, ks * 32 + g * 8, p.d_real, kv_ok);
+            kf[kt][ks] = load_row_frag(krow, ks * 32 + g * 8, p.d_real, kv_ok[kt]);
+            vf[kt][ks] = load_row_frag(vrow, ks * 32 + g * 8, p.d_real, kv_ok[kt]);
         }
     }
-    f32x4_t dk[D / 16], dv[D / 16];
+    f32x4_t dk[KT][D / 16], dv[KT][D / 16];
 #pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) { dk[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
     const int n_my = lds_tiles[DKDV_MAXT];
 
     // PF register sets: the global loads of PF query tiles are in flight while one is computed.  The block is alone on its CU (146 KB
     // of LDS), so with one set each iteration is an exposed L2/HBM round trip (measured: 2.7 ms per call, 7B config 3, NW = 4).
-    constexpr int PF = TR ? 3 : 1;      // 3 tiles in flight (2 or 4 make hipcc spill heavily at the 256-VGPR cap)
+    constexpr int PF = TR ? (KT == 2 ? 1 : 3) : 1;      // tiles in flight (8 waves: 2 or 4 make hipcc spill heavily at the 256-VGPR cap)
     struct QTileRegs { TReg<D, NT> rq, rdo, rqt, rdot; RowMeta rm; };
     QTileRegs rg[PF];
     auto load_tile = [&](QTileRegs& r, int qi) {
         const int64_t Rq0 = (int64_t)qi * 64;
-        prows_load<D, NT>(r.rq, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real);
-        prows_load<D, NT>(r.rdo, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real);
+        prows_load<D, NT>(r.rq, p.Q, p.q_ld, kvh, p.group, Rq0, nR, p.d_real, p.group_magic);
+        prows_load<D, NT>(r.rdo, p.dO, p.do_ld, kvh, p.group, Rq0, nR, p.d_real, p.group_magic);
         if (!TR) {
             T_load<D, NT>(r.rqt, p.QT, p.qt_ld, kvh, Rq0, nR, p.d_real);
             T_load<D, NT>(r.rdot, p.dOT, p.dot_ld, kvh, Rq0, nR, p.d_real);
@@ -300,7 +315,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             const int64_t R = Rq0 + threadIdx.x;
             r.rm = RowMeta{INFINITY, 0.f, 0, 1, 0};
             if (R < nR) {
-                const int t = (int)(R / p.group), hq = (int)(R - (int64_t)t * p.group);
+                int t, hq;
+                att_split_row(p, R, t, hq);
                 const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + t;
                 const float l0 = p.lse[si];
                 r.rm.lse = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
@@ -321,6 +337,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             int* mi = reinterpret_cast<int*>(mf + 128);
             mf[threadIdx.x] = r.rm.lse; mf[64 + threadIdx.x] = r.rm.dlt;
             mi[threadIdx.x] = r.rm.pre; mi[64 + threadIdx.x] = r.rm.lo; mi[128 + threadIdx.x] = r.rm.hi;
+            int mp = r.rm.lse == INFINITY ? 0x7fffffff : r.rm.pre;      // rows without keys (padding) carry p = 0 through lse = +inf
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mp = min(mp, __shfl_xor(mp, o, 64));
+            if (threadIdx.x == 0) mi[192] = mp;                          // min prefix length of the tile: keys below it are visible to every row
         }
     };
 #pragma unroll
@@ -350,32 +370,82 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
         const int* lds_lo = lds_pre + 64;
         const int* lds_hi = lds_pre + 128;
 
-        f32x4_t s[4], dp[4];
+        f32x4_t s[KT][4], dp[KT][4];
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) { s[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) { s[kt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < D / 32; ++ks) {
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(lds_q + (qt * 16 + u) * KSTR + (ks * 4 + g) * 16);
                 const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(lds_do + (qt * 16 + u) * KSTR + (ks * 4 + g) * 16);
-                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], s[qt], 0, 0, 0);
-                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp[qt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt][qt], 0, 0, 0);
+                    dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt][qt], 0, 0, 0);
+                }
             }
         }
-        // lane holds S[q = qt*16 + g*4 + r][kv = u-th key of this wave]
-        f32x4_t pr[4], ds[4];
+        // lane holds S[q = qt*16 + g*4 + r][kv = u-th key of this wave].  Row statistics come as 4-wide LDS reads issued unconditionally (no
+        // short-circuit guards around them); a tile whose rows all see every key of this block (keys below the tile's smallest prefix
+        // length: the common completion-rows x prompt-keys case) skips the interval tests.
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        bf16x8_t pf0[KT], pf1[KT], df0[KT], df1[KT];
+        const bool full = (kvb0 + KB <= lds_pre[192]) && (kvb0 + KB <= p.n_slots);      // block-uniform
+        if (full) {
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
+            for (int h = 0; h < 2; ++h) {                    // query halves: fragment 0 = query sub-tiles 0, 1; fragment 1 = 2, 3
+                f32x4_t l4[2], d4[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qt * 16 + g * 4 + r;
-                const bool ok = kv_ok && att_visible(kv, lds_pre[ql], lds_lo[ql], lds_hi[ql]);
-                const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][r], p.scale_log2, -lds_lse[ql])) : 0.f;
-                pr[qt][r] = pv; ds[qt][r] = pv * (dp[qt][r] - lds_dlt[ql]);
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    l4[q2] = *reinterpret_cast<const f32x4_t*>(lds_lse + (2 * h + q2) * 16 + g * 4);
+                    d4[q2] = *reinterpret_cast<const f32x4_t*>(lds_dlt + (2 * h + q2) * 16 + g * 4);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    f32x4_t pr[2], ds[2];
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][2 * h + q2][r], p.scale_log2, -l4[q2][r]));
+                            pr[q2][r] = pv; ds[q2][r] = pv * (dp[kt][2 * h + q2][r] - d4[q2][r]);
+                        }
+                    if (h == 0) { pf0[kt] = pack_frag(pr[0], pr[1]); df0[kt] = pack_frag(ds[0], ds[1]); }
+                    else { pf1[kt] = pack_frag(pr[0], pr[1]); df1[kt] = pack_frag(ds[0], ds[1]); }
+                }
             }
-        const bf16x8_t pf0 = pack_frag(pr[0], pr[1]), pf1 = pack_frag(pr[2], pr[3]);
-        const bf16x8_t df0 = pack_frag(ds[0], ds[1]), df1 = pack_frag(ds[2], ds[3]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4_t l4[2], d4[2];
+                i32x4_t p4[2], lo4[2], hi4[2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int o = (2 * h + q2) * 16 + g * 4;
+                    l4[q2] = *reinterpret_cast<const f32x4_t*>(lds_lse + o); d4[q2] = *reinterpret_cast<const f32x4_t*>(lds_dlt + o);
+                    p4[q2] = *reinterpret_cast<const i32x4_t*>(lds_pre + o); lo4[q2] = *reinterpret_cast<const i32x4_t*>(lds_lo + o);
+                    hi4[q2] = *reinterpret_cast<const i32x4_t*>(lds_hi + o);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    f32x4_t pr[2], ds[2];
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool ok = kv_ok[kt] & att_visible_nb(kv[kt], p4[q2][r], lo4[q2][r], hi4[q2][r]);
+                            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][2 * h + q2][r], p.scale_log2, -l4[q2][r]));
+                            const float pv = ok ? e : 0.f;
+                            pr[q2][r] = pv; ds[q2][r] = pv * (dp[kt][2 * h + q2][r] - d4[q2][r]);
+                        }
+                    if (h == 0) { pf0[kt] = pack_frag(pr[0], pr[1]); df0[kt] = pack_frag(ds[0], ds[1]); }
+                    else { pf1[kt] = pack_frag(pr[0], pr[1]); df1[kt] = pack_frag(ds[0], ds[1]); }
+                }
+            }
+        }
         if (TR) {
             // lane (u, g) of a transposed fragment: rows qb + g*4 + (u >> 2), 8 bytes at feature dt*16 + (u & 3)*4; it receives Q[qb + g*4 + r][dt*16 + u]
             const char* tq = lds_q + (g * 4 + (u >> 2)) * KSTR + (u & 3) * 8;
@@ -384,15 +454,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             for (int dt = 0; dt < D / 16; ++dt) {
                 const bf16x8_t q0 = make_frag(lds_read_tr16(tq + dt * 32), lds_read_tr16(tq + 16 * KSTR + dt * 32));
                 const bf16x8_t o0 = make_frag(lds_read_tr16(to + dt * 32), lds_read_tr16(to + 16 * KSTR + dt * 32));
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0, dk[dt], 0, 0, 0);
+                _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0[kt], dv[kt][dt], 0, 0, 0);
+                _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0[kt], dk[kt][dt], 0, 0, 0);
             }
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) {
                 const bf16x8_t q1 = make_frag(lds_read_tr16(tq + 32 * KSTR + dt * 32), lds_read_tr16(tq + 48 * KSTR + dt * 32));
                 const bf16x8_t o1 = make_frag(lds_read_tr16(to + 32 * KSTR + dt * 32), lds_read_tr16(to + 48 * KSTR + dt * 32));
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
+                _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1[kt], dv[kt][dt], 0, 0, 0);
+                _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1[kt], dk[kt][dt], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -401,8 +471,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             const char* bo = lds_dot + (dt * 16 + u) * 144 + g * 8;
             const bf16x8_t q0 = make_frag(*reinterpret_cast<const u32x2_t*>(bq), *reinterpret_cast<const u32x2_t*>(bq + 32));
             const bf16x8_t o0 = make_frag(*reinterpret_cast<const u32x2_t*>(bo), *reinterpret_cast<const u32x2_t*>(bo + 32));
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0, dk[dt], 0, 0, 0);
+            _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, pf0[kt], dv[kt][dt], 0, 0, 0);
+            _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, df0[kt], dk[kt][dt], 0, 0, 0);
         }
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) {
@@ -410,8 +480,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             const char* bo = lds_dot + (dt * 16 + u) * 144 + g * 8;
             const bf16x8_t q1 = make_frag(*reinterpret_cast<const u32x2_t*>(bq + 64), *reinterpret_cast<const u32x2_t*>(bq + 96));
             const bf16x8_t o1 = make_frag(*reinterpret_cast<const u32x2_t*>(bo + 64), *reinterpret_cast<const u32x2_t*>(bo + 96));
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1, dk[dt], 0, 0, 0);
+            _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, pf1[kt], dv[kt][dt], 0, 0, 0);
+            _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, df1[kt], dk[kt][dt], 0, 0, 0);
         }
         }
         if (it + 1 < n_my) {
@@ -422,26 +492,28 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
     }
     }
     // lane holds dK^T/dV^T[d = dt*16 + g*4 + r][kv]
-    if (kv_ok) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+    if (kv_ok[kt]) {
         if (part_k) {   // split over query tiles: fp32 partials, summed / scaled / rounded by attn_bwd_reduce_kernel
             const int64_t kvd = (int64_t)p.n_kv * p.d_real;
-            float* pk = part_k + ((int64_t)qz * p.n_slots + kv) * kvd + (int64_t)kvh * p.d_real;
-            float* pv = part_v + ((int64_t)qz * p.n_slots + kv) * kvd + (int64_t)kvh * p.d_real;
+            float* pk = part_k + ((int64_t)qz * p.n_slots + kv[kt]) * kvd + (int64_t)kvh * p.d_real;
+            float* pv = part_v + ((int64_t)qz * p.n_slots + kv[kt]) * kvd + (int64_t)kvh * p.d_real;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) {
                 const int d = dt * 16 + g * 4;
-                if (d < p.d_real) { *reinterpret_cast<f32x4_t*>(pk + d) = dk[dt]; *reinterpret_cast<f32x4_t*>(pv + d) = dv[dt]; }
+                if (d < p.d_real) { *reinterpret_cast<f32x4_t*>(pk + d) = dk[kt][dt]; *reinterpret_cast<f32x4_t*>(pv + d) = dv[kt][dt]; }
             }
         } else {
             const float scale = p.scale_log2 * 0.6931471805599453f;
-            bf16_t* kr = p.dK + (int64_t)kv * p.dk_ld + (int64_t)kvh * p.d_real;
-            bf16_t* vr = p.dV + (int64_t)kv * p.dv_ld + (int64_t)kvh * p.d_real;
+            bf16_t* kr = p.dK + (int64_t)kv[kt] * p.dk_ld + (int64_t)kvh * p.d_real;
+            bf16_t* vr = p.dV + (int64_t)kv[kt] * p.dv_ld + (int64_t)kvh * p.d_real;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) {
                 const int d = dt * 16 + g * 4;
                 if (d < p.d_real) {
-                    u32x2_t wk = {pack2bf(dk[dt][0] * scale, dk[dt][1] * scale), pack2bf(dk[dt][2] * scale, dk[dt][3] * scale)};
-                    u32x2_t wv = {pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
+                    u32x2_t wk = {pack2bf(dk[kt][dt][0] * scale, dk[kt][dt][1] * scale), pack2bf(dk[kt][dt][2] * scale, dk[kt][dt][3] * scale)};
+                    u32x2_t wv = {pack2bf(dv[kt][dt][0], dv[kt][dt][1]), pack2bf(dv[kt][dt][2], dv[kt][dt][3])};
                     *reinterpret_cast<u32x2_t*>(kr + d) = wk;
                     *reinterpret_cast<u32x2_t*>(vr + d) = wv;
                 }
@@ -489,12 +561,17 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     constexpr int KSTR = 2 * D + 16;
     constexpr int NW = (D == 64 || D == 128) ? 8 : 4;
     constexpr int KB = NW * 16;
+    // TR1_DKDV_KT=2 selects the 4-wave x 32-key form (half the LDS reads per MFMA, but one wave per SIMD and - at the 512-register
+    // limit - a single query tile in flight: 1.03 ms against 0.87 ms for the 8-wave form at config 3, so it stays an experiment)
+    static int kt2 = -1;
+    if (kt2 < 0) { const char* e = getenv("TR1_DKDV_KT"); kt2 = (e ? atoi(e) : 1) == 2 && NW == 8; }
     const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR) + 64;
-    const size_t dyn_kv = 2 * (2 * 64 * KSTR + (NW == 8 ? 0 : 2 * D * 144) + 64 * 5 * 4) + (DKDV_MAXT + 1) * 4;
+    const size_t dyn_kv = 2 * (2 * 64 * KSTR + (NW == 8 ? 0 : 2 * D * 144) + 64 * 5 * 4 + 16) + (DKDV_MAXT + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
+        if (NW == 8) hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
@@ -506,7 +583,8 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
         pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
     }
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)((p.n_slots + KB - 1) / KB), p.n_kv, QS), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
+    if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)((p.n_slots + KB - 1) / KB), p.n_kv, QS), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
+    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)((p.n_slots + KB - 1) / KB), p.n_kv, QS), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
     if (QS > 1) {
         const float scale = p.scale_log2 * 0.6931471805599453f;
         hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(tr1_grid_1d(p.n_slots * kvd / 4, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
@@ -535,10 +613,11 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     p.dO = (const bf16_t*)dO; p.do_ld = do_ld; p.dQ = (bf16_t*)dQ; p.dq_ld = dq_ld; p.dK = (bf16_t*)dK; p.dk_ld = dk_ld;
     p.dV = (bf16_t*)dV; p.dv_ld = dv_ld; p.lse = (float*)lse; p.delta = (float*)delta; p.pre = (const int*)pre; p.lo = (const int*)lo;
     p.hi = (const int*)hi; p.qmeta = (const int*)qmeta_ws;
-    p.T = (int)T; p.group = (int)(n_heads / n_kv); p.n_kv = (int)n_kv; p.n_slots = (int)n_slots; p.d_real = (int)head_dim; p.nsplit = 1;
+    p.T = (int)T; const bool magic_ok = att_set_group(p, T, (int)(n_heads / n_kv)); p.n_kv = (int)n_kv; p.n_slots = (int)n_slots; p.d_real = (int)head_dim; p.nsplit = 1;
     p.scale_log2 = scale * 1.4426950408889634f;
     const int d_pad = (int)((head_dim + 31) / 32 * 32);
     TR1_CHECK_ARG(d_pad == 32 || d_pad == 64 || d_pad == 96 || d_pad == 128, "attention bwd: padded head dim must be 32/64/96/128");
+    TR1_CHECK_ARG(magic_ok, "attention bwd: T * group^2 must stay below 2^32");
     TR1_CHECK_ARG(head_dim % 8 == 0 && q_ld % 8 == 0 && k_ld % 8 == 0 && v_ld % 8 == 0 && do_ld % 8 == 0 && o_ld % 8 == 0,
                   "attention bwd: dims must be multiples of 8");
     // Q^T / dO^T are only read by the 4-wave dK/dV form (head dims padded to 32 / 96); the 8-wave form transposes in its LDS reads
@@ -548,7 +627,7 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     TR1_CHECK_ARG(dk_ld % 4 == 0 && dv_ld % 4 == 0, "attention bwd: dk/dv leading dims must be multiples of 4");
     if (T == 0 || n_slots == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T * n_heads + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dO, do_ld,
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T * n_heads + 15) / 16)), dim3(256), 0, s, (const bf16_t*)dO, do_ld,
                        (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim);
     const int n_qtiles = (int)((T * p.group + 63) / 64);
     hipLaunchKernelGGL(attn_qmeta_kernel, dim3(n_qtiles), dim3(64), 0, s, p.pre, p.lo, p.hi, (int*)qmeta_ws, (int)T, p.group);

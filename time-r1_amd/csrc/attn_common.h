@@ -39,6 +39,7 @@ struct AttnParams {
     const int* qmeta;                  // [n_qtiles64, 3] (max pre, min lo, max hi) per 64 packed rows (backward only)
     float* Opart; float* mpart; float* lpart;       // split-KV workspaces
     int T, group, n_kv, n_slots, d_real, nsplit;
+    unsigned group_magic;              // ceil(2^32 / group): R / group == umulhi(R, group_magic) for R < 2^32 / group (att_set_group)
     int n_batch; int64_t kv_batch_slots;   // forward only: batch b uses Q/O/mask rows [b*T,(b+1)*T) and cache slots [b*kv_batch_slots, ...)
     float scale_log2;                  // softmax scale * log2(e)
 };
@@ -186,14 +187,15 @@ TR1_DEV void rows_load(TReg<D, NT>& r, const bf16_t* src, int64_t ld, int64_t co
 }
 // GQA-packed query rows R = R0 + row -> token R/group, head kvh*group + R%group
 template <int D, int NT = 256>
-TR1_DEV void prows_load(TReg<D, NT>& r, const bf16_t* src, int64_t ld, int kvh, int group, int64_t R0, int64_t nR, int d_real) {
+TR1_DEV void prows_load(TReg<D, NT>& r, const bf16_t* src, int64_t ld, int kvh, int group, int64_t R0, int64_t nR, int d_real, unsigned magic) {
     constexpr int CH = D / 8;
 #pragma unroll
     for (int j = 0; j < 8 * D / NT; ++j) {
         const int idx = threadIdx.x + j * NT;
         const int row = idx / CH, c = idx - row * CH;
         int64_t R = R0 + row; if (R > nR - 1) R = nR - 1;
-        const int64_t t = R / group; const int hq = (int)(R - t * group);
+        const unsigned ru = (unsigned)R, tu = group == 1 ? ru : __umulhi(ru, magic);
+        const int64_t t = tu; const int hq = (int)(ru - tu * (unsigned)group);
         const int cc = (c * 8 < d_real) ? c * 8 : 0;
         r.v[j] = *reinterpret_cast<const u32x4_t*>(src + t * ld + (int64_t)(kvh * group + hq) * d_real + cc);
     }
@@ -244,6 +246,20 @@ TR1_DEV void T_store(const TReg<D, NT>& r, char* lds, int64_t col0, int64_t nval
 }
 
 TR1_DEV bool att_visible(int kv, int pre, int lo, int hi) { return (kv < pre) || (kv >= lo && kv <= hi); }
+// branch-free form (bitwise, every operand already in a register): keeps hipcc from guarding operand loads behind short-circuit branches
+TR1_DEV bool att_visible_nb(int kv, int pre, int lo, int hi) { return (kv < pre) | ((kv >= lo) & (kv <= hi)); }
+
+// GQA-packed row R -> (token, query head inside the group) without the 64-bit software division of `R / group`
+TR1_DEV void att_split_row(const AttnParams& p, int64_t R, int& t, int& hq) {
+    const unsigned r = (unsigned)R;
+    const unsigned q = p.group == 1 ? r : __umulhi(r, p.group_magic);
+    t = (int)q; hq = (int)(r - q * (unsigned)p.group);
+}
+static inline bool att_set_group(AttnParams& p, int64_t T, int group) {
+    p.group = group;
+    p.group_magic = group > 1 ? (unsigned)((0x100000000ull + (unsigned)group - 1) / (unsigned)group) : 0u;
+    return (uint64_t)T * (uint64_t)group * (uint64_t)group < 0x100000000ull;     // exactness range of the magic multiply
+}
 
 // Which 64-key tiles can a set of rows with (max_pre, min_lo, max_hi) see?  [0, pre_tiles) U [start2, end2]
 struct TileRange { int pre_tiles, start2, n_rel; };

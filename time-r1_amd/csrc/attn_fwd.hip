@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         const int64_t R = R0 + cb * 16 + u;
         valid[cb] = R < nR;
         const int64_t Rc = valid[cb] ? R : nR - 1;
-        tq[cb] = (int)(Rc / p.group); hq[cb] = (int)(Rc - (int64_t)tq[cb] * p.group);
+        att_split_row(p, Rc, tq[cb], hq[cb]);
         pre[cb] = valid[cb] ? p.pre[tq[cb]] : 0;
         lo[cb] = valid[cb] ? p.lo[tq[cb]] : 1;
         hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
     float L = 0.f;
     for (int s = 0; s < p.nsplit; ++s) L += exp2f(sm_m[rl][s] - Ms) * sm_l[rl][s];
     const float inv = L > 0.f ? 1.f / L : 0.f;
-    const int64_t t = R / p.group; const int hq = (int)(R - t * p.group);
-    bf16_t* orow = p.O + t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real;
+    int t, hq;
+    att_split_row(p, R, t, hq);
+    bf16_t* orow = p.O + (int64_t)t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real;
 #pragma unroll
     for (int j = 0; j < (D + 127) / 128; ++j) {
         const int d = (c + j * 32) * 4;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const bf16_t* __res
         const int64_t R = R0 + rr; const int dd = d0 + cc;
         u32x4_t v = {0, 0, 0, 0};
         if (R < nR && dd < d) {
-            const int64_t t = R / group; const int hq = (int)(R - t * group);
+            const int64_t t = (unsigned)R / (unsigned)group; const int hq = (int)(R - t * group);      // 32-bit division (R < 2^31)
             const bf16_t* src = in + t * ld_in + (int64_t)(kvh * group + hq) * d + dd;
             if (vec_in && dd + 8 <= d) v = *reinterpret_cast<const u32x4_t*>(src);
             else {
@@ -374,10 +375,11 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.VT = (const bf16_t*)VT; p.vt_ld = vt_ld;
     p.O = (bf16_t*)O; p.o_ld = o_ld; p.lse = (float*)lse; p.pre = (const int*)pre; p.lo = (const int*)lo; p.hi = (const int*)hi;
     TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention: n_heads must be a multiple of n_kv");
-    p.T = (int)T; p.group = (int)(n_heads / n_kv); p.n_kv = (int)n_kv; p.n_slots = (int)n_slots; p.d_real = (int)head_dim; p.nsplit = (int)nsplit;
+    p.T = (int)T; const bool magic_ok = att_set_group(p, T * (n_batch > 0 ? n_batch : 1), (int)(n_heads / n_kv)); p.n_kv = (int)n_kv; p.n_slots = (int)n_slots; p.d_real = (int)head_dim; p.nsplit = (int)nsplit;
     p.scale_log2 = scale * 1.4426950408889634f;
     const int d_pad = (int)((head_dim + 31) / 32 * 32);
     if (int e = attn_check(p, d_pad)) return e;
+    TR1_CHECK_ARG(magic_ok, "attention: T * group^2 must stay below 2^32");
     TR1_CHECK_ARG(vt_ld % 8 == 0 && vt_ld >= n_slots, "attention: vt_ld must be a multiple of 8 and >= n_slots");
     if (T == 0) return 0;
     const int64_t nR = T * p.group;

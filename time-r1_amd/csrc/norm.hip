@@ -84,14 +84,12 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                          float* __restrict__ dw, int rows, int cols) {
-    extern __shared__ __attribute__((aligned(16))) float lds_dw[];  // [cols]
+                                                          float* __restrict__ dw_part, int rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dw[];  // [4 waves][cols]
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int nch = cols >> 3;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) lds_dw[c] = 0.f;
-    __syncthreads();
     float dwa[NORM_MAXC][8];
 #pragma unroll
     for (int i = 0; i < NORM_MAXC; ++i)
@@ -140,17 +138,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
             }
         }
     }
-    if (dw) {
+    if (dw_part) {      // per-block partial row (fixed summation order: no atomics, the weight gradient is reproducible)
+        float* mine = lds_dw + (threadIdx.x >> 6) * cols;
 #pragma unroll
         for (int i = 0; i < NORM_MAXC; ++i) {
             const int c = lane + i * 64;
             if (c < nch) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(&lds_dw[c * 8 + j], dwa[i][j]);
+                *reinterpret_cast<f32x4_t*>(mine + c * 8) = (f32x4_t){dwa[i][0], dwa[i][1], dwa[i][2], dwa[i][3]};
+                *reinterpret_cast<f32x4_t*>(mine + c * 8 + 4) = (f32x4_t){dwa[i][4], dwa[i][5], dwa[i][6], dwa[i][7]};
             }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < cols; c += blockDim.x) atomicAdd(&dw[c], lds_dw[c]);
+        for (int c = threadIdx.x; c < cols; c += blockDim.x)
+            dw_part[(size_t)blockIdx.x * cols + c] = (lds_dw[c] + lds_dw[cols + c]) + (lds_dw[2 * cols + c] + lds_dw[3 * cols + c]);
+    }
+}
+
+// dw[c] += sum_b part[b][c], b in ascending order inside each of 16 row groups, groups combined in a fixed order.  64 columns per block.
+__global__ __launch_bounds__(1024) void norm_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int cols) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int per = (nblk + 15) / 16, b0 = rg * per, b1 = min(nblk, b0 + per);
+    float s = 0.f;
+    if (c < cols) {
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += part[(size_t)b * cols + c];
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        dw[c] += t;
     }
 }
 
@@ -300,14 +321,23 @@ extern "C" int tr1_rmsnorm_fwd(const void* x, const void* residual, const void* 
     TR1_LAUNCH_CHECK();
 }
 
+static int norm_bwd_blocks(int64_t rows) { int g = (int)((rows + 3) / 4); return g > 512 ? 512 : g; }
+
+extern "C" int64_t tr1_rmsnorm_bwd_workspace_floats(int64_t rows, int64_t cols) { return (int64_t)norm_bwd_blocks(rows) * cols; }
+
 extern "C" int tr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* rstd, const void* dres, void* dx,
-                               void* dw_f32, int64_t rows, int64_t cols, void* stream) {
+                               void* dw_f32, void* ws_f32, int64_t ws_floats, int64_t rows, int64_t cols, void* stream) {
     TR1_CHECK_ARG(cols % 8 == 0 && cols <= 64 * 8 * NORM_MAXC, "rmsnorm_bwd: cols must be a multiple of 8 and <= 4096");
+    TR1_CHECK_ARG(dy && x && w && rstd && dx, "rmsnorm_bwd: dy, x, w, rstd and dx are required");
     if (rows == 0) return 0;
-    int g = (int)((rows + 3) / 4); if (g > 512) g = 512;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(g), dim3(256), cols * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)w, (const float*)rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)dw_f32,
+    const int g = norm_bwd_blocks(rows);
+    TR1_CHECK_ARG(!dw_f32 || (ws_f32 && ws_floats >= (int64_t)g * cols), "rmsnorm_bwd: workspace too small (tr1_rmsnorm_bwd_workspace_floats)");
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(g), dim3(256), dw_f32 ? 4 * cols * sizeof(float) : 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)w, (const float*)rstd, (const bf16_t*)dres, (bf16_t*)dx, dw_f32 ? (float*)ws_f32 : nullptr,
                        (int)rows, (int)cols);
+    if (dw_f32)
+        hipLaunchKernelGGL(norm_dw_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)ws_f32,
+                           (float*)dw_f32, g, (int)cols);
     TR1_LAUNCH_CHECK();
 }
 

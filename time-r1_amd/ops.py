@@ -194,7 +194,11 @@ class HipOps:
         dx = self.empty(rows, cols)
         if dw is not None:
             assert dw.dtype == F32 and dw.numel() == cols
-        self.L.call("tr1_rmsnorm_bwd", _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), rows, cols, self._s())
+        ws, nws = None, 0
+        if dw is not None:
+            nws = int(self.L.raw("tr1_rmsnorm_bwd_workspace_floats")(rows, cols))
+            ws = self._workspace("rmsnorm_bwd_dw", nws, F32)
+        self.L.call("tr1_rmsnorm_bwd", _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), _p(ws), nws, rows, cols, self._s())
         return dx
 
     def layernorm_fwd(self, x, w, b, eps, need_stats=True):

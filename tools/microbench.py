@@ -198,6 +198,13 @@ def small():
     us = timeit(lambda: ops.rmsnorm_fwd(big, ww, 1e-6), reps=20)
     print("rmsnorm_fwd [29376,3584]  %6.1f us  %6.1f GB/s" % (us, 2 * 29376 * 3584 * 2 / us / 1e3))
     t = rnd(5074, 18944)
+    xb, dyb = rnd(5074, 3584), rnd(5074, 3584)
+    _, rs, _ = ops.rmsnorm_fwd(xb, ww, 1e-6)
+    dwb = torch.zeros(3584, device="cuda")
+    us = timeit(lambda: ops.rmsnorm_bwd(dyb, xb, ww, rs, dres=dyb, dw=dwb), reps=20)
+    print("rmsnorm_bwd [5074,3584] (+dres, dw) %6.1f us  %6.0f GB/s (4 row passes)" % (us, 4 * 5074 * 3584 * 2 / us / 1e3))
+    us = timeit(lambda: ops.rmsnorm_bwd(dyb, xb, ww, rs, dres=dyb, dw=None), reps=20)
+    print("rmsnorm_bwd [5074,3584] (+dres, no dw) %6.1f us" % us)
     us = timeit(lambda: ops.transpose(t), reps=10)
     print("transpose [5074,18944]    %6.1f us  %6.1f GB/s" % (us, 2 * 5074 * 18944 * 2 / us / 1e3))
 
