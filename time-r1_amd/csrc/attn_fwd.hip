@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             bool full = kv0 + ATT_KV <= p.n_slots;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
-                full = full && (!valid[cb] || (kv0 + ATT_KV - 1 < pre[cb]) || (kv0 >= lo[cb] && kv0 + ATT_KV - 1 <= hi[cb]));
+                full = full & (!valid[cb] | (kv0 + ATT_KV - 1 < pre[cb]) | ((kv0 >= lo[cb]) & (kv0 + ATT_KV - 1 <= hi[cb])));   // bitwise: no exec-mask chains
             const bool wave_full = __all(full);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int kv = kv0 + kt * 16 + g * 4 + r;
-                            const bool ok = kv < p.n_slots && att_visible(kv, pre[cb], lo[cb], hi[cb]);
+                            const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre[cb], lo[cb], hi[cb]);   // bitwise: no control flow per element
                             const float v = ok ? s[kt][cb][r] : NEG_INF;
                             s[kt][cb][r] = v; mx = fmaxf(mx, v);
                         }
