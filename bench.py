@@ -52,6 +52,7 @@ class Workload:
         if hasattr(self.params, "init_random_device"):
             self.params.init_random_device(seed=0)
         self.eng = Engine(self.cfg, ops, self.params)
+        self.eng.cache_wt = bool(args.wt_cache)
         self.ref = self.params.train.clone_weights_only() if args.beta != 0.0 else None
         self.core = GRPOCore(self.eng, self.ref, args.G, args.C, beta=args.beta, use_grpo=not args.clip_loss, temperature=1.0, top_k=50,
                              seed=1234 + rank, rope_index_mode="hf4")
@@ -262,6 +263,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only)")
+    ap.add_argument("--wt-cache", action="store_true", help="keep W^T of the dgrad GEMMs across the accumulation window (Engine.cache_wt; measured SLOWER: "
+                    "backward 186 vs 174 ms - the freshly written W^T is served from the Infinity Cache, the cached copy from HBM beside the wgrad stream)")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: all-reduce the gradient arena after backward instead of during it")
     args = ap.parse_args()
 
@@ -313,6 +316,8 @@ def main():
             "rollout_tokens_per_sec": (gen_tokens / world / args.steps) / (phases.get("rollout", 1e-9) / 1000.0) * world,
             "generated_tokens_per_sec_end_to_end": gen_tokens / dt,
             "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
+            "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 1e9, 1), "reserved_peak": round(torch.cuda.max_memory_reserved() / 1e9, 1),
+                       "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0)), "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))},
             "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step" % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta,
                                                                                     "ppo-clip" if args.clip_loss else "grpo", args.ga),

@@ -27,6 +27,7 @@ class AdamWFlat:
         self._sumsq.zero_()
         self.ops.sumsq_accum(a.grad, self._sumsq)
         self.step_count += 1
+        a.version = getattr(a, "version", 0) + 1
         self.ops.adamw_step(a.master, a.m, a.v, a.grad, a.w16, self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
                             self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=True)
         return self._sumsq.sqrt() * mult

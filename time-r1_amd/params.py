@@ -67,6 +67,7 @@ class Arena:
             self.offsets[name] = (off, shape)
             off += (int(math.prod(shape)) + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
+        self.version = 0                 # bumped whenever the weights change (optimizer step, loaders): invalidates derived copies (Engine W^T cache)
         self.w16 = ops.zeros(off, dtype=ops.act_dtype)
         self.grad = self.master = self.m = self.v = None
         if with_grad is None:
@@ -180,6 +181,7 @@ class ModelParams:
     # ---- HF checkpoint <-> arena ----------------------------------------------------------------------------------
     def load_hf_state_dict(self, sd):
         """Accepts transformers 4.51 (`model.layers.*`, `visual.*`) and 5.x (`model.language_model.*`, `model.visual.*`) key layouts."""
+        self.train.version = getattr(self.train, "version", 0) + 1
         cfg = self.cfg
 
         def get(*cands):
