@@ -55,8 +55,11 @@ def test_two_rank_step_equals_single_process_average(wire):
     from test_trainer_host_logic import make_trainer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + os.getpid() % 200
-    procs = [ctx.Process(target=_worker, args=(r, 2, port + (7 if wire == "bf16" else 0), q, wire)) for r in range(2)]
+    import socket
+    with socket.socket() as sk:          # a port the kernel reports free right now (back-to-back runs used to collide on a derived port)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
