@@ -760,6 +760,156 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-streamed form of the fused rmsnorm + gate/up + SwiGLU decode GEMM (M <= 16 rows).
+// The register-fragment stream of norm_gemm_skinny_kernel reads 64-byte pieces of 16 weight rows per wave instruction and tops out at
+// ~4.8 TB/s (a pure load kernel with that shape: 5.5 TB/s; with row-contiguous requests: 6.1 TB/s, tools/probe_stream.hip).  Here the
+// weights go HBM -> LDS with global_load_lds in full 128-byte row runs (8 rows per wave instruction), each wave keeps its OWN ring of
+// stages in LDS and reads the MFMA fragments back with ds_read_b128, so nothing but the issuing wave's counted vmcnt orders a stage
+// (no barrier in the stream).  Consequences used below:
+//   * a block is PERSISTENT over a contiguous range of column-group pairs (16 gate rows + 16 up rows), so the activation fragments
+//     x' = bf16(x * lnw) of the wave's k-slice (K/8 columns) are built ONCE and stay in registers, and sum x^2 is reduced once per block;
+//   * after the last stage of a pair the eight waves drop their partial tiles in LDS, meet at ONE raw barrier (the DMA of the next pair
+//     stays in flight) and 256 threads finish one output each, with the rounding points of norm_gemm_skinny_kernel's GLU epilogue.  The
+//     epilogue's global stores share vmcnt with the DMA; that is safe for the counted waits: loads retire in order among themselves, so
+//     "at most 4(R-1) operations outstanding" still implies that the stage being consumed has landed - outstanding stores can only make
+//     a wait longer, never shorter.
+// LDS image of a stage: [gate 16 rows | up 16 rows] x 128 bytes (64 k); row r keeps its logical 16-byte chunk c at position c ^ keyA(r)
+// (applied on the SOURCE address of the DMA): the 16-row fragment reads are conflict-free.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NST, int R>
+__global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
+                                                           bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                                                           int64_t ldc, float eps, int64_t up_off) {
+    constexpr int STAGE = 4096;                                            // bytes per stage: gate 2 KiB + up 2 KiB
+    constexpr int REDW = 2 * 16 * 17;                                      // floats of one wave's partial (gate | up)
+    // red[2][8][REDW] f32 | ssq[8][16] | [8 waves][R stages][4 KiB].  The rings come LAST: a DMA destination is passed as (slot - stage offset)
+    // because the instruction's immediate offset is added to the LDS address too, and that pointer must not fall below the LDS base.
+    extern __shared__ __attribute__((aligned(16))) char glu_lds[];
+    float* red = reinterpret_cast<float*>(glu_lds);
+    float* ssq = red + 2 * 8 * REDW;
+    char* rings = glu_lds + (2 * 8 * REDW + 8 * 16) * sizeof(float);
+    static_assert((2 * 8 * REDW + 8 * 16) * sizeof(float) >= 6 * 128 && ((2 * 8 * REDW + 8 * 16) * sizeof(float)) % 16 == 0, "ring base");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    const int64_t NP = (N + 15) / 16;
+    const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
+    const int npair = (int)(p1 - p0);
+    const int64_t kb = (int64_t)wave * (K / 8);
+    // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares
+    bf16x8_t xr[NST * 2];
+    {
+        float ss = 0.f;
+        const bf16_t* xp = X + (int64_t)(u < M ? u : M - 1) * ldx + kb + g * 8;
+        const bf16_t* lp = lnw + kb + g * 8;
+#pragma unroll
+        for (int i = 0; i < NST * 2; ++i) {
+            const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xp + i * 32), lv = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
+            xr[i] = scale_frag_sumsq(xv, lv, ss);
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (g == 0) ssq[wave * 16 + u] = ss;
+    }
+    // ---- DMA lane map: instruction j covers rows 8j .. 8j+7; lane -> row 8j + (lane >> 3), physical chunk lane & 7, logical chunk ^ keyA(row).
+    // Four per-lane source pointers (gate / up rows of the pair being ISSUED) advance by 16 rows per pair; the stage inside the pair is an
+    // immediate offset of the DMA instruction, so issuing a stage costs no vector ALU work.
+    char* ring = rings + wave * R * STAGE;
+    const int total = npair * NST;
+    const bf16_t* pg[2]; const bf16_t* pu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        pg[j] = W + (p0 * 16 + r) * ldw + kb + (((lane & 7) ^ keyA(r)) << 3);
+        pu[j] = pg[j] + up_off * ldw;
+    }
+    const int64_t pair_step = 16 * ldw;
+    int islot = 0;                                       // ring slot of the next item to issue (wave-uniform)
+#define GLU_ISSUE(ST) do {                                                                                               \
+        char* dst__ = ring + islot * STAGE - (ST) * 128;   /* the instruction offset is added to the LDS address as well */  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            __builtin_amdgcn_global_load_lds((gptr_t)pg[j], (lptr_t)(dst__ + j * 1024), 16, (ST) * 128, 0);              \
+            __builtin_amdgcn_global_load_lds((gptr_t)pu[j], (lptr_t)(dst__ + 2048 + j * 1024), 16, (ST) * 128, 0);       \
+        }                                                                                                                \
+        islot = (islot + 1 == R) ? 0 : islot + 1;                                                                        \
+    } while (0)
+#define GLU_ISSUE_ST(ST) do { switch (ST) { case 0: GLU_ISSUE(0); break; case 1: GLU_ISSUE(1); break; case 2: GLU_ISSUE(2); break; case 3: GLU_ISSUE(3); break; \
+                                           case 4: GLU_ISSUE(4); break; case 5: GLU_ISSUE(5); break; default: GLU_ISSUE(6); break; } } while (0)
+#define GLU_NEXT_PAIR() do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { pg[j] += pair_step; pu[j] += pair_step; } } while (0)
+    static_assert(NST <= 7, "stage offsets are enumerated up to 7");
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) {                    // prologue: items 0 .. R-2
+        if (i < total) {
+            if (i > 0 && i % NST == 0) GLU_NEXT_PAIR();
+            GLU_ISSUE_ST(i % NST);
+        }
+    }
+    TR1_BARRIER();                                       // the eight waves' sum-of-squares partials are in LDS (the prologue DMA is in flight)
+    float rstd;
+    {
+        float sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sq += ssq[w * 16 + ((threadIdx.x >> 4) & 15)];
+        rstd = rsqrtf(sq * (1.f / (float)K) + eps);
+    }
+    const int rd_off = u * 128;
+    const int kA = keyA(u);
+    int cslot = 0;                                       // ring slot of the item being consumed
+    for (int pi = 0; pi < npair; ++pi) {
+        f32x4_t ag[2], au[2];
+        ag[0] = ag[1] = au[0] = au[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int item = pi * NST + st;
+            if (item + R - 1 < total) {
+                if ((st + R - 1) % NST == 0) GLU_NEXT_PAIR();           // the issue stream enters the next pair here (compile-time position)
+                GLU_ISSUE_ST((st + R - 1) % NST);
+            }
+            const int rem = total - 1 - item;              // items issued after this one and still allowed in flight
+            if (rem >= R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (R - 1)) : "memory");
+            else if (rem == 2 && R > 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1 && R > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* sb = ring + cslot * STAGE + rd_off;
+            cslot = (cslot + 1 == R) ? 0 : cslot + 1;
+            bf16x8_t wg[2], wu[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = ((ks * 4 + g) ^ kA) << 4;
+                wg[ks] = *reinterpret_cast<const bf16x8_t*>(sb + off);
+                wu[ks] = *reinterpret_cast<const bf16x8_t*>(sb + 2048 + off);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ag[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[ks], xr[st * 2 + ks], ag[ks], 0, 0, 0);
+                au[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[ks], xr[st * 2 + ks], au[ks], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this stage's reads have returned before its slot can be refilled
+        }
+        float* rw = red + ((pi & 1) * 8 + wave) * REDW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rw[u * 17 + g * 4 + r] = ag[0][r] + ag[1][r];
+            rw[16 * 17 + u * 17 + g * 4 + r] = au[0][r] + au[1][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TR1_BARRIER();                                                  // partial tiles are visible; the DMA of the next pair stays in flight
+        if (threadIdx.x < 256) {
+            const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
+            const float* rb = red + (pi & 1) * 8 * REDW;
+            float v = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { v += rb[w * REDW + mm * 17 + nn]; v2 += rb[w * REDW + 16 * 17 + mm * 17 + nn]; }
+            v = __fmul_rn(v, rstd);
+            const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
+            const int64_t n = (p0 + pi) * 16 + nn;
+            if (mm < M && n < N) C[(int64_t)mm * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
+        }
+    }
+#undef GLU_ISSUE
+#undef GLU_ISSUE_ST
+#undef GLU_NEXT_PAIR
+}
+
 extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                                     int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream) {
     TR1_CHECK_ARG(K % BK == 0 && K >= BK, "norm_gemm_skinny: K must be a positive multiple of 64");
@@ -773,7 +923,30 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
                        dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W, (bf16_t*)out, (const bf16_t*)bias, \
                        (int)M, N, K, ldx, ldw, ldc, eps, N)
     // gate/up + SwiGLU at <= 16 rows: UNROLL 2 keeps the kernel at 128 VGPRs = 4 blocks per CU (1024 slots for 1184 blocks); measured 59.2 vs 60.9 us
-    if (glu) { if (M <= 16) NG(4, 2, 1, true); else if (M <= 32) NG(4, 2, 2, true); else NG(4, 2, 4, true); }
+    static int glu_lds = -1;                         // TR1_GLU_LDS=0 selects the register-fragment form (A/B measurements)
+    if (glu_lds < 0) { const char* e = getenv("TR1_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
+    const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
+    if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 3) && N % 16 == 0) {
+        constexpr int RING = 3;
+        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        static int n_cu = 0;
+        if (!n_cu) {
+            hipDeviceProp_t prop; int dev = 0;
+            hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<7, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<3, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        }
+        const int64_t NP = N / 16;
+        const unsigned grid = (unsigned)(NP < n_cu ? NP : n_cu);
+        if (nst == 7)
+            hipLaunchKernelGGL((norm_glu_lds_kernel<7, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
+                               (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
+        else
+            hipLaunchKernelGGL((norm_glu_lds_kernel<3, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
+                               (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
+    }
+    else if (glu) { if (M <= 16) NG(4, 2, 1, true); else if (M <= 32) NG(4, 2, 2, true); else NG(4, 2, 4, true); }
     else if (N >= 100000 && M <= 32) {      // lm_head: 4 column groups per block halve the re-reads of x (228 -> ~195 us at M = 16)
 #define NG4(UN, MGR)                                                                                                                 \
     hipLaunchKernelGGL((norm_gemm_skinny_kernel<4, UN, MGR, false, 4>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, (const bf16_t*)x,    \
