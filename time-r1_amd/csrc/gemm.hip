@@ -777,7 +777,7 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 // LDS image of a stage: [gate 16 rows | up 16 rows] x 128 bytes (64 k); row r keeps its logical 16-byte chunk c at position c ^ keyA(r)
 // (applied on the SOURCE address of the DMA): the 16-row fragment reads are conflict-free.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NST, int R>
+template <int NST, int R, int NRED = 2>
 __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                                                            int64_t ldc, float eps, int64_t up_off) {
@@ -787,9 +787,9 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
     // because the instruction's immediate offset is added to the LDS address too, and that pointer must not fall below the LDS base.
     extern __shared__ __attribute__((aligned(16))) char glu_lds[];
     float* red = reinterpret_cast<float*>(glu_lds);
-    float* ssq = red + 2 * 8 * REDW;
-    char* rings = glu_lds + (2 * 8 * REDW + 8 * 16) * sizeof(float);
-    static_assert((2 * 8 * REDW + 8 * 16) * sizeof(float) >= 6 * 128 && ((2 * 8 * REDW + 8 * 16) * sizeof(float)) % 16 == 0, "ring base");
+    float* ssq = red + NRED * 8 * REDW;
+    char* rings = glu_lds + (NRED * 8 * REDW + 8 * 16) * sizeof(float);
+    static_assert((NRED * 8 * REDW + 8 * 16) * sizeof(float) >= 6 * 128 && ((NRED * 8 * REDW + 8 * 16) * sizeof(float)) % 16 == 0, "ring base");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int64_t NP = (N + 15) / 16;
     const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this stage's reads have returned before its slot can be refilled
         }
-        float* rw = red + ((pi & 1) * 8 + wave) * REDW;
+        float* rw = red + ((NRED == 2 ? (pi & 1) : 0) * 8 + wave) * REDW;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             rw[u * 17 + g * 4 + r] = ag[0][r] + ag[1][r];
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
         TR1_BARRIER();                                                  // partial tiles are visible; the DMA of the next pair stays in flight
         if (threadIdx.x < 256) {
             const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
-            const float* rb = red + (pi & 1) * 8 * REDW;
+            const float* rb = red + (NRED == 2 ? (pi & 1) : 0) * 8 * REDW;
             float v = 0.f, v2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) { v += rb[w * REDW + mm * 17 + nn]; v2 += rb[w * REDW + 16 * 17 + mm * 17 + nn]; }
@@ -904,6 +904,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             const int64_t n = (p0 + pi) * 16 + nn;
             if (mm < M && n < N) C[(int64_t)mm * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
         }
+        if (NRED == 1) TR1_BARRIER();                                   // single reduction buffer: everybody has read it before the next pair writes
     }
 #undef GLU_ISSUE
 #undef GLU_ISSUE_ST
@@ -927,7 +928,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     if (glu_lds < 0) { const char* e = getenv("TR1_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
     const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
     if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 3) && N % 16 == 0) {
-        constexpr int RING = 3;
+        constexpr int RING = 3;          // a ring of 4 (with a single reduction buffer and a second barrier per pair) measured the same: 50.0 us
         const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
         static int n_cu = 0;
         if (!n_cu) {
