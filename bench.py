@@ -349,7 +349,7 @@ def main():
         mfma = {"kernel": "gemm_nt_kernel+gemm_nt8p_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms / nstep, "traffic": None}
         mfma["frac"] = mfma["achieved"] / PEAK_BF16_TFLOPS
-        hbm = {"kernel": "gemm_skinny_kernel+norm_gemm_skinny_kernel", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
+        hbm = {"kernel": "decode GEMM family: gemm_skinny + norm_gemm_skinny + norm_glu_lds + gemm_skinny_lds_fix kernels", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
                "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms / nstep, "traffic": None}
         hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
         # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, gfx950 x2 read
@@ -360,7 +360,7 @@ def main():
                 def fam(*names):      # launch-weighted mean over the kernel families that make up one roofline entry
                     n = sum(pmc[k]["launches"] for k in names if k in pmc)
                     return sum(pmc[k]["launches"] * pmc[k]["fetch_bytes_per_launch_corrected"] for k in names if k in pmc) / max(n, 1)
-                hbm["traffic"] = fam("gemm_skinny_kernel", "norm_gemm_skinny_kernel")
+                hbm["traffic"] = fam("gemm_skinny_kernel", "norm_gemm_skinny_kernel", "norm_glu_lds_kernel", "gemm_skinny_lds_fix_kernel")
                 hbm["algorithmic_bytes_per_launch"] = sk_by / max(sk_n, 1)
                 mfma["traffic"] = fam("gemm_nt_kernel", "gemm_nt8p_kernel", "gemm_nt256_kernel")
                 mfma["algorithmic_flops_per_launch"] = big_fl / max(big_n, 1)
