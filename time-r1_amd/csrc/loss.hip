@@ -169,6 +169,33 @@ TR1_DEV void samp_find_bin(const unsigned* hist, int need, int& bin, int& rem) {
     bin = b; rem = need - acc;
 }
 
+// The same search by the first 256 threads of a block (one bin each, from the top): a suffix scan replaces the up-to-255 dependent reads of the
+// serial walk (12 us of a 26 us launch).  hist: 256 bins in LDS; scr: 8 unsigned of LDS scratch; result in *bin_out / *rem_out (LDS).
+TR1_DEV void samp_find_bin_par(const unsigned* hist, int need, unsigned* scr, int* bin_out, int* rem_out) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned val = 0u, incl = 0u;
+    if (tid < 256) {
+        val = hist[255 - tid];
+        incl = val;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) scr[w] = incl;
+    }
+    if (tid == 0) { *bin_out = 0; *rem_out = -1; }
+    __syncthreads();
+    if (tid < 256) {
+        unsigned off = 0u;
+        for (int j = 0; j < w; ++j) off += scr[j];
+        incl += off;
+        const unsigned excl = incl - val;
+        if (tid < 255 && (int)incl >= need && (int)excl < need) { *bin_out = 255 - tid; *rem_out = need - (int)excl; }   // exactly one thread
+        if (tid == 254) scr[4] = incl;                                            // count in bins 255 .. 1 (fallback: bin 0)
+    }
+    __syncthreads();
+    if (tid == 0 && *rem_out < 0) *rem_out = need - (int)scr[4];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void samp_hist_hi_kernel(SampleArgs a) {
     __shared__ unsigned h[256];
     __shared__ unsigned smax;
@@ -193,9 +220,12 @@ __global__ __launch_bounds__(256) void samp_hist_lo_kernel(SampleArgs a) {
     const int r = blockIdx.y;
     if (samp_row_done(a, r)) return;
     unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
+    __shared__ unsigned hh[256], scr[8];
+    __shared__ int srem;
     h[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) { int bin, rem; samp_find_bin(ws, a.top_k, bin, rem); sbin = bin; }
+    hh[threadIdx.x] = ws[threadIdx.x];
     __syncthreads();
+    samp_find_bin_par(hh, a.top_k, scr, &sbin, &srem);
     const unsigned bin = (unsigned)sbin;
     const bf16_t* row = a.logits + (int64_t)r * a.ld;
     const int per = (a.V + SAMP_S - 1) / SAMP_S, i0 = blockIdx.x * per, i1 = min(a.V, i0 + per);
@@ -285,6 +315,129 @@ __global__ __launch_bounds__(256) void samp_pick_kernel(SampleArgs a) {
     }
 }
 
+// slice_sum + pick in ONE launch, one 1024-thread block per row (the separate pair cost 15 + 33 us per decode step, most of it the serial
+// walks of thread 0).  The 16 waves own contiguous segments of the row; a wave reads its segment coalesced (64 lanes x 16 bytes per
+// iteration) and keeps the per-iteration wave sums, so the inverse-CDF walk in vocabulary order is a three-level search (segment ->
+// iteration -> lane) with one lane finally walking 8 logits.  Needs V % 8 == 0, ld % 8 == 0 and V <= SAMP_FUSED_MAXV.
+#define SAMP_MAXIT 20
+#define SAMP_FUSED_MAXV (16 * 64 * SAMP_MAXIT * 8)
+__global__ __launch_bounds__(1024) void samp_sum_pick_kernel(SampleArgs a) {
+    __shared__ float wsum[16];
+    __shared__ unsigned sthr; __shared__ int sseg; __shared__ float sbase, starget;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    int* tok_out = a.tokens + (int64_t)r * a.tok_ld + step;
+    if (samp_row_done(a, r)) { if (tid == 0) *tok_out = a.pad_id; return; }
+    unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
+    __shared__ unsigned shist[512];                 // both histograms staged once: the threshold search of thread 0 then walks LDS, not global memory
+    __shared__ unsigned scr[8];
+    __shared__ int sbin, srem, slo, srem2;
+    if (tid < 512) shist[tid] = ws[tid];
+    __syncthreads();
+    if (a.top_k <= 0 || a.top_k >= a.V) { if (tid == 0) sthr = 0u; __syncthreads(); }
+    else {
+        samp_find_bin_par(shist, a.top_k, scr, &sbin, &srem);
+        samp_find_bin_par(shist + 256, srem, scr, &slo, &srem2);
+        if (tid == 0) sthr = ((unsigned)sbin << 8) | (unsigned)slo;
+        __syncthreads();
+    }
+    const unsigned thr = sthr;
+    const float mx = key_logit(ws[512]);
+    const bf16_t* row = a.logits + (int64_t)r * a.ld;
+    const int nch = a.V >> 3, seg = (nch + 15) >> 4, c0 = wave * seg, c1 = min(nch, c0 + seg);
+    const int nit = (seg + 63) >> 6;
+    // all loads of the segment are issued up front (clamped addresses, no branches around them): one L2 round trip instead of one per iteration
+    u32x4_t vals[SAMP_MAXIT];
+#pragma unroll
+    for (int it = 0; it < SAMP_MAXIT; ++it) {
+        int ch = c0 + it * 64 + lane; if (ch > nch - 1) ch = nch - 1;
+        vals[it] = *reinterpret_cast<const u32x4_t*>(row + (int64_t)ch * 8);
+    }
+    float lsum[SAMP_MAXIT], itsum[SAMP_MAXIT];
+    float wtot = 0.f;
+    // Chunk-level reject for top-k: the two 16-bit keys of every dword are formed with 32-bit ops (key = b ^ (sign ? 0xffff : 0x8000)) and the
+    // chunk's largest key is compared with the threshold key - one test per 8 logits instead of 8 key transforms + 8 divergent branches (one
+    // CU handles the whole row, so this loop is instruction-issue bound); only the ~k chunks that hold a kept logit take the exact path.
+    const bool filt = thr != 0u;
+#pragma unroll
+    for (int it = 0; it < SAMP_MAXIT; ++it) {
+        const int ch = c0 + it * 64 + lane;
+        const bool okc = it < nit && ch < c1;
+        bool any = okc;
+        if (filt) {
+            unsigned mk = 0u;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned w = vals[it][d];
+                const unsigned neg = (w >> 15) & 0x00010001u;                 // 1 in each half that holds a negative value
+                const unsigned kw = w ^ (((neg << 15) - neg) | 0x80008000u);  // negative half: ^ 0xffff, positive half: ^ 0x8000
+                mk = max(mk, max(kw >> 16, kw & 0xffffu));
+            }
+            any = okc & (mk >= thr);
+        }
+        float sacc = 0.f;
+        if (any) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {        // vocabulary order inside the chunk
+                const bf16_t b = (bf16_t)((e & 1) ? (vals[it][e >> 1] >> 16) : (vals[it][e >> 1] & 0xffffu));
+                if (bfkey(b) >= thr) sacc += __expf((bf2f(b) - mx) * a.inv_temp);
+            }
+        }
+        lsum[it] = sacc;
+        itsum[it] = wave_sum(sacc);
+        wtot += itsum[it];
+    }
+    if (lane == 0) wsum[wave] = wtot;
+    __syncthreads();
+    if (tid == 0) {
+        float Z = 0.f;
+        for (int w = 0; w < 16; ++w) Z += wsum[w];
+        const int grp = a.group_rows > 0 ? r / a.group_rows : 0;
+        const unsigned long long sd = a.seed + (unsigned long long)grp * a.seed_stride;
+        unsigned c[4] = {(unsigned)(a.group_rows > 0 ? r % a.group_rows : r), (unsigned)step, 0u, 0u};
+        philox4x32_10(c, (unsigned)(sd & 0xffffffffu), (unsigned)(sd >> 32));
+        const float uu = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        if (a.u_out) a.u_out[r] = uu;
+        const float target = uu * Z;
+        const int nv = (nch + seg - 1) / seg;        // non-empty segments (small vocabularies leave the last waves without chunks)
+        float acc = 0.f; int sg = 0;
+        for (; sg < nv - 1; ++sg) { if (acc + wsum[sg] >= target) break; acc += wsum[sg]; }
+        sseg = sg; sbase = acc; starget = target;
+    }
+    __syncthreads();
+    if (wave != sseg) return;
+    const float target = starget;
+    float c = sbase;
+    int it = 0;
+    float sl = lsum[0];
+#pragma unroll
+    for (int j = 0; j < SAMP_MAXIT - 1; ++j) {      // wave-uniform walk over the iteration sums; `sl` follows the selected iteration
+        if (it == j && j + 1 < nit && !(c + itsum[j] >= target)) { c += itsum[j]; it = j + 1; sl = lsum[j + 1]; }
+    }
+    float incl = sl;                                // inclusive scan over the lanes (vocabulary order inside the iteration)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const float excl = incl - sl;
+    const int last_ch = min(c1, c0 + (it + 1) * 64) - 1;                 // last valid chunk of this iteration
+    const unsigned long long hit = __ballot(c + incl >= target && c0 + it * 64 + lane <= last_ch);
+    const int L = hit ? (__ffsll((long long)hit) - 1) : (last_ch - (c0 + it * 64));
+    if (lane != L) return;
+    const int ch = c0 + it * 64 + L;
+    float cc = c + excl;
+    int tok = -1, last_kept = -1;
+    for (int i = ch * 8; i < ch * 8 + 8; ++i) {
+        const bf16_t b = row[i];
+        if (bfkey(b) >= thr) { last_kept = i; cc += __expf((bf2f(b) - mx) * a.inv_temp); if (cc >= target) { tok = i; break; } }
+    }
+    if (tok < 0) {   // rounding slack: fall back to the last kept token at or before this point
+        if (last_kept >= 0) tok = last_kept;
+        else { for (int i = ch * 8 + 7; i >= 0; --i) { if (bfkey(row[i]) >= thr) { tok = i; break; } } }
+        if (tok < 0) { for (int i = 0; i < a.V; ++i) { if (bfkey(row[i]) >= thr) { tok = i; break; } } }
+    }
+    *tok_out = tok;
+    if (a.finished && tok == a.eos_id) a.finished[r] = 1;
+}
+
 extern "C" int tr1_logp_entropy_fwd(const void* logits, int64_t ld, const void* targets, void* logp, void* entropy, void* lse, int64_t R,
                                     int64_t V, void* stream) {
     TR1_CHECK_ARG(ld % 8 == 0, "logp_entropy: ld must be a multiple of 8");
@@ -328,7 +481,11 @@ extern "C" int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, i
     dim3 grid(SAMP_S, (unsigned)rows);
     hipLaunchKernelGGL(samp_hist_hi_kernel, grid, dim3(256), 0, s, a);     // also yields the row max (needed without top-k too)
     if (top_k > 0 && top_k < V) hipLaunchKernelGGL(samp_hist_lo_kernel, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(samp_slice_sum_kernel, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(samp_pick_kernel, dim3((unsigned)rows), dim3(256), 0, s, a);
+    if (V % 8 == 0 && ld % 8 == 0 && V <= SAMP_FUSED_MAXV && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        hipLaunchKernelGGL(samp_sum_pick_kernel, dim3((unsigned)rows), dim3(1024), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(samp_slice_sum_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(samp_pick_kernel, dim3((unsigned)rows), dim3(256), 0, s, a);
+    }
     TR1_LAUNCH_CHECK();
 }
