@@ -301,8 +301,11 @@ def test_grpo_loss(hip_ops, ref_ops, use_grpo, beta):
         close(h, r, 1e-5, rtol=1e-4, what="grpo " + w)
 
 
-def test_sampler(hip_ops, ref_ops):
-    rows, V, C = 8, 3000, 4
+@pytest.mark.parametrize("rows,V", [(8, 3000), (16, 152064), (3, 1001), (5, 40), (2, 16392)])
+def test_sampler(hip_ops, ref_ops, rows, V):
+    """(16, 152064): the rollout's shape (fused slice-sum + pick launch, 19 iterations per wave); 1001: V % 8 != 0 takes the separate kernels;
+    40 / 16392: fewer chunks than waves / a ragged last segment."""
+    C = 4
     logits = rnd(rows, V, seed=1, scale=2.5)
     for top_k in (0, 50):
         tok_h = torch.zeros(rows, C, dtype=torch.int32, device="cuda:0")
@@ -317,7 +320,7 @@ def test_sampler(hip_ops, ref_ops):
         x = logits.float() / 0.9
         for r in range(rows):
             xr = x[r].double()
-            keep = xr >= (torch.topk(xr, top_k).values[-1] if top_k else -1e30)
+            keep = xr >= (torch.topk(xr, top_k).values[-1] if top_k and top_k < V else -1e30)
             p = torch.where(keep, (xr - xr.max()).exp(), torch.zeros_like(xr))
             cdf = torch.cumsum(p, 0) / p.sum()
             t = int(tok_h[r, 2])
@@ -413,7 +416,9 @@ def test_video_preprocess_fused(hip_ops, ref_ops, T, H, W, Ho, Wo):
 
 
 @pytest.mark.parametrize("M,N,K,glu", [(8, 512, 256, False), (16, 4608, 3584, False), (16, 100032, 256, False), (32, 100096, 320, False), (5, 72, 320, False), (16, 1024, 3584, True), (13, 200, 512, True),
-                                       (32, 4608, 3584, False), (24, 1024, 1536, True), (64, 512, 3584, False), (40, 136, 832, True)])
+                                       (32, 4608, 3584, False), (24, 1024, 1536, True), (64, 512, 3584, False), (40, 136, 832, True),
+                                       # LDS-streamed GLU kernel (M <= 16, K = 3584 / 1536): full gate/up width, fewer pairs than CUs, ragged row counts
+                                       (5, 18944, 3584, True), (1, 48, 3584, True), (16, 8960, 1536, True), (9, 4112, 1536, True)])
 def test_norm_gemm_fused(hip_ops, ref_ops, M, N, K, glu):
     """rmsnorm folded into the decode GEMM (and SwiGLU into its epilogue) vs the unfused oracle composition."""
     x, lnw = rnd(M, K, seed=1, scale=2.0), (1.0 + 0.1 * rnd(K, seed=2).float()).to(BF16)
@@ -432,7 +437,7 @@ def test_norm_gemm_fused(hip_ops, ref_ops, M, N, K, glu):
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 3584, 18944), (16, 3584, 3584), (8, 1536, 8960), (5, 200, 2048), (32, 3584, 18944), (24, 1536, 1536), (64, 512, 4096),
-                                   (16, 128, 256)])
+                                   (16, 128, 256), (3, 128, 18944), (1, 64, 8192)])
 def test_gemm_skinny_fixup(hip_ops, M, N, K):
     """Cross-block split-K with in-kernel fixup == the single-pass skinny GEMM (fp32 sums in a different order: bf16-ulp tolerance),
     launched repeatedly to exercise the self re-arming ticket counters."""
