@@ -52,7 +52,6 @@ class Workload:
         if hasattr(self.params, "init_random_device"):
             self.params.init_random_device(seed=0)
         self.eng = Engine(self.cfg, ops, self.params)
-        self.eng.cache_wt = bool(args.wt_cache)
         self.ref = self.params.train.clone_weights_only() if args.beta != 0.0 else None
         self.core = GRPOCore(self.eng, self.ref, args.G, args.C, beta=args.beta, use_grpo=not args.clip_loss, temperature=1.0, top_k=50,
                              seed=1234 + rank, rope_index_mode="hf4")
@@ -263,8 +262,6 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only)")
-    ap.add_argument("--wt-cache", action="store_true", help="keep W^T of the dgrad GEMMs across the accumulation window (Engine.cache_wt; measured SLOWER: "
-                    "backward 186 vs 174 ms - the freshly written W^T is served from the Infinity Cache, the cached copy from HBM beside the wgrad stream)")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: all-reduce the gradient arena after backward instead of during it")
     args = ap.parse_args()
 

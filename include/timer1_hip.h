@@ -32,6 +32,9 @@ int tr1_device_info(int device, char* arch, int64_t arch_len, int64_t* n_cu, int
  * K % 64 == 0 (pad), N % 8 == 0.  out_f32: C is fp32; accumulate (fp32 only): C += result (weight-gradient accumulation).
  * M <= 16 dispatches the HBM-streaming skinny kernel used by rollout decode. */
 int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream);
+/* C[M,N] = A[M,K] * B[K,N], B K-major ("NN").  The dgrad of a Linear (dX = dY * W; reference: autograd of F.linear under accelerator.backward,
+ * TF trainer.py:1952-1961) reads the weight as stored instead of a transposed copy.  Needs M >= 512, N >= 256, K % 64 == 0; bf16 in / out. */
+int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, void* stream);
 /* Decode-step fusion (M <= 64 rows): out = rmsnorm(x; lnw, eps) @ W[N,K]^T (+ bias), the norm folded into the GEMM's operand load
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
  * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */

@@ -66,6 +66,10 @@ class RefOps:
         return x.to(self.act_dtype)
 
     # ---- GEMM (ref: nn.Linear, TF:501-504 / :459-466 / :251-274 / :277-290 / :1323)
+    def gemm_nn(self, a, b):
+        """C = a @ b with b K-major (dgrad of a Linear: dX = dY @ W)"""
+        return a.float() @ b.float()
+
     def gemm_nt(self, a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
         c = a.float() @ b.float().t()
         if bias is not None:

@@ -519,3 +519,15 @@ def test_norm_gemm_qkv_fused(hip_ops, ref_ops, R, nh, nkv, hd, K):
     close(outs[0][0], rq, 0.05, what="fused qkv: q")
     close(outs[0][1], kc, 0.05, what="fused qkv: K cache")
     close(outs[0][2], vt, 0.05, what="fused qkv: V^T cache")
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (1000, 520, 192), (5074, 3584, 4608), (1600, 3584, 18944), (700, 264, 1024), (2049, 1288, 320)])
+def test_gemm_nn(hip_ops, M, N, K):
+    """K-major B operand (dgrad dX = dY @ W reads the weight as stored): transposing LDS reads vs a float64 product, and bit-equal to the
+    NT kernel fed with the transposed copy (same tiles, same k order inside every MFMA, same accumulation order)."""
+    a, b = rnd(M, K, seed=1).cuda(), rnd(K, N, seed=2, scale=1.0 / math.sqrt(K)).cuda()
+    got = hip_ops.gemm_nn(a, b)
+    ref = (a.double() @ b.double()).float()
+    close(got, ref.cpu(), 0.03, rtol=0.02, what="gemm_nn")
+    nt = hip_ops.gemm_nt(a, b.t().contiguous())
+    assert torch.equal(got, nt), "NN and NT forms accumulate in the same order"

@@ -318,6 +318,27 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 #define TR1_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TR1_BARRIER() do { TR1_PIN(); __builtin_amdgcn_s_barrier(); TR1_PIN(); } while (0)
 
+// K-major ("NN") B operand: B is [K, N] row-major (the weight itself in dX = dY * W).  A round stages 16 k-rows x 256 columns (512 bytes
+// per row, two rows per wave instruction); row r keeps its logical 16-byte chunk c at position c ^ keyKM(r), and the MFMA fragments are read
+// back TRANSPOSED with ds_read_b64_tr_b16 (a 16-lane group reads a 4 x 16 block, each lane supplying an 8-byte address and receiving one
+// column), so no W^T copy is ever built.  With 512-byte rows eight k-rows of a half-wave share their banks; the key spreads them over the
+// four translates a 16-byte-granular swizzle can reach (2-way conflicts on these reads, 8 of the 24 fragment reads of a tile).
+typedef __attribute__((ext_vector_type(4))) short gemm_s16x4_t;
+TR1_DEV u32x2_t gemm_lds_read_tr16(const char* p) {
+    const gemm_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gemm_s16x4_t*)(p));
+    return __builtin_bit_cast(u32x2_t, v);
+}
+TR1_DEV int keyKM(int krow) { return (krow & 1) | ((krow & 2) << 2); }
+TR1_DEV void stage_round_km(const bf16_t* __restrict__ g, int64_t ld, int64_t n0, int64_t n_valid, int64_t k0, char* lds_region, int round,
+                            int wave, int lane) {
+    const int inst = round * 8 + wave;                                   // 2 k-rows (1 KiB) per wave-instruction
+    const int krow = inst * 2 + (lane >> 5);
+    const int logical = (lane & 31) ^ keyKM(krow);
+    int64_t col = n0 + logical * 8;
+    if (col + 8 > n_valid) col = n_valid - 8;                            // columns past N: any valid chunk (their outputs are never stored)
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (k0 + krow) * ld + col), (lptr_t)(lds_region + inst * 1024), 16, 0, 0);
+}
+
 template <bool IS_B, int REGION_ROWS>
 TR1_DEV void stage_round(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_region,
                          char* junk, int round, int wave, int lane) {
@@ -331,7 +352,7 @@ TR1_DEV void stage_round(const bf16_t* __restrict__ g, int64_t ld, int64_t row0,
     __builtin_amdgcn_global_load_lds((gptr_t)(g + grow * ld + k0 + logical * 8), (lptr_t)dst, 16, 0, 0);
 }
 
-template <bool OUT_F32, bool ACCUM, int RT>
+template <bool OUT_F32, bool ACCUM, int RT, bool BKM = false>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
                                                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
@@ -372,9 +393,14 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
     // per-lane LDS byte offsets of the fragment reads (k-step 1 = k-step 0 with chunk bit 2 flipped: offset ^ 64)
     const int a_off = (wm * (RT * 16) + u) * 128 + ((g ^ ((u >> 1) & 7)) << 4);
     const int b_off = (wn * 64 + (u >> 2) * 16 + (u & 3)) * 128 + ((g ^ (((u >> 2) << 1) | ((u >> 1) & 1))) << 4);
+    // BKM fragment j of k step ks: lane L of a 16-lane group supplies row (L >> 2) of a 4-row block, 8 bytes at columns wn*64 + (L & 3)*16 + j*4.
+    // Lane group g takes the blocks of k rows g*8 .. +3 and g*8 + 4 .. +7, i.e. the standard k order of the MFMA, so the A side is unchanged.
+    const int bkm_row = g * 8 + (u >> 2);                                   // + ks*32 (+4 for the second half)
+    const int bkm_key = keyKM(bkm_row);                                     // depends on the row's low two bits only
 
 #define STAGE_A(t, r) stage_round<false, BMX>(A, lda, m0, M, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES, junk, (r), wave, lane)
-#define STAGE_B(t, r) stage_round<true, BN2>(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, junk, (r), wave, lane)
+#define STAGE_B(t, r) do { if (BKM) stage_round_km(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, (r), wave, lane); \
+                           else stage_round<true, BN2>(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, junk, (r), wave, lane); } while (0)
     // prologue: tile 0 complete, B of tile 1 in flight
 #pragma unroll
     for (int r = 0; r < 4; ++r) STAGE_B(0, r);
@@ -412,10 +438,23 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
         const char* curA = smem2 + (t & 1) * BUF_BYTES;
         const char* curB = curA + A_BYTES;
         // ---- phase 0: all B fragments + A quarter 0; A rounds [0, AR0) of tile t+1
+        if (BKM) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bf[j][0] = *reinterpret_cast<const bf16x8_t*>(curB + b_off + j * 512);
-            bf[j][1] = *reinterpret_cast<const bf16x8_t*>(curB + (b_off ^ 64) + j * 512);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int lc = wn * 8 + (u & 3) * 2 + (j >> 1);                                    // logical 16-byte chunk of the piece
+                    const char* pb = curB + (ks * 32 + bkm_row) * 512 + ((lc ^ bkm_key) << 4) + (j & 1) * 8;
+                    const u32x2_t h0 = gemm_lds_read_tr16(pb), h1 = gemm_lds_read_tr16(pb + 4 * 512);    // rows +4: same key (low two bits unchanged)
+                    u32x4_t w = {h0[0], h0[1], h1[0], h1[1]};
+                    bf[j][ks] = __builtin_bit_cast(bf16x8_t, w);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf[j][0] = *reinterpret_cast<const bf16x8_t*>(curB + b_off + j * 512);
+                bf[j][1] = *reinterpret_cast<const bf16x8_t*>(curB + (b_off ^ 64) + j * 512);
+            }
         }
         LOAD_A(Q0, Q1);
         if (t + 1 < nk) {
@@ -1112,6 +1151,41 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     if (out_f32) { if (accumulate) LAUNCH(true, true); else LAUNCH(true, false); }
     else LAUNCH(false, false);
 #undef LAUNCH
+    TR1_LAUNCH_CHECK();
+}
+
+// C[M,N] = A[M,K] * B[K,N]  ("NN": B is K-major - the dgrad dX = dY * W reads the weight as stored, no W^T copy).  Phased 8-wave forms only
+// (M >= 512, N >= 256): B tiles are staged as 16 k-rows x 256 columns per round and read back transposed (ds_read_b64_tr_b16).  bf16 output.
+extern "C" int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                void* stream) {
+    TR1_CHECK_ARG(K % BK == 0, "gemm_nn: K must be a multiple of 64");
+    TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "gemm_nn: N%8, lda%8, ldb%8, ldc%8 required");
+    TR1_CHECK_ARG(M >= 512 && N >= 256, "gemm_nn: M >= 512 and N >= 256 required (smaller problems: transpose B and use gemm_nt)");
+    hipStream_t s = (hipStream_t)stream;
+    auto cost = [&](int64_t bm, double eff) {
+        const int64_t t = ((M + bm - 1) / bm) * ((N + BN2 - 1) / BN2);
+        return (double)((t + 255) / 256) * 256.0 * (double)(bm * BN2) / eff;
+    };
+    static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
+    int rt = 8; double best = cost(256, 1.0);
+    for (int r = 7; r <= 10; ++r) { const double c = cost(r * 32, eff[r - 7]); if (c < best) { best = c; rt = r; } }
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES)) + 4096;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<false, false, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<false, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<false, false, 9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<false, false, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr_set = true;
+    }
+    dim3 grid2((unsigned)(t2m * t2n));
+#define LAUNCHNN(R) hipLaunchKernelGGL((gemm_nt8p_kernel<false, false, R, true>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, \
+                                       (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, (int64_t)0, (int)t2m, (int)t2n)
+    if (rt == 7) LAUNCHNN(7); else if (rt == 9) LAUNCHNN(9); else if (rt == 10) LAUNCHNN(10); else LAUNCHNN(8);
+#undef LAUNCHNN
     TR1_LAUNCH_CHECK();
 }
 

@@ -25,12 +25,6 @@ class Engine:
         self.cfg, self.ops, self.params = cfg, ops, params
         self.overlap_wgrad = True
         self._side = None
-        # dgrad needs W^T; the weights only change at the optimizer step, so a trainer that bumps `arena.version` there (AdamWFlat.step does)
-        # may keep the transposed copies across the micro-steps of an accumulation window (opt-in: +2 bytes per parameter of HBM).  Measured on
-        # MI355X (7B, GA = 2): backward 186 ms with the cache vs 174 ms without - a W^T written just before its GEMM is read back from the 256 MB
-        # Infinity Cache, a cached one from HBM in competition with the weight-gradient stream - so it stays off by default.
-        self.cache_wt = False
-        self._wt_cache = {}
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
@@ -62,18 +56,11 @@ class Engine:
         x.record_stream(side)
 
     def _dgrad(self, dy, w, key=None):
-        """dx[M,K] = dy[M,N] @ w[N,K]"""
+        """dx[M,K] = dy[M,N] @ w[N,K].  The weight is the K-major operand of an "NN" GEMM: large problems read it as stored through the
+        transposing LDS reads of the phased kernel (ops.gemm_nn), so no W^T copy is built (a cached W^T was measured SLOWER than a fresh one -
+        the fresh copy is served from the Infinity Cache - and the NN form needs neither)."""
         assert dy.shape[1] % 64 == 0, "dgrad: N must be a multiple of 64"
-        if self.cache_wt and key is not None:
-            ver = getattr(self.params.train, "version", 0)
-            hit = self._wt_cache.get(key)
-            if hit is None or hit[0] != ver or hit[1].shape[1] != w.shape[0]:
-                hit = (ver, self.ops.transpose(w))
-                self._wt_cache[key] = hit
-            wt = hit[1]
-        else:
-            wt = self.ops.transpose(w)       # [K, N]
-        return self.ops.gemm_nt(dy, wt)
+        return self.ops.gemm_nn(dy, w)
 
     # ============================================================================================================ ViT
     def vit_features(self, pixels, grid_thw):

@@ -60,6 +60,19 @@ class HipOps:
                 assert t.device.type == "cuda" and t.dtype == dtype, (t.device, t.dtype, dtype)
 
     # ---- GEMM -----------------------------------------------------------------------------------------------------
+    def gemm_nn(self, a, b):
+        """C[M,N] = a[M,K] @ b[K,N] (b K-major, e.g. the weight itself in a dgrad).  Large problems run the K-major form of the phased GEMM
+        (no transposed copy); small ones transpose b and use gemm_nt."""
+        self._chk(a, b)
+        M, K = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
+        if M >= 512 and N >= 256 and K % 64 == 0 and N % 8 == 0:
+            c = self.empty(M, N)
+            self.L.call("tr1_gemm_nn_bf16", _p(a), _p(b), _p(c), M, N, K, _ld(a), _ld(b), _ld(c), self._s())
+            return c
+        return self.gemm_nt(a, self.transpose(b))
+
     def gemm_nt(self, a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
         """C[M,N] = a[M,K] @ b[N,K]^T (+bias) (+residual); bf16 in, fp32 accumulate. K must be a multiple of 64."""
         self._chk(a, b, bias, residual)

@@ -81,7 +81,6 @@ class GRPOConfig:
     gpu_video_preprocess: bool = False      # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path
     rollout_weight_dtype: str = "bf16"      # "fp8": the SAMPLING policy reads e4m3 copies of the decoder matrices (row scales, re-quantised every window);
                                             # log-probs, KL and the update keep bf16 weights (BASELINE config "fp8 weights")
-    cache_weight_transposes: bool = False   # keep W^T (dgrad operand) across the micro-steps of an accumulation window (+2 B / parameter); measured slower on MI355X
     dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
@@ -226,7 +225,6 @@ class TimeR1_Trainer:
             raise TypeError("model must be a checkpoint path, a preset name, a ModelConfig or a ModelParams")
         self.model = self.params
         self.engine = Engine(self.cfg, ops, self.params)
-        self.engine.cache_wt = bool(getattr(args, "cache_weight_transposes", False))   # W^T kept across the accumulation window
         self.beta = args.beta
         self.ref_model = self.params.train.clone_weights_only() if self.beta != 0.0 else None    # reference :295-307
         # ---- processor

@@ -142,6 +142,12 @@ def gemm():
         a, b = rnd(M, K), rnd(N, K)
         us = timeit(lambda: ops.gemm_nt(a, b), reps=10, warm=2)
         print("M=%6d N=%6d K=%6d  %9.1f us  %7.1f TF" % (M, N, K, us, 2.0 * M * N * K / us / 1e6))
+    print("== dgrad dX = dY @ W: transpose(W) + NT   vs   NN (K-major B): us")
+    for M, N, K in [(5074, 3584, 18944), (5074, 18944, 3584), (5074, 3584, 37888), (5074, 3584, 4608), (5074, 3584, 3584)]:
+        dy, w = rnd(M, K), rnd(K, N)
+        t0 = timeit(lambda: ops.gemm_nt(dy, ops.transpose(w)), reps=10, warm=2)
+        t1 = timeit(lambda: ops.gemm_nn(dy, w), reps=10, warm=2)
+        print("M=%6d N=%6d K=%6d  transpose+NT %8.1f   NN %8.1f  (%.0f TF)" % (M, N, K, t0, t1, 2.0 * M * N * K / t1 / 1e6))
     a, b = rnd(3584, 5120), rnd(18944, 5120)
     out = torch.zeros(3584, 18944, device="cuda")
     us = timeit(lambda: ops.gemm_nt(a, b, out_f32=True, out=out, accumulate=True), reps=10, warm=2)
