@@ -28,16 +28,26 @@ class Engine:
         # chain.  With the dgrad reading the weights as stored (NN form) the main stream has slack: keeping the down projection's weight
         # gradient there balanced the two streams best on MI355X (backward 175 ms against 180 with everything on the side stream).
         self.wgrad_on_main = "d"
+        self.wgrad_overwrite_first = True    # see _wgrad: relies on the optimizer zeroing the gradient arena and bumping arena.version (AdamWFlat.step)
+        self._gw_ver = {}
         self._side = None
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
-    def _wgrad(self, dy, x, gw):
-        """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K]"""
+    def _wgrad(self, dy, x, gw, key=None):
+        """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K].  key (decoder-layer weights): the FIRST weight gradient after an optimizer step (the arena's
+        version changed) overwrites gw instead of accumulating - AdamW left it at zero, so the result is identical and the GEMM epilogue skips
+        reading 4 bytes per parameter (33 GB per accumulation window at 7B)."""
         ops = self.ops
         dyt = ops.transpose(dy)          # [N, Mp]
         xt = ops.transpose(x)            # [K, Mp]
-        ops.gemm_nt(dyt, xt, out_f32=True, out=gw, accumulate=True)
+        acc = True
+        if key is not None and self.wgrad_overwrite_first:
+            ver = getattr(self.params.train, "version", None)
+            if ver is not None and self._gw_ver.get(key) != ver:
+                self._gw_ver[key] = ver
+                acc = False
+        ops.gemm_nt(dyt, xt, out_f32=True, out=gw, accumulate=acc)
 
     # Weight gradients of the decoder layers on a second HIP stream: wgrad (dy^T x) and dgrad (dy W) of a Linear only share their input,
     # so the two GEMM chains run concurrently and each fills the CUs the other leaves idle in its last, partially filled round of tiles
@@ -49,13 +59,13 @@ class Engine:
             self._side = torch.cuda.Stream(device=self.ops.device)
         return self._side
 
-    def _wgrad_async(self, dy, x, gw, side):
+    def _wgrad_async(self, dy, x, gw, side, key=None):
         if side is None:
-            return self._wgrad(dy, x, gw)
+            return self._wgrad(dy, x, gw, key)
         main = torch.cuda.current_stream(self.ops.device)
         side.wait_stream(main)                         # dy (and every earlier write of gw) is ordered before the side work
         with torch.cuda.stream(side):
-            self._wgrad(dy, x, gw)
+            self._wgrad(dy, x, gw, key)
         dy.record_stream(side)                         # keep the caching allocator from recycling them under the side stream
         x.record_stream(side)
 
@@ -284,14 +294,14 @@ class Engine:
             M = dh.shape[0]
             # h_out = a @ Wd^T + h2
             _sync = self.wgrad_on_main
-            self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side)
+            self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side, key=p + "down.w")
             da = self._dgrad(dh, tr.w(p + "down.w"), key=p + "down.w")
             dgu = ops.swiglu_bwd(da, L["gu"])
-            self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side)
+            self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side, key=p + "gu.w")
             dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"), key=p + "gu.w")
             dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))
             # h2 = o @ Wo^T + h
-            self._wgrad_async(dh2, L["o"], tr.g(p + "o.w"), None if "o" in _sync else side)
+            self._wgrad_async(dh2, L["o"], tr.g(p + "o.w"), None if "o" in _sync else side, key=p + "o.w")
             do = self._dgrad(dh2, tr.w(p + "o.w"), key=p + "o.w")
             dqkv = ops.empty(M, t.qkv_dim)
             v = L["qkv"][:, qd + kvd:]
@@ -300,7 +310,7 @@ class Engine:
             ops.rope_apply(dq, t.n_heads, hd, cos, sin, backward=True, out=dqkv[:, :qd])
             ops.rope_apply(dk, t.n_kv_heads, hd, cos, sin, backward=True, out=dqkv[:, qd:qd + kvd])
             ops.colsum_accum(dqkv, tr.g(p + "qkv.b"))
-            self._wgrad_async(dqkv, L["xn"], tr.g(p + "qkv.w"), None if "q" in _sync else side)
+            self._wgrad_async(dqkv, L["xn"], tr.g(p + "qkv.w"), None if "q" in _sync else side, key=p + "qkv.w")
             dxn = self._dgrad(dqkv, tr.w(p + "qkv.w"), key=p + "qkv.w")
             dh = ops.rmsnorm_bwd(dxn, L["h"], tr.w(p + "ln1"), L["rstd1"], dres=dh2, dw=tr.g(p + "ln1"))
             ctx["layers"][i] = None  # release this layer's activations
