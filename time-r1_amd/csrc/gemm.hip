@@ -834,21 +834,6 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
     const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
     const int npair = (int)(p1 - p0);
     const int64_t kb = (int64_t)wave * (K / 8);
-    // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares
-    bf16x8_t xr[NST * 2];
-    {
-        float ss = 0.f;
-        const bf16_t* xp = X + (int64_t)(u < M ? u : M - 1) * ldx + kb + g * 8;
-        const bf16_t* lp = lnw + kb + g * 8;
-#pragma unroll
-        for (int i = 0; i < NST * 2; ++i) {
-            const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xp + i * 32), lv = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
-            xr[i] = scale_frag_sumsq(xv, lv, ss);
-        }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        if (g == 0) ssq[wave * 16 + u] = ss;
-    }
     // ---- DMA lane map: instruction j covers rows 8j .. 8j+7; lane -> row 8j + (lane >> 3), physical chunk lane & 7, logical chunk ^ keyA(row).
     // Four per-lane source pointers (gate / up rows of the pair being ISSUED) advance by 16 rows per pair; the stage inside the pair is an
     // immediate offset of the DMA instruction, so issuing a stage costs no vector ALU work.
@@ -881,6 +866,22 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             if (i > 0 && i % NST == 0) GLU_NEXT_PAIR();
             GLU_ISSUE_ST(i % NST);
         }
+    }
+    // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares - built AFTER the first weight stages were
+    // issued, so the HBM stream starts at kernel entry instead of waiting for this L2 round trip
+    bf16x8_t xr[NST * 2];
+    {
+        float ss = 0.f;
+        const bf16_t* xp = X + (int64_t)(u < M ? u : M - 1) * ldx + kb + g * 8;
+        const bf16_t* lp = lnw + kb + g * 8;
+#pragma unroll
+        for (int i = 0; i < NST * 2; ++i) {
+            const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xp + i * 32), lv = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
+            xr[i] = scale_frag_sumsq(xv, lv, ss);
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (g == 0) ssq[wave * 16 + u] = ss;
     }
     TR1_BARRIER();                                       // the eight waves' sum-of-squares partials are in LDS (the prologue DMA is in flight)
     float rstd;
