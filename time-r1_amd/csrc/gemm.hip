@@ -967,7 +967,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     static int glu_lds = -1;                         // TR1_GLU_LDS=0 selects the register-fragment form (A/B measurements)
     if (glu_lds < 0) { const char* e = getenv("TR1_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
     const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
-    if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 3) && N % 16 == 0) {
+    if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3) && N % 16 == 0) {   // hidden 3584 / 2048 / 1536
         constexpr int RING = 3;          // a ring of 4 (with a single reduction buffer and a second barrier per pair) measured the same: 50.0 us
         const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
         static int n_cu = 0;
@@ -977,11 +977,15 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<7, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<3, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<4, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         }
         const int64_t NP = N / 16;
         const unsigned grid = (unsigned)(NP < n_cu ? NP : n_cu);
         if (nst == 7)
             hipLaunchKernelGGL((norm_glu_lds_kernel<7, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
+                               (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
+        else if (nst == 4)
+            hipLaunchKernelGGL((norm_glu_lds_kernel<4, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
                                (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
         else
             hipLaunchKernelGGL((norm_glu_lds_kernel<3, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
