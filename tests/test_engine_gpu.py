@@ -159,3 +159,45 @@ def test_fp8_weight_rollout(hip_ops):
     st2 = core.prepare(ids, pix, grid)
     core.rollout(st2)
     assert not torch.equal(q_before, core.roll._w8["layers"][0]["down.w"][0])
+
+
+def test_layer_done_hook_sees_final_gradients(hip_ops):
+    """Data-parallel overlap hook (GradSync.ready): when llm_bwd announces a layer on the main stream, every gradient of that layer - the ones
+    produced on the weight-gradient side stream included - must already be final.  The hook copies the layer's gradient range on the main
+    stream; the copies must equal the gradients after the whole backward."""
+    import time_r1_amd  # noqa: F401
+    from time_r1_amd.config import tiny_test
+    from time_r1_amd.params import ModelParams
+    from time_r1_amd.model import Engine
+    from time_r1_amd.grpo import GRPOCore
+    from time_r1_amd.synthetic import synthetic_prompt
+    cfg = tiny_test(n_layers=4)
+    ops = hip_ops
+    params = ModelParams(cfg, ops, seed=1)
+    eng = Engine(cfg, ops, params)
+    G, C = 4, 6
+    core = GRPOCore(eng, None, G, C, beta=0.0, seed=3, rope_index_mode="hf4")
+    ids, pix, grid = synthetic_prompt(cfg, (4, 6, 8), 9, 7, seed=2, text_vocab=400)
+    st = core.prepare(ids, pix, grid)
+    core.rollout(st)
+    core.forward_logps(st)
+    tr = params.train
+    snaps, order = {}, []
+
+    class FakeSync:
+        active = True
+
+        def ready(self, a, b):
+            snaps[(a, b)] = tr.grad[a:b].clone()       # main-stream copy at announcement time
+            order.append((a, b))
+    mask = torch.ones(G, C, dtype=torch.int32, device="cuda")
+    adv = torch.linspace(-1, 1, G, device="cuda")
+    core.loss_backward(st, mask, adv, 1.0, grad_sync=FakeSync())
+    torch.cuda.synchronize()
+    layer_ranges = [tr.range_of("l%d." % i) for i in range(cfg.text.n_layers)]
+    for rng in layer_ranges:
+        assert tuple(rng) in snaps, "layer range %s was never announced" % (rng,)
+        assert torch.equal(snaps[tuple(rng)], tr.grad[rng[0]:rng[1]]), "layer gradients changed after they were announced"
+        assert float(snaps[tuple(rng)].abs().sum()) > 0
+    announced_layers = [r for r in order if r in [tuple(x) for x in layer_ranges]]
+    assert announced_layers == [tuple(x) for x in reversed(layer_ranges)], "layers are announced in backward order"

@@ -288,6 +288,7 @@ class Engine:
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
         scale = hd ** -0.5
         side = self._side_stream()
+        pending = None
         for i in reversed(range(t.n_layers)):
             p = "l%d." % i
             L = ctx["layers"][i]
@@ -316,10 +317,20 @@ class Engine:
             ctx["layers"][i] = None  # release this layer's activations
             if on_layer_done is not None:
                 if side is not None:
-                    torch.cuda.current_stream(self.ops.device).wait_stream(side)     # this layer's weight gradients are final
-                on_layer_done(i)
+                    # this layer's side-stream weight gradients are final once `ev` has fired.  The announcement is deferred by one layer, so
+                    # the main stream waits on an event that is (almost always) already past instead of draining the side stream per layer
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    if pending is not None:
+                        torch.cuda.current_stream(self.ops.device).wait_event(pending[1])
+                        on_layer_done(pending[0])
+                    pending = (i, ev)
+                else:
+                    on_layer_done(i)
         if side is not None:
             torch.cuda.current_stream(self.ops.device).wait_stream(side)
+        if pending is not None:
+            on_layer_done(pending[0])
         return dh
 
     def embed_bwd(self, dh0, ids_for_grad, vid_rows=None):
