@@ -1201,14 +1201,14 @@ extern "C" int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
 // the 16 x 64 activation stages travel HBM/L2 -> LDS as full 128-byte row runs (global_load_lds), each wave has its own two-slot ring and
 // takes the slab's 64-wide stages round-robin, so the only ordering in the stream is the issuing wave's counted vmcnt.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, int MG = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int M,
                                                                          int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr,
                                                                          float* __restrict__ fix_ws, int* __restrict__ fix_cnt) {
-    constexpr int NC = 4, STAGE = NC * 2048 + 2048;                         // 64 weight rows + 16 activation rows, 128 bytes each
-    constexpr int TILE = NC * 256;
-    extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // [WAVES][2][STAGE]; afterwards red[WAVES][NC][16][17] f32; ticket at the end
+    constexpr int NC = 4, STAGE = NC * 2048 + MG * 2048;                    // 64 weight rows + 16*MG activation rows, 128 bytes each
+    constexpr int TILE = NC * MG * 256;
+    extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // [WAVES][2][STAGE]; afterwards red[WAVES][NC][MG][16][17] f32; ticket at the end
     int* s_ticket = reinterpret_cast<int*>(sk_lds + WAVES * 2 * STAGE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * (16 * NC);
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     const int n_my = wave < nst ? (nst - wave + WAVES - 1) / WAVES : 0;       // stages wave, wave + WAVES, ...
     char* ring = sk_lds + wave * 2 * STAGE;
     // DMA lane map (8 rows x 128 bytes per instruction): lane -> row 8j + (lane >> 3), physical chunk lane & 7, logical chunk ^ keyA(row)
-    const bf16_t* pw[8]; const bf16_t* px[2];
+    const bf16_t* pw[8]; const bf16_t* px[2 * MG];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = 8 * j + (lane >> 3);
@@ -1225,56 +1225,62 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
         pw[j] = W + row * ldw + k0 + (int64_t)wave * 64 + (((lane & 7) ^ keyA(r)) << 3);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2 * MG; ++j) {
         const int r = 8 * j + (lane >> 3);
         px[j] = X + (int64_t)(r < M ? r : M - 1) * ldx + k0 + (int64_t)wave * 64 + (((lane & 7) ^ keyA(r)) << 3);
     }
 #define SKL_ISSUE(SLOT) do {                                                                                              \
         char* dst__ = ring + (SLOT) * STAGE;                                                                              \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)pw[j], (lptr_t)(dst__ + j * 1024), 16, 0, 0); pw[j] += WAVES * 64; } \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)px[j], (lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 64; } \
+        _Pragma("unroll") for (int j = 0; j < 2 * MG; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)px[j], (lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 64; } \
     } while (0)
-    f32x4_t acc[NC][2];
+    f32x4_t acc[NC][MG][2];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) acc[c][mg][0] = acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int rd_w = u * 128, kA = keyA(u);
 #define SKL_CONSUME(SLOT) do {                                                                                            \
         const char* sb__ = ring + (SLOT) * STAGE;                                                                         \
-        bf16x8_t xf__[2], wf__[NC][2];                                                                                    \
+        bf16x8_t xf__[MG][2], wf__[NC][2];                                                                                \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
             const int off__ = ((ks * 4 + g) ^ kA) << 4;                                                                   \
-            xf__[ks] = *reinterpret_cast<const bf16x8_t*>(sb__ + NC * 2048 + rd_w + off__);                               \
+            _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) xf__[mg][ks] = *reinterpret_cast<const bf16x8_t*>(sb__ + (NC + mg) * 2048 + rd_w + off__); \
             _Pragma("unroll") for (int c = 0; c < NC; ++c) wf__[c][ks] = *reinterpret_cast<const bf16x8_t*>(sb__ + c * 2048 + rd_w + off__); \
         }                                                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
-        _Pragma("unroll") for (int c = 0; c < NC; ++c) acc[c][ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf__[c][ks], xf__[ks], acc[c][ks], 0, 0, 0); \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                                    \
+        _Pragma("unroll") for (int mg = 0; mg < MG; ++mg)                                                                 \
+            acc[c][mg][ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf__[c][ks], xf__[mg][ks], acc[c][mg][ks], 0, 0, 0); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
     } while (0)
     if (n_my > 0) SKL_ISSUE(0);
     for (int i = 0; i < n_my; i += 2) {
-        if (i + 1 < n_my) { SKL_ISSUE(1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i + 1 < n_my) { SKL_ISSUE(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * MG) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SKL_CONSUME(0);
         if (i + 1 < n_my) {
-            if (i + 2 < n_my) { SKL_ISSUE(0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (i + 2 < n_my) { SKL_ISSUE(0); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * MG) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             SKL_CONSUME(1);
         }
     }
 #undef SKL_ISSUE
 #undef SKL_CONSUME
     TR1_BARRIER();                                                          // every wave is done with its ring: the space becomes the reduction buffer
-    float* red = reinterpret_cast<float*>(sk_lds);                          // [WAVES][NC][16][17]
+    float* red = reinterpret_cast<float*>(sk_lds);                          // [WAVES][NC][MG][16][17]
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * NC + c) * 16 + u) * 17 + g * 4 + r] = acc[c][0][r] + acc[c][1][r];
+        for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave * NC + c) * MG + mg) * 16 + u) * 17 + g * 4 + r] = acc[c][mg][0][r] + acc[c][mg][1][r];
     __syncthreads();
     // ---- cross-block fixup (see gemm_skinny_kernel): park the tile with device-scope stores, draw a ticket, the last slab sums in slab order
     float* mine = fix_ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * TILE;
     for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
-        const int c = i >> 8, mm = (i >> 4) & 15, nn = i & 15;
+        const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) v += red[((w * NC + c) * 16 + mm) * 17 + nn];
+        for (int w = 0; w < WAVES; ++w) v += red[(((w * NC + c) * MG + mg) * 16 + mm) * 17 + nn];
         __hip_atomic_store(mine + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1283,7 +1289,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     __syncthreads();
     if (*s_ticket != (int)gridDim.y - 1) return;
     for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
-        const int c = i >> 8, mm = (i >> 4) & 15, nn = i & 15;
+        const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = mg * 16 + ((i >> 4) & 15), nn = i & 15;
         const int64_t n = n0 + c * 16 + nn;
         float v = 0.f;
         for (int ks = 0; ks < (int)gridDim.y; ++ks)
@@ -1333,7 +1339,13 @@ extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, cons
                        (int)M, N, K, lda, ldb, ldc, ldr, tiles, ks > 1 ? cnt : (int*)nullptr)
     static int down_lds = -1;                        // TR1_DOWN_LDS=0 selects the register-fragment form (A/B measurements); 6 / 7 = waves per block
     if (down_lds < 0) { const char* e = getenv("TR1_DOWN_LDS"); down_lds = e ? atoi(e) : 7; }
-    if (mg == 1 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {
+    if (mg == 2 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {       // 17 .. 32 rows: 12 KiB stages, 6 waves
+        static bool attr2 = false;
+        if (!attr2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 2 * 12288 + 16); attr2 = true; }
+        hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<6, 2>), dim3((unsigned)groups, (unsigned)ks), dim3(384), 6 * 2 * 12288 + 16, s, (const bf16_t*)A, (const bf16_t*)B,
+                           (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr, tiles, cnt);
+    }
+    else if (mg == 1 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 2 * 10240 + 16);
