@@ -315,6 +315,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
 //   Every ds_read is retired (lgkmcnt(0)) before the barrier that ends its load section, so a region may be restaged from the next
 //   barrier interval on.  A tiles whose row count is not a multiple of 64 send the surplus half round to a 4 KiB junk area.
 // ------------------------------------------------------------------------------------------------------------------
+// cache policy bits of the weight-stream DMA loads of the decode kernels (0 = default, 2 = nt: read-once weights leave L2 first)
+#ifndef TR1_W_AUX
+#define TR1_W_AUX 2
+#endif
 #define TR1_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TR1_BARRIER() do { TR1_PIN(); __builtin_amdgcn_s_barrier(); TR1_PIN(); } while (0)
 
@@ -851,8 +855,8 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
 #define GLU_ISSUE(ST) do {                                                                                               \
         char* dst__ = ring + islot * STAGE - (ST) * 128;   /* the instruction offset is added to the LDS address as well */  \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
-            __builtin_amdgcn_global_load_lds((gptr_t)pg[j], (lptr_t)(dst__ + j * 1024), 16, (ST) * 128, 0);              \
-            __builtin_amdgcn_global_load_lds((gptr_t)pu[j], (lptr_t)(dst__ + 2048 + j * 1024), 16, (ST) * 128, 0);       \
+            __builtin_amdgcn_global_load_lds((gptr_t)pg[j], (lptr_t)(dst__ + j * 1024), 16, (ST) * 128, TR1_W_AUX);              \
+            __builtin_amdgcn_global_load_lds((gptr_t)pu[j], (lptr_t)(dst__ + 2048 + j * 1024), 16, (ST) * 128, TR1_W_AUX);       \
         }                                                                                                                \
         islot = (islot + 1 == R) ? 0 : islot + 1;                                                                        \
     } while (0)
@@ -1231,7 +1235,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     }
 #define SKL_ISSUE(SLOT) do {                                                                                              \
         char* dst__ = ring + (SLOT) * STAGE;                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)pw[j], (lptr_t)(dst__ + j * 1024), 16, 0, 0); pw[j] += WAVES * 64; } \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)pw[j], (lptr_t)(dst__ + j * 1024), 16, 0, TR1_W_AUX); pw[j] += WAVES * 64; } \
         _Pragma("unroll") for (int j = 0; j < 2 * MG; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)px[j], (lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 64; } \
     } while (0)
     f32x4_t acc[NC][MG][2];

@@ -4,12 +4,24 @@
 // HBM-bound: 16 B read (g, p, m, v) + 14 B written (p, m, v, bf16 copy) [+4 B when the gradient is zeroed in place] per parameter.
 #include "tr1_common.h"
 
+// every array is streamed exactly once per step (258 GB for the 7B arena): nt loads/stores keep it from turning over L2 / the memory-side cache
+#ifndef TR1_OPT_NT
+#define TR1_OPT_NT 1
+#endif
+#if TR1_OPT_NT
+#define OPT_LD(ptr) __builtin_nontemporal_load(ptr)
+#define OPT_ST(val, ptr) __builtin_nontemporal_store(val, ptr)
+#else
+#define OPT_LD(ptr) (*(ptr))
+#define OPT_ST(val, ptr) (*(ptr) = (val))
+#endif
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
     __shared__ float red[16];
     float s = 0.f;
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4_t v = reinterpret_cast<const f32x4_t*>(g)[i];
+        const f32x4_t v = OPT_LD(reinterpret_cast<const f32x4_t*>(g) + i);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     if (blockIdx.x == 0) for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
@@ -30,8 +42,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4_t pv = reinterpret_cast<f32x4_t*>(p)[i], mv = reinterpret_cast<f32x4_t*>(m)[i], vv = reinterpret_cast<f32x4_t*>(v)[i];
-        const f32x4_t gv = reinterpret_cast<f32x4_t*>(g)[i];
+        f32x4_t pv = OPT_LD(reinterpret_cast<f32x4_t*>(p) + i), mv = OPT_LD(reinterpret_cast<f32x4_t*>(m) + i), vv = OPT_LD(reinterpret_cast<f32x4_t*>(v) + i);
+        const f32x4_t gv = OPT_LD(reinterpret_cast<f32x4_t*>(g) + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float gg = gv[j] * coef;
@@ -41,10 +53,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
             const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
             pv[j] -= (lr / bc1) * (mv[j] / denom);
         }
-        reinterpret_cast<f32x4_t*>(p)[i] = pv; reinterpret_cast<f32x4_t*>(m)[i] = mv; reinterpret_cast<f32x4_t*>(v)[i] = vv;
-        u32x2_t w = {pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
-        reinterpret_cast<u32x2_t*>(p16)[i] = w;
-        if (zero_grad) reinterpret_cast<f32x4_t*>(g)[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        OPT_ST(pv, reinterpret_cast<f32x4_t*>(p) + i); OPT_ST(mv, reinterpret_cast<f32x4_t*>(m) + i); OPT_ST(vv, reinterpret_cast<f32x4_t*>(v) + i);
+        const u32x2_t w = {pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+        OPT_ST(w, reinterpret_cast<u32x2_t*>(p16) + i);
+        if (zero_grad) OPT_ST(((f32x4_t){0.f, 0.f, 0.f, 0.f}), reinterpret_cast<f32x4_t*>(g) + i);
     }
     if (blockIdx.x == 0) {
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {

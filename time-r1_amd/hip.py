@@ -8,7 +8,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "timer1_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libtimer1_hip.so")
+LIB_PATH = os.environ.get("TR1_HIP_LIB") or os.path.join(_HERE, "lib", "libtimer1_hip.so")   # TR1_HIP_LIB: A/B builds of the same ABI
 
 _CT = {
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel micro-benchmarks on one MI355X (HIP events on the launch stream). Usage: python tools/microbench.py <what> [...]
-   what: skinny | fixup | fused | gemm | attn_decode | attn_train | small | sampler | all"""
+   what: skinny | fixup | fused | gemm | attn_decode | attn_train | small | sampler | optim | all"""
 import os
 import sys
 
@@ -215,6 +215,17 @@ def small():
     print("transpose [5074,18944]    %6.1f us  %6.1f GB/s" % (us, 2 * 5074 * 18944 * 2 / us / 1e3))
 
 
+def optim():
+    n = 2 * 1000 * 1000 * 1000
+    p, m, v, g = (torch.zeros(n, device="cuda") for _ in range(4))
+    p16 = torch.zeros(n, dtype=BF, device="cuda")
+    ss = torch.zeros(1, device="cuda")
+    us = timeit(lambda: ops.sumsq_accum(g, ss), reps=5, warm=1)
+    print("sumsq  n=2e9  %8.1f us  %6.0f GB/s" % (us, 4 * n / us / 1e3))
+    us = timeit(lambda: ops.adamw_step(p, m, v, g, p16, 1e-6, 0.9, 0.999, 1e-8, 0.0, 1, ss, 1.0, 1.0, True), reps=5, warm=1)
+    print("adamw  n=2e9  %8.1f us  %6.0f GB/s (34 B per parameter)" % (us, 34 * n / us / 1e3))
+
+
 def sampler():
     logits = rnd(8, 152064)
     tok = torch.zeros(8, 4, dtype=torch.int32, device="cuda")
@@ -226,5 +237,5 @@ def sampler():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     for w in what:
-        for name in (["skinny", "fixup", "w8", "transpose", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler"] if w == "all" else [w]):
+        for name in (["skinny", "fixup", "w8", "transpose", "fused", "gemm", "attn_decode", "attn_train", "small", "sampler", "optim"] if w == "all" else [w]):
             globals()[name]()
