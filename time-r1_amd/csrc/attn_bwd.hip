@@ -13,10 +13,30 @@
 #include "attn_common.h"
 #include <stdlib.h>
 
+// per 64 packed rows: (max pre, min lo, max hi) over rows with a non-empty [lo,hi].  One wave per tile; runs inside attn_delta_kernel (its
+// first n_qtiles blocks): under a weight-gradient GEMM on the side stream every extra small launch of the main stream waits ~150 us for
+// wave slots, so the 6 us of work used to cost 170 us per layer as a launch of its own.
+TR1_DEV void attn_qmeta_tile(const int* __restrict__ pre, const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta,
+                             int T, int group, int tile, int lane) {
+    const int64_t R = (int64_t)tile * 64 + lane;
+    int mp = 0, ml = 0x7fffffff, mh = -1;
+    if (R < (int64_t)T * group) {
+        const int t = (int)((unsigned)R / (unsigned)group);
+        mp = pre[t];
+        if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { mp = max(mp, __shfl_xor(mp, o, 64)); ml = min(ml, __shfl_xor(ml, o, 64)); mh = max(mh, __shfl_xor(mh, o, 64)); }
+    if (lane == 0) { qmeta[tile * 3 + 0] = mp; qmeta[tile * 3 + 1] = ml; qmeta[tile * 3 + 2] = mh; }
+}
+
 // delta[h][t] = sum_d dO[t,h,d] * O[t,h,d].  16 lanes per (t, h) row, 16 bytes per lane: consecutive rows are consecutive in memory, so a
 // wave instruction reads 4 rows = 1 KiB contiguous (was one thread per row: 64 different lines per load, 72 us for 73 MB at config 3).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, int64_t do_ld, const bf16_t* __restrict__ O, int64_t o_ld,
-                                                         float* __restrict__ delta, int T, int n_heads, int d) {
+                                                         float* __restrict__ delta, int T, int n_heads, int d, const int* __restrict__ pre,
+                                                         const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta, int group,
+                                                         int n_qtiles) {
+    if ((int)blockIdx.x < n_qtiles && threadIdx.x < 64) attn_qmeta_tile(pre, lo, hi, qmeta, T, group, (int)blockIdx.x, (int)threadIdx.x);
     const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
     const bool ok = i < (int64_t)T * n_heads;
@@ -35,21 +55,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 1, 64);
     if (ok && sub == 0) delta[(int64_t)h * T + t] = s;
-}
-
-// per 64 packed rows: (max pre, min lo, max hi) over rows with a non-empty [lo,hi]
-__global__ void attn_qmeta_kernel(const int* __restrict__ pre, const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta,
-                                  int T, int group) {
-    const int64_t R = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    int mp = 0, ml = 0x7fffffff, mh = -1;
-    if (R < (int64_t)T * group) {
-        const int t = (int)((unsigned)R / (unsigned)group);
-        mp = pre[t];
-        if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; }
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { mp = max(mp, __shfl_xor(mp, o, 64)); ml = min(ml, __shfl_xor(ml, o, 64)); mh = max(mh, __shfl_xor(mh, o, 64)); }
-    if (threadIdx.x == 0) { qmeta[blockIdx.x * 3 + 0] = mp; qmeta[blockIdx.x * 3 + 1] = ml; qmeta[blockIdx.x * 3 + 2] = mh; }
 }
 
 // Transposed MFMA operands straight from a ROW-major LDS tile: ds_read_b64_tr_b16.  Every lane supplies its own 8-byte address; inside a 16-lane
@@ -627,10 +632,11 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     TR1_CHECK_ARG(dk_ld % 4 == 0 && dv_ld % 4 == 0, "attention bwd: dk/dv leading dims must be multiples of 4");
     if (T == 0 || n_slots == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T * n_heads + 15) / 16)), dim3(256), 0, s, (const bf16_t*)dO, do_ld,
-                       (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim);
     const int n_qtiles = (int)((T * p.group + 63) / 64);
-    hipLaunchKernelGGL(attn_qmeta_kernel, dim3(n_qtiles), dim3(64), 0, s, p.pre, p.lo, p.hi, (int*)qmeta_ws, (int)T, p.group);
+    const unsigned delta_blocks = (unsigned)((T * n_heads + 15) / 16);          // >= 4 * n_qtiles (n_heads >= group)
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(delta_blocks > (unsigned)n_qtiles ? delta_blocks : (unsigned)n_qtiles), dim3(256), 0, s,
+                       (const bf16_t*)dO, do_ld, (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim, p.pre, p.lo, p.hi,
+                       (int*)qmeta_ws, p.group, n_qtiles);
     int rc = 0;
     switch (d_pad) {
         case 32: rc = launch_bwd<32>(p, s, (float*)ws_f32, ws_floats); break;
