@@ -239,11 +239,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     //  ~nsplit dependent load rounds, 38-80 us against 7.5 us for the separate 56-block combine launch below.)
 }
 
-// Merge split-KV partials. Block = 256 threads = 8 packed rows x 32 lanes; each lane owns D/32 groups of 4 features.
-// The (m, l) statistics of the block's rows are staged in LDS first so the split loop carries no dependent global loads.
+// Merge split-KV partials. Block = 256 threads = 2 packed rows x 4 split groups x 32 lanes; each lane owns 4 features (D <= 128).
+// The merge is a latency chain, not a bandwidth problem (7 MB at 7B): the splits of a row are spread over 4 lane groups and every
+// lane issues all of its (<= 16) partial-row loads up front - clamped address, zero weight beyond nsplit - instead of walking the
+// splits four at a time (7.5 us per layer before).  The (m, l) statistics of the block's rows are staged in LDS first.
+#define ATT_COMBINE_ROWS 2
 template <int D>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t nRpad) {
-    __shared__ float sm_m[8][64], sm_l[8][64];
+    __shared__ float sm_m[ATT_COMBINE_ROWS][64], sm_l[ATT_COMBINE_ROWS][64];
+    __shared__ __attribute__((aligned(16))) f32x4_t part[ATT_COMBINE_ROWS][4][32];
     const int64_t nR = (int64_t)p.T * p.group;
     const int kvh = blockIdx.y % p.n_kv, by = blockIdx.y, nby = gridDim.y;
     {
@@ -251,41 +255,50 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
         p.O += (int64_t)b * p.T * p.o_ld;
         if (p.lse) p.lse += (int64_t)b * p.n_kv * p.group * p.T;
     }
-    const int rl = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const int64_t Rb = (int64_t)blockIdx.x * 8;
-    for (int i = threadIdx.x; i < 8 * p.nsplit; i += 256) {
-        const int r = i / p.nsplit, s = i - r * p.nsplit;
-        const int64_t R = Rb + r;
-        const int64_t slot = ((int64_t)s * nby + by) * nRpad + R;
-        sm_m[r][s] = (R < nR) ? p.mpart[slot] : NEG_INF;
-        sm_l[r][s] = (R < nR) ? p.lpart[slot] : 0.f;
+    const int c = threadIdx.x & 31, sg = (threadIdx.x >> 5) & 3, rl = threadIdx.x >> 7;
+    const int64_t Rb = (int64_t)blockIdx.x * ATT_COMBINE_ROWS;
+    const int64_t R = Rb + rl;
+    const bool act = R < nR;
+    const int64_t Rc = act ? R : nR - 1;
+    const int d = c * 4;
+    // partial rows first (independent of the statistics): splits sg, sg + 4, ...
+    f32x4_t ov[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int sp = sg + 4 * i;
+        ov[i] = *reinterpret_cast<const f32x4_t*>(p.Opart + (((int64_t)(sp < p.nsplit ? sp : 0) * nby + by) * nRpad + Rc) * D + (d < D ? d : 0));
+    }
+    for (int i = threadIdx.x; i < ATT_COMBINE_ROWS * p.nsplit; i += 256) {
+        const int r = i / p.nsplit, sp = i - r * p.nsplit;
+        const int64_t Rr = Rb + r;
+        const int64_t slot = ((int64_t)sp * nby + by) * nRpad + Rr;
+        sm_m[r][sp] = (Rr < nR) ? p.mpart[slot] : NEG_INF;
+        sm_l[r][sp] = (Rr < nR) ? p.lpart[slot] : 0.f;
     }
     __syncthreads();
-    const int64_t R = Rb + rl;
-    if (R >= nR) return;
     float M = NEG_INF;
-    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, sm_m[rl][s]);
+    for (int sp = 0; sp < p.nsplit; ++sp) M = fmaxf(M, sm_m[rl][sp]);
     const float Ms = (M == NEG_INF) ? 0.f : M;
     float L = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) L += exp2f(sm_m[rl][s] - Ms) * sm_l[rl][s];
+    for (int sp = 0; sp < p.nsplit; ++sp) L += exp2f(sm_m[rl][sp] - Ms) * sm_l[rl][sp];
     const float inv = L > 0.f ? 1.f / L : 0.f;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int sp = sg + 4 * i;
+        const float w = sp < p.nsplit ? exp2f(sm_m[rl][sp < 64 ? sp : 0] - Ms) : 0.f;
+        acc += w * ov[i];
+    }
+    part[rl][sg][c] = acc;
+    __syncthreads();
+    if (!act || sg != 0) return;
+    acc = (part[rl][0][c] + part[rl][1][c]) + (part[rl][2][c] + part[rl][3][c]);
     int t, hq;
     att_split_row(p, R, t, hq);
-    bf16_t* orow = p.O + (int64_t)t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real;
-#pragma unroll
-    for (int j = 0; j < (D + 127) / 128; ++j) {
-        const int d = (c + j * 32) * 4;
-        if (d >= D) break;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s = 0; s < p.nsplit; ++s) {
-            const int64_t slot = ((int64_t)s * nby + by) * nRpad + R;
-            acc += exp2f(sm_m[rl][s] - Ms) * *reinterpret_cast<const f32x4_t*>(p.Opart + slot * D + d);
-        }
-        if (d < p.d_real) {
-            u32x2_t w = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
-            *reinterpret_cast<u32x2_t*>(orow + d) = w;
-        }
+    if (d < p.d_real) {
+        bf16_t* orow = p.O + (int64_t)t * p.o_ld + (int64_t)(kvh * p.group + hq) * p.d_real;
+        u32x2_t w = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
+        *reinterpret_cast<u32x2_t*>(orow + d) = w;
     }
     if (c == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
 }
@@ -419,7 +432,7 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
         }
     }
     if (nsplit > 1) {
-        dim3 cg((unsigned)((nR + 7) / 8), (unsigned)(n_kv * n_batch));
+        dim3 cg((unsigned)((nR + ATT_COMBINE_ROWS - 1) / ATT_COMBINE_ROWS), (unsigned)(n_kv * n_batch));
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;
             case 64: hipLaunchKernelGGL(attn_combine_kernel<64>, cg, dim3(256), 0, s, p, nRpad); break;
