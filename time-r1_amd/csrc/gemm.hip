@@ -213,6 +213,89 @@ TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, co
     }
 }
 
+// Epilogue of the phased 8-wave forms THROUGH LDS.  In the accumulator layout a store instruction of store_acc256 writes 64 separate
+// 16-byte pieces (16 rows x 4 pieces at 64-byte stride for fp32): every 128-byte line is visited by 4-8 instructions, and the fp32
+// read-modify-write of a weight gradient ran at 2.3 TB/s (904 against 1297 TFLOP/s for the same shape with bf16 output).  Here each wave
+// parks CH of its 16-row accumulator tiles in its own slice of the (now dead) operand buffers - 256-byte rows, 16-byte chunks XOR-swizzled
+// with the row so both directions are bank-conflict free - and reads them back row-contiguous: an instruction then covers 4 full fp32 rows
+// (8 bf16 rows) of the wave's 64 columns, i.e. only whole lines.  Values and rounding are unchanged.
+#ifndef TR1_EPI_LDS
+#define TR1_EPI_LDS 1
+#endif
+template <bool OUT_F32, bool ACCUM, int RT>
+TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wave_lds, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+                              const bf16_t* __restrict__ residual, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int64_t mrow0, int64_t ncol0,
+                              int lane) {
+    constexpr int CH = (RT % 2 == 0) ? 4 : 3;                             // 16-row tiles per pass: 8 waves x CH x 4 KiB fit the operand buffers
+    const int u = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i0 = 0; i0 < RT; i0 += CH) {
+        const int cnt = RT - i0 < CH ? RT - i0 : CH;
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+            if (ii < cnt) {
+                const int row = ii * 16 + u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(wave_lds + row * 256 + (((g * 4 + j) ^ u) << 4)) = acc[i0 + ii][j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (OUT_F32) {
+            const int c = lane & 15;
+            const int64_t n = ncol0 + c * 4;
+#pragma unroll
+            for (int r4 = 0; r4 < CH * 4; ++r4) {
+                if (r4 < cnt * 4) {
+                    const int rr = r4 * 4 + (lane >> 4);
+                    f32x4_t v = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + ((c ^ (rr & 15)) << 4));
+                    const int64_t m = mrow0 + i0 * 16 + rr;
+                    if (m < M && n + 4 <= N) {
+                        if (bias) { const u32x2_t bv = *reinterpret_cast<const u32x2_t*>(bias + n); v[0] += bflo(bv[0]); v[1] += bfhi(bv[0]); v[2] += bflo(bv[1]); v[3] += bfhi(bv[1]); }
+                        if (residual) {
+                            const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(residual + m * ldr + n);
+                            v[0] += bflo(rv[0]); v[1] += bfhi(rv[0]); v[2] += bflo(rv[1]); v[3] += bfhi(rv[1]);
+                        }
+                        float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
+                        if (ACCUM) v += *reinterpret_cast<const f32x4_t*>(cp);
+                        *reinterpret_cast<f32x4_t*>(cp) = v;
+                    }
+                }
+            }
+        } else {
+            const int c8 = lane & 7;
+            const int64_t n = ncol0 + c8 * 8;
+            u32x4_t bv = {0, 0, 0, 0};
+            if (bias && n + 8 <= N) bv = *reinterpret_cast<const u32x4_t*>(bias + n);
+#pragma unroll
+            for (int r8 = 0; r8 < CH * 2; ++r8) {
+                if (r8 < cnt * 2) {
+                    const int rr = r8 * 8 + (lane >> 3);
+                    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8) ^ (rr & 15)) << 4));
+                    const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8 + 1) ^ (rr & 15)) << 4));
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    const int64_t m = mrow0 + i0 * 16 + rr;
+                    if (m < M && n + 8 <= N) {
+                        if (bias) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(bv[e]); v[2 * e + 1] += bfhi(bv[e]); }
+                        }
+                        if (residual) {
+                            const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
+                        }
+                        u32x4_t o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+                        *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(Cv) + m * ldc + n) = o;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the next pass overwrites the slice
+    }
+}
+
 template <bool IS_B, int ROWS>
 TR1_DEV void stage_tile2(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
                          int wave, int lane) {
@@ -492,7 +575,13 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 #undef COMPUTE
 #undef STAGE_A
 #undef STAGE_B
+#if TR1_EPI_LDS
+    // every wave is past its last LDS read (the realignment barrier above): the operand buffers become 8 private staging slices
+    store_acc256_lds<OUT_F32, ACCUM, RT>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, residual, M, N, ldc, ldr,
+                                         m0 + wm * (RT * 16), n0 + wn * 64, lane);
+#else
     store_acc256<OUT_F32, ACCUM, RT>(acc, Cv, bias, residual, M, N, ldc, ldr, m0 + wm * (RT * 16), n0 + wn * 64, u, g);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
