@@ -251,7 +251,7 @@ def test_attention_decode_over_cache(hip_ops, ref_ops):
     vt_h = hip_ops.pack_transpose(v.cuda(), nkv, nkv, hd)
     vt_r = ref_ops.pack_transpose(v.float(), nkv, nkv, hd)
     o_r, _ = ref_ops.attn_fwd(q.float(), k.float(), vt_r, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5)
-    for nsplit in (1, 4, 16):
+    for nsplit in (1, 4, 16, 57, 64):
         o_h, _ = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, hd ** -0.5, nsplit=nsplit,
                                   need_lse=False)
         close(o_h, o_r, 0.02, what="decode attention nsplit=%d" % nsplit)
@@ -393,7 +393,7 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
         vt_h[:, b * s_cap:(b + 1) * s_cap] = hip_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].cuda(), nkv, nkv, hd)
         vt_r[:, b * s_cap:(b + 1) * s_cap] = ref_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].float(), nkv, nkv, hd)
     o_r, _ = ref_ops.attn_fwd(q.float(), k.float(), vt_r, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, n_batch=B, kv_batch_slots=s_cap)
-    for nsplit in (1, 5, 12):
+    for nsplit in (1, 5, 12, 28):
         o_h, _ = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
                                   need_lse=False, n_batch=B, kv_batch_slots=s_cap)
         close(o_h, o_r, 0.02, what="batched decode attention nsplit=%d" % nsplit)
