@@ -273,6 +273,7 @@ def main():
     device = "cuda:%d" % local
     from time_r1_amd.ops import HipOps
     ops = HipOps(device)
+    ops.use_priority_stream()            # main chain ahead of the weight-gradient side stream in the dispatcher (same call as the trainer)
     wl = Workload(args, ops, device, rank)
     dp = DataParallel()
 

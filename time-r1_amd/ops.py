@@ -3,6 +3,8 @@
 `HipOps` is the product backend. The engine (model.py / rollout.py / grpo.py) is written against this small interface so that
 tests can drive the same host logic with `oracle.ref_ops.RefOps` on CPU - the product never imports oracle/.
 """
+import os
+
 import torch
 
 from . import hip
@@ -33,6 +35,19 @@ class HipOps:
             raise hip.HipError("HipOps needs a HIP device (got %s); there is no CPU fallback" % device)
         self.L = hip.lib()
         self._ws = {}
+
+    def use_priority_stream(self):
+        """Make a HIGH-priority HIP stream the current stream of this process (call once, before any device work).  The backward pass
+        runs its weight gradients on a normal-priority side stream (Engine._side_stream): with both at the same priority every small
+        kernel of the main chain queues behind the pending workgroups of a 1-block-per-CU weight-gradient GEMM (~150 us per launch);
+        with the main chain ahead in the dispatcher's arbitration the 7B backward drops from 171 to 164 ms.  TR1_MAIN_PRIO=0 keeps the
+        default stream (A/B measurements)."""
+        if os.environ.get("TR1_MAIN_PRIO", "1") == "0":
+            return None
+        if getattr(self, "_main_stream", None) is None:
+            self._main_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            torch.cuda.set_stream(self._main_stream)
+        return self._main_stream
 
     # ---- memory helpers -------------------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None):

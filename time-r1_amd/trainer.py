@@ -209,6 +209,7 @@ class TimeR1_Trainer:
         if ops is None:
             from .ops import HipOps   # fails loudly without the HIP library / a GPU: there is no CPU fallback in the product
             ops = HipOps("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+            ops.use_priority_stream()
         self.ops = ops
         # ---- model
         if isinstance(model, str):
