@@ -9,6 +9,8 @@ Reference call sites restated here (transformers/models/qwen2_vl/modeling_qwen2_
   decoder layer  :559-624; attention :501-556; MLP :459-466; final norm :839; lm_head :1323; video scatter :1170-1176
 and the logprob stage of src/time_r1/rl/timer1_trainer.py:449-481.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -26,8 +28,9 @@ class Engine:
         self.overlap_wgrad = True
         # weight gradients that stay on the MAIN stream (d = down, g = gate/up, o, q = qkv); the rest runs on the side stream beside the dgrad
         # chain.  With the dgrad reading the weights as stored (NN form) the main stream has slack: keeping the down projection's weight
-        # gradient there balanced the two streams best on MI355X (backward 175 ms against 180 with everything on the side stream).
-        self.wgrad_on_main = "d"
+        # gradient there balanced the two streams best on MI355X (backward 175 ms against 180 with everything on the side stream; with the main
+        # chain on a high-priority stream: "d" 161, "" 164, "dq" 161, "o" / "dg" 174 ms).  TR1_WGRAD_MAIN overrides for A/B runs.
+        self.wgrad_on_main = os.environ.get("TR1_WGRAD_MAIN", "d")
         self.wgrad_overwrite_first = True    # see _wgrad: relies on the optimizer zeroing the gradient arena and bumping arena.version (AdamWFlat.step)
         self._gw_ver = {}
         self._side = None
