@@ -1,12 +1,17 @@
 #!/usr/bin/env python
 """GRPO throughput benchmark (BASELINE.json metric): video-query samples/s and rollout tokens/s for Qwen2-VL GRPO post-training.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one of the N ranks; started plainly,
+        bench.py re-launches itself under torch.distributed.run with N ranks.  WORLD_SIZE != N is an error, never a silent 1-GPU run.
 
-A "step" is one GRPO micro-step on one synthetic prompt per GPU: vision tower -> G sampled completions (shared-prefix rollout)
--> policy + reference log-probs -> rewards / group advantages -> loss gradient -> backward; the AdamW step (with the RCCL gradient
-average for N > 1) runs every `--ga` steps inside the timed region, exactly like the reference's gradient_accumulation_steps=2
-(scripts/posttrain/train_rl.sh:27).  Inputs (token ids, normalised patches) are resident in HBM before the timed region.
+A "step" is one GRPO micro-step on one synthetic prompt per GPU: uint8 frames -> fused resize / normalise / patchify kernel ->
+vision tower -> G sampled completions (shared-prefix rollout) -> policy + reference log-probs -> rewards / group advantages ->
+loss gradient -> backward; the AdamW step (with the RCCL gradient exchange for N > 1) closes every window of `--ga` steps inside
+the timed region, like the reference's gradient_accumulation_steps=2 (scripts/posttrain/train_rl.sh:27).  ANY --steps / --warmup
+is accepted: K steps are K micro-steps in windows of `ga`, the last window holding the remainder (it still ends in an optimizer
+step), so exactly K steps are timed.  Inputs (token ids, decoded uint8 frames - what the reference's video reader hands over,
+src/utils/vision_process.py:467-472) are resident in HBM before the timed region.
 Weights are random-init of the exact architecture; data is synthetic (no checkpoints / videos exist offline).
 Prints ONE JSON line on rank 0.
 """
@@ -28,12 +33,15 @@ from time_r1_amd.model import Engine  # noqa: E402
 from time_r1_amd.grpo import GRPOCore, eos_mask, group_advantages  # noqa: E402
 from time_r1_amd.synthetic import synthetic_prompt  # noqa: E402
 from time_r1_amd import rewards as R  # noqa: E402
+from time_r1_amd import vision_process as VP  # noqa: E402
 from time_r1_amd.dist import init_from_env, DataParallel  # noqa: E402
 
 # (frames -> video_grid_thw) for a 360x640 source under the reference's pixel budget
 GRIDS = {8: (4, 26, 46), 16: (8, 26, 46), 32: (16, 22, 38), 64: (32, 14, 28)}
-PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA, vendor nominal (MI355X_MICROARCH.md); `peak_measured` is probed on the box beside it
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
+SRC_HW = (360, 640)         # synthetic source resolution
+VIDEO_ELE = {"total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}      # reference timer1_trainer.py:503-509
 
 _PIECES = ["<think>", "</think>", "<answer>", "</answer>", " to ", " and ", "1", "2", "3", "4", "5", "6", "7", "8", "9", "0", ".", " ", "the", "person",
            "because", "\n", "step", "observe", "<timestep>", "</timestep>"]
@@ -44,11 +52,22 @@ def fake_decode(ids_row):
     return "".join(_PIECES[int(i) % len(_PIECES)] for i in ids_row)
 
 
+def window_plan(n_steps, ga):
+    """K micro-steps -> window sizes: full windows of `ga`, then the remainder (every window ends in an optimizer step)."""
+    n_steps, ga = int(n_steps), max(1, int(ga))
+    plan = [ga] * (n_steps // ga)
+    if n_steps % ga:
+        plan.append(n_steps % ga)
+    return plan
+
+
 class Workload:
     def __init__(self, args, ops, device, rank):
         self.cfg = PRESETS[args.model]()
         self.args, self.ops, self.rank = args, ops, rank
-        self.params = ModelParams(self.cfg, ops, init="none")
+        dp = DataParallel()
+        shard = bool(args.shard_optimizer) and dp.enabled      # sharded: master / m / v are allocated as 1/world shards only (AdamWFlat -> Arena.set_shard)
+        self.params = ModelParams(self.cfg, ops, init="none", optimizer_state=not shard)
         if hasattr(self.params, "init_random_device"):
             self.params.init_random_device(seed=0)
         self.eng = Engine(self.cfg, ops, self.params)
@@ -58,25 +77,54 @@ class Workload:
         if args.rollout_fp8:
             self.core.roll.weight_dtype = "fp8"
         from time_r1_amd.optim import AdamWFlat
-        self.opt = AdamWFlat(self.params, ops, lr=1e-6, dp=DataParallel())
-        grid = GRIDS[args.frames] if args.model != "tiny" else (2, 4, 6)
+        self.opt = AdamWFlat(self.params, ops, lr=1e-6, dp=dp, shard_optimizer=shard)
+        tiny = args.model.startswith("tiny")
+        grid = GRIDS[args.frames] if not tiny else (2, 4, 6)
         self.grid = grid
-        self.prompts = []
         v = self.cfg.vision
+        # decoded source frames (uint8, what the reference's video reader returns) and the size plan of the reference's fetch_video_v3
+        n_frames = grid[0] * v.temporal_patch_size
+        src_hw = SRC_HW if not tiny else (72, 96)
+        self.target = VP.video_target_size(VIDEO_ELE, n_frames, *src_hw) if not tiny else (56, 84)
+        assert (self.target[0] // v.patch_size, self.target[1] // v.patch_size) == tuple(grid[1:]), (self.target, grid)
+        self.prompts = []
         for i in range(args.n_prompts):
-            ids, pix, g = synthetic_prompt(self.cfg, grid, 64, 64, seed=100 * rank + i)
-            pp = ops.zeros(pix.shape[0], v.patch_dim_padded)
-            pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)   # staged in HBM before the timed region
-            self.prompts.append((ids, pp, g))
+            ids, _, g = synthetic_prompt(self.cfg, grid, 64, 64, seed=100 * rank + i)
+            gen = torch.Generator().manual_seed(7 + 100 * rank + i)
+            frames = torch.randint(0, 256, (n_frames, 3) + tuple(src_hw), generator=gen, dtype=torch.uint8).to(device)   # staged in HBM before the timed region
+            self.prompts.append((ids, frames, g))
         self.P = len(self.prompts[0][0])
         self.reward_funcs = [R.iou_timestamp_reward_v2, R.format_reward]
         self.micro = 0
         self.ev = []
 
-    def window(self, timing=None):
-        """`ga` micro-steps = one optimizer step. The rollouts of the window are decoded together (weights are constant inside an
-        accumulation window, so this is the reference's sequence of micro-steps with the decode GEMMs amortised over ga*G rows)."""
+    def _finish(self, st, last, mark, n_in_window):
+        """Policy / reference log-probs, host rewards, loss gradient and backward of one prompt."""
         a, core = self.args, self.core
+        core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
+        toks_host = st.completion_ids.cpu().numpy()
+        completions = [fake_decode(r) for r in toks_host]
+        mask = eos_mask(toks_host, self.cfg.eos_token_id)
+        rew = torch.zeros(a.G, len(self.reward_funcs))
+        kw = dict(solution=[(2.0, 12.0)] * a.G, durations=[30.0] * a.G)
+        for j, fn in enumerate(self.reward_funcs):
+            rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
+        _, adv, _ = group_advantages(rew, a.G)
+        mark("logps")
+        sync = None
+        if last and self.opt.dp.enabled and not a.no_grad_overlap:
+            sync = self.opt.sync
+            sync.begin()                # last micro-step of the window: overlap the RCCL gradient exchange with its backward
+        core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / n_in_window, grad_sync=sync)
+        mark("backward")
+        self.micro += 1
+        self.last_tokens += int(mask.sum())
+
+    def window(self, timing=None, n=None):
+        """`n` (default `ga`) micro-steps = one optimizer step. The rollouts of the window are decoded together (weights are constant inside
+        an accumulation window, so this is the reference's sequence of micro-steps with the decode GEMMs amortised over n*G rows)."""
+        a, core, v = self.args, self.core, self.cfg.vision
+        n = a.ga if n is None else n
 
         def mark(name):
             if timing is not None:
@@ -84,39 +132,66 @@ class Workload:
                 e.record()
                 timing.append((name, e))
         mark("start")
-        states = []
-        for j in range(a.ga):
-            ids, pix, grid = self.prompts[(self.micro + j) % len(self.prompts)]
-            states.append(core.prepare(ids, pix, grid))
-        mark("vision")
-        if a.no_rollout_batching:
-            for st in states:
-                core.rollout(st)
-        else:
-            core.rollout_many(states)
-        mark("rollout")
         self.last_tokens = 0
-        for si, st in enumerate(states):
-            core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
-            toks_host = st.completion_ids.cpu().numpy()
-            completions = [fake_decode(r) for r in toks_host]
-            mask = eos_mask(toks_host, self.cfg.eos_token_id)
-            rew = torch.zeros(a.G, len(self.reward_funcs))
-            kw = dict(solution=[(2.0, 12.0)] * a.G, durations=[30.0] * a.G)
-            for j, fn in enumerate(self.reward_funcs):
-                rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
-            _, adv, _ = group_advantages(rew, a.G)
-            mark("logps")
-            sync = None
-            if si == len(states) - 1 and self.opt.dp.enabled and not a.no_grad_overlap:
-                sync = self.opt.sync
-                sync.begin()                # last micro-step of the window: overlap the RCCL gradient exchange with its backward
-            core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga, grad_sync=sync)
-            mark("backward")
-            self.micro += 1
-            self.last_tokens += int(mask.sum())
+
+        def prepare(j):
+            ids, frames, grid = self.prompts[(self.micro + j) % len(self.prompts)]
+            # reference: resize + rescale / normalise + patchify inside compute_loss (timer1_trainer.py:531-556) -> here one fused kernel
+            pix, g = self.ops.video_preprocess(frames, self.target, v.patch_dim_padded, v.patch_size, v.temporal_patch_size, v.spatial_merge_size)
+            assert tuple(g) == tuple(grid[0]), (g, grid)
+            mark("preprocess")
+            st = core.prepare(ids, pix, grid)
+            mark("vision")
+            return st
+        if a.no_rollout_batching:
+            # one prompt at a time: rollout and update of a prompt are interleaved (its saved prefill lives in the single slot-0 buffers)
+            for j in range(n):
+                st = prepare(j)
+                core.rollout(st)
+                mark("rollout")
+                self._finish(st, j == n - 1, mark, n)
+        else:
+            states = [prepare(j) for j in range(n)]
+            core.rollout_many(states)
+            mark("rollout")
+            for si, st in enumerate(states):
+                self._finish(st, si == n - 1, mark, n)
         self.opt.step()
         mark("optimizer")
+
+
+def measure_peaks(ops, device):
+    """On-box probes printed beside the vendor nominals: HBM device-to-device copy rate, and the bf16 GEMM rate of this library's own
+    kernel and of hipBLASLt (torch.matmul) on 8192^3.  Runs before the workload is built; the buffers are freed again."""
+    out = {}
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.zero_(); b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    out["hbm_copy_GBs"] = 2.0 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    M = 8192
+    x = torch.randn(M, M, device=device, dtype=torch.bfloat16) * 0.05
+    w = torch.randn(M, M, device=device, dtype=torch.bfloat16) * 0.05
+    for name, fn in (("gemm_bf16_own_TFLOPs", lambda: ops.gemm_nt(x, w)), ("gemm_bf16_hipblaslt_TFLOPs", lambda: torch.matmul(x, w.t()))):
+        try:
+            fn(); fn()
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            out[name] = 2.0 * M ** 3 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        except Exception as e:          # the probe is informative only
+            out[name] = None
+            out[name + "_error"] = repr(e)[:200]
+    del x, w
+    torch.cuda.empty_cache()
+    return {k: (round(v, 1) if isinstance(v, float) else v) for k, v in out.items()}
 
 
 def instrument_gemms(ops):
@@ -245,7 +320,7 @@ def cpu_baseline(args, budget_note=True):
             "seconds_per_sample_est": est}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -260,13 +335,48 @@ def main():
     ap.add_argument("--n-prompts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-peak-probe", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only)")
-    ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: all-reduce the gradient arena after backward instead of during it")
-    args = ap.parse_args()
+    ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
+    ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
+                    "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json)")
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.ga < 1:
+        ap.error("--gpus/--steps/--ga must be >= 1 and --warmup >= 0")
+    return args
+
+
+def resolve_launch(args, env, device_count):
+    """-> ("run", None) when this process is a rank (or the only process), ("spawn", argv) when it must re-launch itself under
+    torch.distributed.run with one rank per GPU.  Raises SystemExit on any mismatch: a run never silently uses fewer GPUs than --gpus."""
+    world = env.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            raise SystemExit("bench.py: WORLD_SIZE=%s but --gpus %d; launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus))
+        return "run", None
+    if args.gpus == 1:
+        return "run", None
+    if env.get("TR1_FORCE_DEVICE") is None and device_count < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (args.gpus, device_count))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return "spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), os.path.abspath(__file__)]
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    mode, cmd = resolve_launch(args, os.environ, torch.cuda.device_count())
+    if mode == "spawn":
+        import subprocess
+        raise SystemExit(subprocess.call(cmd + list(sys.argv[1:] if argv is None else argv)))
 
     rank, local, world = init_from_env("cuda")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: world size %d != --gpus %d" % (world, args.gpus))
     if os.environ.get("TR1_FORCE_DEVICE") is not None:      # test hook: several ranks on one GPU (gloo backend)
         local = int(os.environ["TR1_FORCE_DEVICE"])
     torch.cuda.set_device(local)
@@ -274,18 +384,19 @@ def main():
     from time_r1_amd.ops import HipOps
     ops = HipOps(device)
     ops.use_priority_stream()            # main chain ahead of the weight-gradient side stream in the dispatcher (same call as the trainer)
+    peaks = measure_peaks(ops, device) if (rank == 0 and not args.no_peak_probe) else None
     wl = Workload(args, ops, device, rank)
     dp = DataParallel()
 
-    assert args.steps % args.ga == 0 and args.warmup % args.ga == 0, "--steps and --warmup must be multiples of --ga (whole optimizer steps)"
-    for _ in range(args.warmup // args.ga):
-        wl.window()
+    for n in window_plan(args.warmup, args.ga):
+        wl.window(n=n)
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     timing = []
     gen_tokens = 0
+    timed_plan = window_plan(args.steps, args.ga)
     t0 = time.perf_counter()
-    for _ in range(args.steps // args.ga):
-        wl.window(timing)
+    for n in timed_plan:
+        wl.window(timing, n=n)
         gen_tokens += wl.last_tokens
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -314,13 +425,16 @@ def main():
             "rollout_tokens_per_sec": (gen_tokens / world / args.steps) / (phases.get("rollout", 1e-9) / 1000.0) * world,
             "generated_tokens_per_sec_end_to_end": gen_tokens / dt,
             "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
+            "optimizer_steps": len(timed_plan), "windows": "%d x %d" % (args.steps // args.ga, args.ga) + (" + 1 x %d" % (args.steps % args.ga) if args.steps % args.ga else ""),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 1e9, 1), "reserved_peak": round(torch.cuda.max_memory_reserved() / 1e9, 1),
                        "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0)), "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))},
             "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
-                                   "loss=%s, grad-accum %d, 1 prompt/GPU/step" % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta,
-                                                                                    "ppo-clip" if args.clip_loss else "grpo", args.ga),
+                                   "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step"
+                                   % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
+                                      wl.prompts[0][1].shape[2], wl.prompts[0][1].shape[3]),
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
-                       "rollout_weight_dtype": "fp8-e4m3 (sampling policy only)" if args.rollout_fp8 else "bf16"},
+                       "rollout_weight_dtype": "fp8-e4m3 (sampling policy only)" if args.rollout_fp8 else "bf16",
+                       "optimizer": "zero-sharded (reduce-scatter / local AdamW / all-gather)" if (args.shard_optimizer and world > 1) else "replicated AdamW + gradient all-reduce"},
         }
     # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step
     if not args.no_roofline:
@@ -353,7 +467,8 @@ def main():
         # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, gfx950 x2 read
         # correction; same workload shapes) - PMC counters cannot be collected inside this un-profiled run
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc_name = [f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             if args.model == "qwen2-vl-7b" and args.G == 8 and args.ga == 2:
                 def fam(*names):      # launch-weighted mean over the kernel families that make up one roofline entry
                     n = sum(pmc[k]["launches"] for k in names if k in pmc)
@@ -362,12 +477,20 @@ def main():
                 hbm["algorithmic_bytes_per_launch"] = sk_by / max(sk_n, 1)
                 mfma["traffic"] = fam("gemm_nt_kernel", "gemm_nt8p_kernel", "gemm_nt256_kernel")
                 mfma["algorithmic_flops_per_launch"] = big_fl / max(big_n, 1)
-                hbm["traffic_source"] = mfma["traffic_source"] = "profiles/r01_pmc_traffic.json"
+                hbm["traffic_source"] = mfma["traffic_source"] = "profiles/" + pmc_name
         except Exception:
             pass
+        if peaks:                 # measured on this box beside the vendor nominal `peak` (frac stays against the nominal)
+            own, lib = peaks.get("gemm_bf16_own_TFLOPs"), peaks.get("gemm_bf16_hipblaslt_TFLOPs")
+            mfma["peak_measured"] = max([x for x in (own, lib) if x] or [0.0]) or None
+            hbm["peak_measured"] = peaks.get("hbm_copy_GBs")
+            for r in (mfma, hbm):
+                r["frac_of_measured"] = (r["achieved"] / r["peak_measured"]) if r.get("peak_measured") else None
         dominant, other = (mfma, hbm) if big_ms >= sk_ms else (hbm, mfma)
         out["roofline"] = dominant
         out["roofline_secondary"] = other
+    if rank == 0 and peaks:
+        out["peak_probe"] = peaks
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -1,0 +1,52 @@
+"""bench.py end to end on the GPU with the tiny model: the driver's argument shape (odd warmup), the self-spawned multi-rank launch
+(2 ranks sharing the one GPU of the test box over gloo - the rendezvous, the world-size check and the max-over-ranks timing are the
+same code the 8-GPU RCCL run uses) and the sharded optimizer flag."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--G", "4", "--C", "8", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_driver_argument_shape_runs_and_reports_contract_fields():
+    out = _run(["--gpus", "1", "--steps", "5", "--warmup", "3"])
+    assert out["metric"] == "grpo_samples_per_sec" and out["unit"] == "samples/s" and out["n_gpus"] == 1
+    assert out["steps"] == 5 and out["warmup"] == 3 and out["optimizer_steps"] == 3 and out["windows"] == "2 x 2 + 1 x 1"
+    assert out["value"] > 0 and abs(out["value"] - 1000.0 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert out["scaling"] == "weak" and out["dtype"] == "bf16" and out["vs_baseline"] is None and "workload" in out["config"]
+    assert {"preprocess", "vision", "rollout", "logps", "backward", "optimizer"} <= set(out["phases_ms_per_step"])
+    for k in ("roofline", "roofline_secondary"):
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "peak_measured"} <= set(out[k])
+    assert out["peak_probe"]["hbm_copy_GBs"] > 500
+
+
+@pytest.mark.parametrize("shard", [False, True])
+def test_self_spawned_two_rank_run(shard):
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-peak-probe"] + (["--shard-optimizer"] if shard else []),
+               env={"TR1_FORCE_DEVICE": "0", "TR1_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["steps"] == 3
+    assert abs(out["value"] - 2 * 1000.0 / out["ms_per_step"]) < 1e-6 * out["value"]       # whole-job aggregate over both ranks
+    assert ("zero-sharded" in out["config"]["optimizer"]) == shard
+
+
+def test_world_size_mismatch_is_an_error():
+    e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--gpus", "2"], capture_output=True, text=True, env=e, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

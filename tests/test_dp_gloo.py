@@ -82,3 +82,100 @@ def test_two_rank_step_equals_single_process_average(wire):
         assert torch.allclose(tr.params.train.master, res[0][1], atol=1e-7, rtol=1e-6)
     else:   # bf16 wire: the summed gradient is rounded to 8 bits of mantissa before AdamW; first-step update = lr * sign-like ratio
         assert torch.allclose(tr.params.train.master, res[0][1], atol=2e-5, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ ZeRO-style sharded optimizer (config 4)
+def _worker_sharded(rank, world, port, q, wire, shard):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import load_case
+    from test_trainer_host_logic import make_trainer
+    from time_r1_amd.dist import ShardSync, GradSync
+    fx = load_case("grpo_beta")
+    cfg, tr = make_trainer(fx, grad_wire_dtype=wire, shard_optimizer=shard)
+    assert isinstance(tr.optimizer.sync, ShardSync if shard else GradSync)
+    a = tr.params.train
+    if shard:
+        assert a.shard == (rank, world) and a.master.numel() == a.numel // world == a.m.numel() == a.v.numel()
+    tr._video_inputs = lambda ex: ([ex["_frames"]], [2.0])
+    tr.args.learning_rate = 1e-3
+    norms = []
+    for step in range(2):                      # two optimizer steps: the second one sees non-zero m / v and freshly zeroed gradients
+        row = _rows(fx)[rank]
+        row["_forced_completion_ids"] = (row["_forced_completion_ids"] + 5 * step) % 480 + 2
+        tr.accumulation_window([[row]])
+        if shard:
+            assert tr.optimizer.sync.active and len(tr.optimizer.sync.pending) >= cfg.text.n_layers, "layer segments must be in flight before step()"
+        norms.append(float(tr.optimizer.step()))
+        assert float(a.grad.abs().max()) == 0.0
+    master_full = torch.zeros(a.numel)
+    if shard:
+        for (ca, cb, la) in a.chunks():
+            master_full[ca:cb] = a.master[la:la + cb - ca]
+        dist.all_reduce(master_full)          # chunks of different ranks are disjoint
+    else:
+        master_full.copy_(a.master)
+    q.put((rank, a.w16.clone(), master_full, norms))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn2(target, *extra):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_sharded_optimizer_equals_replicated_optimizer(wire):
+    """world = 2: reduce-scatter -> AdamW on the local half of every segment -> all-gather must leave every rank with the weights the
+    replicated path (all-reduce -> full AdamW everywhere) produces, after TWO optimizer steps, including the global-norm clip."""
+    sharded = _spawn2(_worker_sharded, wire, True)
+    plain = _spawn2(_worker_sharded, wire, False)
+    assert torch.equal(sharded[0][1], sharded[1][1]), "every rank must hold the same full bf16 weights after the all-gather"
+    assert torch.equal(sharded[0][2], sharded[1][2])
+    assert sharded[0][3] == sharded[1][3] and abs(sharded[0][3][0] - plain[0][3][0]) < 1e-5 * max(1.0, plain[0][3][0])     # same global grad norm
+    tol = dict(atol=1e-7, rtol=1e-6) if wire == "fp32" else dict(atol=2e-5, rtol=1e-3)
+    assert torch.allclose(sharded[0][2], plain[0][2], **tol), float((sharded[0][2] - plain[0][2]).abs().max())
+    assert torch.allclose(sharded[0][1].float(), plain[0][1].float(), atol=1e-2 if wire == "bf16" else 1e-6, rtol=1e-2)
+
+
+def test_arena_segments_split_evenly_for_every_world_size():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.ref_ops import RefOps
+    from time_r1_amd.config import tiny_test, tiny_test_25
+    from time_r1_amd.params import ModelParams, SEG_ALIGN
+    for cfg in (tiny_test(), tiny_test(tie=True), tiny_test_25()):
+        a = ModelParams(cfg, RefOps(), seed=0).train
+        assert a.segments[0][1] == 0 and a.segments[-1][2] == a.numel
+        assert all(s[2] == n[1] for s, n in zip(a.segments, a.segments[1:]))
+        assert all(s[1] % SEG_ALIGN == 0 and s[2] % SEG_ALIGN == 0 for s in a.segments)
+        keys = [s[0] for s in a.segments]
+        assert keys[0] == "embed" and "l0" in keys and "norm" in keys and "merger" in keys and len(set(keys)) == len(keys)
+        for prefix in ["l%d." % i for i in range(cfg.text.n_layers)] + ["norm", "embed", "merger"]:
+            r = a.range_of(prefix)
+            assert r in [(s[1], s[2]) for s in a.segments], (prefix, r)
+        for world in (1, 2, 4, 8):
+            cover = torch.zeros(a.numel, dtype=torch.int32)
+            for r in range(world):
+                loc = 0
+                for ca, cb, la in a.chunks(r, world):
+                    assert la == loc and (cb - ca) % 64 == 0
+                    loc += cb - ca
+                    cover[ca:cb] += 1
+                assert loc == a.numel // world
+            assert bool((cover == 1).all())

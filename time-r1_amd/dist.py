@@ -104,6 +104,73 @@ class GradSync:
         self.active = False
 
 
+class ShardSync:
+    """Sharded-optimizer gradient exchange: per arena SEGMENT (embed | decoder layer | norm | lm_head | merger) a REDUCE-SCATTER that
+    leaves rank r with the sum of chunk r of that segment - the part of the gradient its 1/world shard of master / m / v needs -
+    instead of an all-reduce that would hand every rank everything (reference: DeepSpeed ZeRO reduce_scatter, scripts/zero3.json:22-33).
+    Same begin / ready / finish protocol as GradSync, so the backward's per-layer overlap hook drives either.  After finish() the
+    summed local gradient shard is in `self.gshard` (fp32 [numel / world], chunk order = Arena.chunks()).  On the xGMI full mesh a
+    reduce-scatter moves (world-1)/world of the bytes once over all 7 links in parallel; the matching all-gather of the updated bf16
+    weights is issued by the optimizer (AdamWFlat._step_sharded)."""
+
+    def __init__(self, arena, dp: DataParallel, wire_dtype=torch.bfloat16):
+        self.arena, self.g, self.dp = arena, arena.grad, dp
+        self.wire_dtype = wire_dtype
+        self.stage = None
+        self.recv = None
+        self.gshard = None
+        self.pending, self.done = [], set()
+        self.active = False
+        self._seg_at = {a: (a, b) for _, a, b in arena.segments}
+
+    def begin(self):
+        self.pending, self.done = [], set()
+        self.active = self.dp.enabled
+        if not self.active:
+            return
+        W = self.dp.world
+        if self.gshard is None:
+            self.gshard = torch.empty(self.arena.numel // W, dtype=torch.float32, device=self.g.device)
+        if self.wire_dtype != self.g.dtype and self.stage is None:
+            self.stage = torch.empty(self.g.numel(), dtype=self.wire_dtype, device=self.g.device)
+            self.recv = torch.empty(self.arena.numel // W, dtype=self.wire_dtype, device=self.g.device)
+
+    def ready(self, a, b):
+        """Elements [a, b) of the gradient arena (whole segments) are final on this rank: start their reduce-scatter (asynchronous)."""
+        if not self.active or b <= a:
+            return
+        W = self.dp.world
+        x = a
+        while x < b:
+            assert x in self._seg_at, "sharded gradient exchange works on whole arena segments (offset %d is not a segment start)" % x
+            _, y = self._seg_at[x]
+            assert y <= b, (a, b, x, y)
+            if x not in self.done:
+                self.done.add(x)
+                if self.stage is not None:
+                    src = self.stage[x:y]
+                    src.copy_(self.g[x:y])            # fp32 -> bf16 wire format (staging copy on the compute stream)
+                    dst = self.recv[x // W: y // W]
+                else:
+                    src = self.g[x:y]
+                    dst = self.gshard[x // W: y // W]
+                work = dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, async_op=True)
+                self.pending.append((x // W, y // W, work))
+            x = y
+
+    def finish(self):
+        if not self.active:
+            return
+        for _, a, b in self.arena.segments:        # every segment nobody announced
+            self.ready(a, b)
+        for x, y, work in self.pending:
+            work.wait()
+            if self.stage is not None:
+                self.gshard[x:y].copy_(self.recv[x:y])
+        self.pending, self.done = [], set()
+        self.active = False
+
+
 def init_from_env(device_type="cuda"):
     """torchrun-style env:// rendezvous (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT). Returns (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -3,23 +3,36 @@ data-parallel gradient exchange.  Replaces HF Trainer.training_step's clip + Dee
 (reference: TF trainer.py:1785, scripts/zero3.json:13-21, :35 gradient_clipping auto = max_grad_norm 1.0)."""
 import torch
 
-from .dist import DataParallel, GradSync
+import torch.distributed as dist
+
+from .dist import DataParallel, GradSync, ShardSync
 
 
 class AdamWFlat:
     def __init__(self, params, ops, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, dp: DataParallel = None,
-                 grad_wire_dtype=torch.bfloat16):
+                 grad_wire_dtype=torch.bfloat16, shard_optimizer=False):
         self.params, self.ops = params, ops
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
         self.dp = dp or DataParallel()
-        self.sync = GradSync(params.train.grad, self.dp, wire_dtype=grad_wire_dtype)
+        # ZeRO-style sharding (config "ZeRO-3 + DP=8", reference scripts/zero3.json): master / m / v live on 1/world of every arena segment;
+        # gradients arrive by reduce-scatter, the updated bf16 weights leave by all-gather.  A single process keeps the plain path.
+        self.sharded = bool(shard_optimizer) and self.dp.enabled
+        if self.sharded:
+            if params.train.shard is None:
+                params.train.set_shard(self.dp.rank, self.dp.world)
+            assert params.train.shard == (self.dp.rank, self.dp.world), params.train.shard
+            self.sync = ShardSync(params.train, self.dp, wire_dtype=grad_wire_dtype)
+        else:
+            self.sync = GradSync(params.train.grad, self.dp, wire_dtype=grad_wire_dtype)
         self._sumsq = ops.zeros(1, dtype=torch.float32)
 
     def step(self, lr=None):
         """Averages grads across ranks, clips by global norm, applies AdamW, refreshes the bf16 working weights, zeroes grads.
         Returns the (pre-clip) gradient norm as a device scalar (no host sync)."""
         a = self.params.train
+        if self.sharded:
+            return self._step_sharded(lr)
         if self.dp.enabled and not self.sync.active:
             self.sync.begin()           # nobody overlapped the exchange with backward: reduce everything now
         self.sync.finish()              # grad arena now holds the SUM over ranks; the mean is folded into grad_mult
@@ -32,12 +45,47 @@ class AdamWFlat:
                             self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=True)
         return self._sumsq.sqrt() * mult
 
+    def _step_sharded(self, lr=None):
+        """reduce-scatter (overlapped with the backward through ShardSync.ready, finished here) -> global norm from the local shards (one
+        scalar all-reduce) -> fused AdamW on the local chunk of every segment, writing the new bf16 weights straight into their place in
+        the full working arena -> per-segment in-place all-gather of those bf16 chunks, issued right behind the segment's AdamW launch so
+        the exchange of segment s overlaps the update of segment s+1."""
+        a, ops, W = self.params.train, self.ops, self.dp.world
+        if not self.sync.active:
+            self.sync.begin()
+        self.sync.finish()
+        g = self.sync.gshard
+        mult = 1.0 / W
+        self._sumsq.zero_()
+        ops.sumsq_accum(g, self._sumsq)
+        dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM)
+        self.step_count += 1
+        a.version = getattr(a, "version", 0) + 1
+        works = []
+        for (_, sa, sb), (ca, cb, la) in zip(a.segments, a.chunks()):
+            n = cb - ca
+            ops.adamw_step(a.master[la:la + n], a.m[la:la + n], a.v[la:la + n], g[la:la + n], a.w16[ca:cb], self.lr if lr is None else lr,
+                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm,
+                           grad_mult=mult, zero_grad=False)
+            works.append(dist.all_gather_into_tensor(a.w16[sa:sb], a.w16[ca:cb], async_op=True))
+        a.grad.zero_()                  # the full fp32 accumulator (the fused kernel only sees the reduced shard)
+        for w in works:
+            w.wait()
+        return self._sumsq.sqrt() * mult
+
     def state_dict(self):
         a = self.params.train
-        return dict(step=self.step_count, master=a.master, m=a.m, v=a.v)
+        return dict(step=self.step_count, master=a.master, m=a.m, v=a.v, shard=a.shard)
 
     def load_state_dict(self, sd):
         a = self.params.train
+        if sd.get("shard") != a.shard:
+            raise ValueError("optimizer state was saved with shard %s but this run uses %s (resume with the same world size / --shard-optimizer setting)"
+                             % (sd.get("shard"), a.shard))
         self.step_count = int(sd["step"])
         a.master.copy_(sd["master"]); a.m.copy_(sd["m"]); a.v.copy_(sd["v"])
-        a.w16.copy_(a.master)
+        if a.shard is None:
+            a.w16.copy_(a.master)
+        else:       # every rank restores its chunks; the other ranks' chunks come from the checkpoint's full 16-bit weights (already loaded)
+            for ca, cb, la in a.chunks():
+                a.w16[ca:cb].copy_(a.master[la:la + cb - ca])

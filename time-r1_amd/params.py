@@ -12,6 +12,12 @@ import torch
 from .config import ModelConfig
 
 ALIGN = 64  # elements; keeps every view 128-byte aligned in bf16
+SEG_ALIGN = 8 * ALIGN  # a SEGMENT (embed | one decoder layer | norm | lm_head | merger) starts on a multiple of this, so for world sizes 1/2/4/8
+#                        it splits into `world` equal, 128-byte aligned chunks: the unit of the sharded optimizer's reduce-scatter / all-gather
+
+
+def _segment_key(name):
+    return name.split(".")[0]
 
 
 def _specs_llm(cfg: ModelConfig):
@@ -62,11 +68,23 @@ class Arena:
         self.ops = ops
         self.specs = specs
         self.offsets = {}
+        self.segments = []               # [(key, start, end)] contiguous, covering [0, numel); every boundary is a multiple of SEG_ALIGN
         off = 0
         for name, shape in specs:
+            key = _segment_key(name)
+            if not self.segments or self.segments[-1][0] != key:
+                off = (off + SEG_ALIGN - 1) // SEG_ALIGN * SEG_ALIGN
+                if self.segments:
+                    self.segments[-1][2] = off
+                self.segments.append([key, off, off])
             self.offsets[name] = (off, shape)
             off += (int(math.prod(shape)) + ALIGN - 1) // ALIGN * ALIGN
+        off = (off + SEG_ALIGN - 1) // SEG_ALIGN * SEG_ALIGN
+        if self.segments:
+            self.segments[-1][2] = off
+        self.segments = [tuple(s) for s in self.segments]
         self.numel = off
+        self.shard = None                # (rank, world) once the optimizer state is sharded (set_shard)
         self.version = 0                 # bumped whenever the weights change (optimizer step, loaders): invalidates derived copies (Engine W^T cache)
         self.w16 = ops.zeros(off, dtype=ops.act_dtype)
         self.grad = self.master = self.m = self.v = None
@@ -105,12 +123,44 @@ class Arena:
 
     def sync_master_from_w16(self):
         if self.master is not None:
-            self.master.copy_(self.w16)
+            self.master.copy_(self.local_of(self.w16) if self.shard else self.w16)
+
+    # ---- ZeRO-style optimizer-state sharding (reference scripts/zero3.json:22-33 shards optimizer state, gradients and parameters over the
+    # data-parallel ranks; here 288 GB of HBM keep the bf16 weights and the fp32 gradient accumulator whole and only master / m / v - 12 of
+    # the 18 bytes per parameter - are split): rank r owns the r-th of `world` equal chunks of EVERY segment, stored back to back.
+    def chunks(self, rank=None, world=None):
+        """[(global_start, global_end, local_start)] of the chunks `rank` owns (default: this arena's shard)."""
+        r, w = self.shard if rank is None else (rank, world)
+        out = []
+        for _, a, b in self.segments:
+            c = (b - a) // w
+            out.append((a + r * c, a + (r + 1) * c, a // w))
+        return out
+
+    def local_of(self, flat):
+        """The local shard (1/world of the arena) of a full flat tensor, as one contiguous tensor."""
+        return torch.cat([flat[a:b] for a, b, _ in self.chunks()])
+
+    def set_shard(self, rank, world):
+        """Keep only this rank's 1/world of master / m / v.  Existing state is sliced; a weights-only arena gets master = fp32(w16), m = v = 0."""
+        assert self.shard is None and SEG_ALIGN % (world * ALIGN) == 0, (self.shard, world)
+        self.shard = (rank, world)
+        n = self.numel // world
+        for name in ("master", "m", "v"):
+            full = getattr(self, name)
+            if full is not None:
+                setattr(self, name, self.local_of(full).clone())
+            elif name == "master":
+                self.master = self.ops.zeros(n, dtype=torch.float32)
+                self.master.copy_(self.local_of(self.w16))
+            else:
+                setattr(self, name, self.ops.zeros(n, dtype=torch.float32))
+            del full
 
     def clone_weights_only(self):
         """bf16-only snapshot (the frozen reference policy, reference timer1_trainer.py:295-307)."""
         a = Arena.__new__(Arena)
-        a.ops, a.specs, a.offsets, a.numel = self.ops, self.specs, self.offsets, self.numel
+        a.ops, a.specs, a.offsets, a.numel, a.segments, a.shard = self.ops, self.specs, self.offsets, self.numel, self.segments, None
         a.w16 = self.w16.clone()
         a.grad = a.master = a.m = a.v = None
         return a

@@ -77,7 +77,9 @@ class GRPOConfig:
     fix_vit: bool = True
     stop_at_eos: bool = False               # the reference's GenerationConfig carries no eos_token_id (a6): always C tokens
     rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
-    grad_wire_dtype: str = "bf16"           # data-parallel gradient all-reduce wire format ("bf16" | "fp32")
+    grad_wire_dtype: str = "bf16"           # data-parallel gradient exchange wire format ("bf16" | "fp32")
+    shard_optimizer: Optional[bool] = None  # ZeRO-style: master/m/v on 1/world of every arena segment, reduce-scatter grads, all-gather bf16 weights.
+                                            # None = follow `deepspeed` (a zero2 / zero3 json, as in every reference script) ; no effect on one GPU
     gpu_video_preprocess: bool = False      # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path
     rollout_weight_dtype: str = "bf16"      # "fp8": the SAMPLING policy reads e4m3 copies of the decoder matrices (row scales, re-quantised every window);
                                             # log-probs, KL and the update keep bf16 weights (BASELINE config "fp8 weights")
@@ -238,10 +240,8 @@ class TimeR1_Trainer:
                 processing_class.image_processor.max_pixels = max_pixels     # reference :317-319
                 processing_class.image_processor.min_pixels = min_pixels
         self.processing_class = processing_class
-        pad = getattr(processing_class, "pad_token_id", None)
-        if pad is None and hasattr(processing_class, "tokenizer"):
-            pad = processing_class.tokenizer.pad_token_id
-            processing_class.pad_token_id = pad
+        if hasattr(processing_class, "tokenizer"):                       # reference :321-323 sets both unconditionally
+            processing_class.pad_token_id = processing_class.tokenizer.pad_token_id
             processing_class.eos_token_id = processing_class.tokenizer.eos_token_id
         # ---- rewards / metrics
         if not isinstance(reward_funcs, list):
@@ -273,13 +273,22 @@ class TimeR1_Trainer:
             raise NotImplementedError("custom torch optimizers are not supported; the engine owns a fused AdamW over its flat arena")
         self.optimizer = AdamWFlat(self.params, ops, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
                                    weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, dp=self.dp,
-                                   grad_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_dtype", "bf16") == "bf16" else torch.float32)
+                                   grad_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_dtype", "bf16") == "bf16" else torch.float32,
+                                   shard_optimizer=self._wants_shard(args))
         self._metrics = defaultdict(list)
         self.state = TrainerState()
         self.state.is_world_process_zero = self.dp.rank == 0
         self.control = TrainerControl()
         self.is_deepspeed_enabled = False
         self._micro = 0
+
+    @staticmethod
+    def _wants_shard(args):
+        so = getattr(args, "shard_optimizer", None)
+        if so is not None:
+            return bool(so)
+        ds = getattr(args, "deepspeed", None)       # reference scripts: --deepspeed scripts/zero3.json | zero3_offload.json | zero2.json
+        return isinstance(ds, str) and "zero" in os.path.basename(ds).lower()
 
     # ------------------------------------------------------------------------------------------------------ prompt building
     def make_conversation_video(self, example):
@@ -416,19 +425,29 @@ class TimeR1_Trainer:
     def accumulation_window(self, batches):
         """All micro-steps of one optimizer step. With rollout_batching the G x len(batches) completions are decoded together
         (weights do not change inside the window, so this equals the reference's sequential micro-steps). Returns the losses."""
+        if not getattr(self.args, "rollout_batching", True):
+            # one prompt at a time, rollout and update interleaved: a sequential rollout keeps its saved prefill (prompt activations, K/V)
+            # in the single slot-0 buffers, which the NEXT prompt's prefill overwrites - so each prompt is finished before the next starts
+            losses = []
+            for i, b in enumerate(batches):
+                c = self._step_prepare(b)
+                if c["forced"] is None:
+                    self.core.rollout(c["st"])
+                losses.append(self._step_finish(c, last_in_window=(i == len(batches) - 1)))
+            return losses
         ctxs = [self._step_prepare(b) for b in batches]
         todo = [c["st"] for c in ctxs if c["forced"] is None]
-        if todo:
-            if getattr(self.args, "rollout_batching", True) and len(todo) > 1:
-                self.core.rollout_many(todo)
-            else:
-                for st in todo:
-                    self.core.rollout(st)
+        if len(todo) > 1:
+            self.core.rollout_many(todo)
+        elif todo:
+            self.core.rollout(todo[0])
         return [self._step_finish(c, last_in_window=(i == len(ctxs) - 1)) for i, c in enumerate(ctxs)]
 
     # ------------------------------------------------------------------------------------------------------ training loop
     def get_train_dataloader(self):
-        """Batches of `per_device_train_batch_size` dataset rows (identity collation), sharded rank-wise: perm(seed)[rank::world]."""
+        """Batches of `per_device_train_batch_size` dataset rows (identity collation), sharded rank-wise: perm(seed)[rank::world], the
+        permutation wrapped to a multiple of `world` first (torch DistributedSampler / accelerate even_batches semantics), so every rank
+        sees the SAME number of batches - ranks with different step counts would dead-lock in the gradient exchange."""
         n = len(self.train_dataset)
         bs = self.args.per_device_train_batch_size
         seed = self.args.data_seed if self.args.data_seed is not None else self.args.seed
@@ -436,17 +455,29 @@ class TimeR1_Trainer:
 
         class _Loader:
             def __init__(self):
-                self.epoch = 0
                 self.gen = torch.Generator().manual_seed(seed)
+                self.skip_next = 0            # batches the NEXT iteration leaves out at its start (mid-epoch resume), without loading their rows
+
+            def per_rank(self):
+                return (n + trainer.dp.world - 1) // trainer.dp.world
 
             def __len__(self):
-                per_rank = len(range(trainer.dp.rank, n, trainer.dp.world))
-                return per_rank // bs
+                return self.per_rank() // bs
+
+            def skip_epochs(self, k):
+                """Advance the sampler past k fully consumed epochs (resume) without touching the dataset."""
+                for _ in range(k):
+                    torch.randperm(n, generator=self.gen)
 
             def __iter__(self):
                 perm = torch.randperm(n, generator=self.gen).tolist()
-                mine = perm[trainer.dp.rank::trainer.dp.world]
-                for i in range(0, len(mine) - bs + 1, bs):
+                world = trainer.dp.world
+                total = self.per_rank() * world
+                while len(perm) < total:                  # wrap-around padding, like DistributedSampler(drop_last=False)
+                    perm += perm[: total - len(perm)]
+                mine = perm[trainer.dp.rank::world]
+                first, self.skip_next = self.skip_next * bs, 0
+                for i in range(first, len(mine) - bs + 1, bs):
                     yield [trainer.train_dataset[j] for j in mine[i:i + bs]]
         return _Loader()
 
@@ -468,6 +499,8 @@ class TimeR1_Trainer:
         import collections
         import itertools
         depth = int(getattr(self.args, "dataloader_prefetch", 0) or 0)
+        if skip and hasattr(loader, "skip_next"):
+            loader.skip_next, skip = skip, 0
         it = itertools.islice(iter(loader), skip, None)
         if depth <= 0:
             yield from it
@@ -498,32 +531,34 @@ class TimeR1_Trainer:
         return self.compute_loss(self.params, inputs)
 
     def train(self, resume_from_checkpoint=None):
+        """The loop that replaces transformers.Trainer.train for main.py:589-625: accumulation windows of `gradient_accumulation_steps`
+        micro-steps, optimizer step + LR schedule, callbacks, checkpoints, and HF's resume arithmetic: a checkpoint at global step s
+        restarts in epoch s // steps_per_epoch after skipping the (s % steps_per_epoch) * GA batches that epoch already consumed; the
+        run ends at state.max_steps (main.py sets max_steps = global_step + epochs * steps_per_epoch before resuming, :600-618)."""
         a = self.args
         loader = self.get_train_dataloader()
         ga = max(1, a.gradient_accumulation_steps)
         steps_per_epoch = max(len(loader) // ga, 1)
         if self.state.max_steps <= 0:
             self.state.max_steps = a.max_steps if a.max_steps > 0 else math.ceil(a.num_train_epochs * steps_per_epoch)
-        n_epochs = math.ceil(a.num_train_epochs) if a.max_steps <= 0 else math.ceil(self.state.max_steps / steps_per_epoch)
+        n_epochs = math.ceil(self.state.max_steps / steps_per_epoch)
         self.state.num_train_epochs = n_epochs
         start_step = 0
         ckpt = resume_from_checkpoint if resume_from_checkpoint is not None else a.resume_from_checkpoint
         if ckpt:
             start_step = self._load_checkpoint(ckpt)
+        epoch = start_step // steps_per_epoch                  # fully trained epochs: the sampler is advanced, nothing is replayed
+        loader.skip_epochs(epoch)
+        skip_batches = (start_step % steps_per_epoch) * ga      # consumed part of the current epoch (skipped before any prefetch work)
+        self.state.epoch = self.state.global_step / steps_per_epoch
         for cb in self.callbacks:
             _call(cb, "on_train_begin", a, self.state, self.control)
         t_start = time.time()
         tr_loss, n_loss = 0.0, 0
-        skip_micro = start_step * ga
-        micro_seen = 0
         self.control.should_training_stop = False
-        epoch = 0
-        while not self.control.should_training_stop and self.state.global_step < self.state.max_steps:
+        while not self.control.should_training_stop and self.state.global_step < self.state.max_steps and epoch < n_epochs:
             window = []
-            to_skip = max(0, skip_micro - micro_seen)      # resume: replay the sampler, skip consumed batches (before any prefetch work)
-            micro_seen += min(to_skip, len(loader))
-            for batch in self._prefetching(loader, to_skip):
-                micro_seen += 1
+            for batch in self._prefetching(loader, skip_batches):
                 window.append(batch)
                 if len(window) < ga:
                     continue
@@ -534,24 +569,26 @@ class TimeR1_Trainer:
                 window = []
                 gnorm = self.optimizer.step(lr=self._lr(self.state.global_step))
                 self.state.global_step += 1
-                self.state.epoch = epoch + (micro_seen // ga % steps_per_epoch) / steps_per_epoch
+                self.state.epoch = self.state.global_step / steps_per_epoch
                 for cb in self.callbacks:
                     _call(cb, "on_step_end", a, self.state, self.control)
                 if a.logging_steps and self.state.global_step % a.logging_steps == 0:
-                    self.log({"loss": round(tr_loss / max(n_loss, 1) / ga, 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
+                    # HF logs the mean of the micro-step losses since the last log (training_step returns loss / GA, summed over GA micro-steps)
+                    self.log({"loss": round(tr_loss / max(n_loss, 1), 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
                     tr_loss, n_loss = 0.0, 0
                 if a.save_strategy == "steps" and a.save_steps and self.state.global_step % a.save_steps == 0:
                     self._save_checkpoint()
                 if self.state.global_step >= self.state.max_steps or self.control.should_training_stop:
                     break
+            skip_batches = 0
+            if self.state.global_step < (epoch + 1) * steps_per_epoch:
+                break                      # stopped inside the epoch (max_steps / callback): no epoch-end event
             epoch += 1
             self.state.epoch = float(epoch)
             for cb in self.callbacks:
                 _call(cb, "on_epoch_end", a, self.state, self.control)
             if a.save_strategy == "epoch":
                 self._save_checkpoint()
-            if epoch >= n_epochs:
-                break
         for cb in self.callbacks:
             _call(cb, "on_train_end", a, self.state, self.control)
         return types.SimpleNamespace(global_step=self.state.global_step, training_loss=tr_loss / max(n_loss, 1), metrics={"train_runtime": time.time() - t_start})
@@ -580,6 +617,12 @@ class TimeR1_Trainer:
         json.dump(dataclasses.asdict(self.cfg), open(os.path.join(output_dir, "timer1_model_config.json"), "w"), indent=1)
         from .config import to_hf_config
         json.dump(to_hf_config(self.cfg), open(os.path.join(output_dir, "config.json"), "w"), indent=1)   # reference: save_pretrained via Trainer
+        # HF Trainer._save also writes the processor / tokenizer, so `--model_name_or_path <output_dir>/checkpoint-N` reloads (train_rl_SF.sh, eval)
+        sp = getattr(self.processing_class, "save_pretrained", None)
+        if sp is not None:
+            sp(output_dir)
+        json.dump({"eos_token_id": self.cfg.eos_token_id, "pad_token_id": self.cfg.pad_token_id, "do_sample": True,
+                   "temperature": float(getattr(self.args, "temperature", 1.0))}, open(os.path.join(output_dir, "generation_config.json"), "w"), indent=1)
 
     def _save_checkpoint(self):
         d = os.path.join(self.args.output_dir, "checkpoint-%d" % self.state.global_step)
@@ -606,11 +649,12 @@ class TimeR1_Trainer:
         st = json.load(open(os.path.join(d, "trainer_state.json")))
         self.state.global_step = int(st["global_step"])
         self.state.log_history = st.get("log_history", [])
+        self.state.epoch = float(st.get("epoch") or 0.0)
         opt = os.path.join(d, "optimizer_rank%d.pt" % self.dp.rank)
         if os.path.exists(opt):
             sd = torch.load(opt, weights_only=False)
             self.params.train.version += 1
-            self.optimizer.load_state_dict({k: (v.to(self.ops.device) if torch.is_tensor(v) else v) for k, v in sd.items() if k in ("step", "master", "m", "v")})
+            self.optimizer.load_state_dict({k: (v.to(self.ops.device) if torch.is_tensor(v) else v) for k, v in sd.items() if k in ("step", "master", "m", "v", "shard")})
             self.core.roll.calls = sd.get("rollout_calls", 0)
             self._micro = sd.get("micro", 0)
             if self.ref_model is not None and "ref_w16" in sd:
