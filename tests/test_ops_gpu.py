@@ -415,6 +415,20 @@ def test_video_preprocess_fused(hip_ops, ref_ops, T, H, W, Ho, Wo):
     assert float((err > 0.009).float().mean()) < 1e-3
 
 
+def test_video_preprocess_matches_hf_processor_golden(hip_ops):
+    """The fused HIP preprocessing kernel (target size == source size: the resize taps collapse to identity) against pixel_values_videos
+    captured from transformers' Qwen2VLVideoProcessor (tests/golden/patchify_hf.pt): layout, odd-frame padding, constants; bf16 output."""
+    import os
+    fx = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patchify_hf.pt"), weights_only=False)
+    for c in fx["cases"]:
+        frames = torch.randint(0, 256, tuple(c["shape"]), generator=torch.Generator().manual_seed(c["seed"]), dtype=torch.uint8)
+        out, grid = hip_ops.video_preprocess(frames.cuda(), tuple(c["shape"][2:]), 1216)
+        assert list(grid) == list(c["video_grid_thw"])
+        a, want = out.float().cpu(), c["pixel_values_videos"]
+        assert a.shape == (want.shape[0], 1216) and float(a[:, 1176:].abs().max()) == 0.0
+        assert float((a[:, :1176] - want).abs().max()) <= 0.008 + 1e-5, float((a[:, :1176] - want).abs().max())      # bf16 rounding of |x| < 2.3
+
+
 @pytest.mark.parametrize("M,N,K,glu", [(8, 512, 256, False), (16, 4608, 3584, False), (16, 100032, 256, False), (32, 100096, 320, False), (5, 72, 320, False), (16, 1024, 3584, True), (13, 200, 512, True),
                                        (32, 4608, 3584, False), (24, 1024, 1536, True), (64, 512, 3584, False), (40, 136, 832, True),
                                        # LDS-streamed GLU kernel (M <= 16, K = 3584 / 1536): full gate/up width, fewer pairs than CUs, ragged row counts

@@ -71,22 +71,33 @@ def test_patchify_layout():
                         n += 1
 
 
-def test_patchify_matches_hf_video_processor():
-    """Cross-check against transformers' Qwen2VLVideoProcessor when it is importable with torch-only deps."""
-    try:
-        from transformers.models.qwen2_vl.video_processing_qwen2_vl import Qwen2VLVideoProcessor
-        proc = Qwen2VLVideoProcessor(do_resize=False, do_sample_frames=False)
-    except Exception as e:  # torchvision-less builds cannot construct it
-        pytest.skip("HF video processor unavailable: %r" % (e,))
-    g = torch.Generator().manual_seed(0)
-    frames = torch.randint(0, 256, (4, 3, 56, 84), generator=g, dtype=torch.uint8)
-    try:
-        out = proc(videos=[frames], return_tensors="pt")
-    except Exception as e:
-        pytest.skip("HF video processor call failed offline: %r" % (e,))
-    pv, grid = VP.patchify(frames.float())
-    assert tuple(out["video_grid_thw"][0].tolist()) == grid
-    assert torch.allclose(out["pixel_values_videos"].float(), pv, atol=1e-5)
+def _hf_patchify_cases():
+    fx = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patchify_hf.pt"), weights_only=False)
+    for c in fx["cases"]:
+        frames = torch.randint(0, 256, tuple(c["shape"]), generator=torch.Generator().manual_seed(c["seed"]), dtype=torch.uint8)
+        yield frames, c["pixel_values_videos"], tuple(c["video_grid_thw"])
+
+
+def test_patchify_matches_hf_video_processor_golden():
+    """VP.patchify == transformers' Qwen2VLVideoProcessor (fixture captured by tests/golden/gen_patchify_golden.py from the unmodified HF
+    class: layout, temporal padding of odd frame counts, fused rescale/normalise constants).  Reference call: timer1_trainer.py:547-556."""
+    n = 0
+    for frames, want, grid in _hf_patchify_cases():
+        pv, g = VP.patchify(frames.float())
+        assert g == grid and pv.shape == want.shape
+        assert torch.allclose(pv, want, atol=2e-6, rtol=0), float((pv - want).abs().max())
+        n += 1
+    assert n == 4
+
+
+def test_oracle_video_preprocess_matches_hf_golden(ref_ops):
+    """The oracle of the fused GPU preprocessing kernel (uint8 frames, no resize needed: target == source size) reproduces the HF patches."""
+    for frames, want, grid in _hf_patchify_cases():
+        T, _, H, W = frames.shape
+        out, g = ref_ops.video_preprocess(frames, (H, W), 1216)
+        assert tuple(g) == grid
+        assert torch.allclose(out[:, :1176].float(), want, atol=2e-6), float((out[:, :1176].float() - want).abs().max())
+        assert float(out[:, 1176:].abs().max()) == 0.0
 
 
 def test_process_vision_info_predecoded():

@@ -147,6 +147,18 @@ def _call(cb, name, *a, **k):
         return r
 
 
+def clip_ratio_metrics(logp, old_logp, advantages, mask, eps_low=0.2, eps_high=0.2):
+    """Fractions of completion tokens whose probability ratio exp(logp - old_logp) left the PPO clip range on the side that matters for
+    the sign of the advantage: (low, high, either), each sum(flag * mask) / sum(mask) (reference timer1_trainer_ft.py:820-829)."""
+    coef = torch.exp(logp - old_logp)
+    adv = advantages.reshape(-1, 1)
+    m = mask.to(coef.dtype)
+    is_low = (coef < 1 - eps_low) & (adv < 0)
+    is_high = (coef > 1 + eps_high) & (adv > 0)
+    tot = m.sum()
+    return (is_low * m).sum() / tot, (is_high * m).sum() / tot, ((is_low | is_high) * m).sum() / tot
+
+
 def load_model_dir(path, ops):
     """HF checkpoint directory (config.json + *.safetensors) -> (ModelConfig, ModelParams)."""
     from safetensors.torch import load_file
@@ -415,9 +427,15 @@ class TimeR1_Trainer:
             for fn in self.metric_funcs:
                 vals = torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
                 self._metrics["metrics/%s" % fn.__name__].append(gather(vals.to(dev)).mean().item())
-            if not self.use_grpo:   # on-policy: ratio == 1, so no token is clipped (reference :820-842; undefined there for use_grpo)
-                for k in ("low_mean", "low_min", "high_mean", "high_max", "region_mean"):
-                    self._metrics["clip_ratio/" + k].append(0.0)
+            if not self.use_grpo:   # reference timer1_trainer_ft.py:820-842 (undefined there for use_grpo: coef_1 does not exist)
+                lp = st.logp.float().cpu()
+                low, high, region = clip_ratio_metrics(lp, lp, advantages, mask_t, self.epsilon_low, self.epsilon_high)   # old policy == policy (one update per rollout)
+                g_low, g_high, g_reg = gather(low.reshape(1).to(dev)), gather(high.reshape(1).to(dev)), gather(region.reshape(1).to(dev))
+                self._metrics["clip_ratio/low_mean"].append(g_low.nanmean().item())
+                self._metrics["clip_ratio/low_min"].append(g_low[~g_low.isnan()].min().item() if (~g_low.isnan()).any() else float("nan"))
+                self._metrics["clip_ratio/high_mean"].append(g_high.nanmean().item())
+                self._metrics["clip_ratio/high_max"].append(g_high[~g_high.isnan()].max().item() if (~g_high.isnan()).any() else float("nan"))
+                self._metrics["clip_ratio/region_mean"].append(g_reg.nanmean().item())
         self.last_completions = completions
         self.last_rewards = rewards
         return out3_h[0]
