@@ -51,7 +51,21 @@ def test_metrics():
     assert E.compute_iou((3.0, 9.0), (2.0, 12.0)) == 0.6
     assert E.compute_iou(None, (0, 1)) == 0.0
     m = E.grounding_metrics([0.2, 0.4, 0.6, 0.8])
-    assert m == {"mIoU": 50.0, "R1@0.3": 75.0, "R1@0.5": 50.0, "R1@0.7": 25.0}
+    assert m == {"mIoU": 50.0, "R1@0.3": 75.0, "R1@0.5": 50.0, "R1@0.7": 25.0, "avg": 50.0}
+
+
+def test_eval_helpers_match_reference_kat():
+    """extract_answer / compute_IoU / calc_score outputs captured from the reference (tests/golden/gen_eval_kat.py): bit-exact."""
+    import json
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_kat.json")))
+    for r in k["rows"]:
+        p = E.extract_answer_span(r["output"])
+        assert p == (None if None in r["pred"] else tuple(r["pred"])), r["output"]
+        for gt, want in zip(k["gts"], r["ious"]):
+            assert repr(float(E.compute_iou(p, gt))) == want, (r["output"], gt)
+    for s in k["scores"]:
+        m = E.grounding_metrics(s["ious"])
+        assert {"mIoU": repr(m["mIoU"]), "0.3": repr(m["R1@0.3"]), "0.5": repr(m["R1@0.5"]), "0.7": repr(m["R1@0.7"]), "avg": repr(m["avg"])} == s["scores"]
 
 
 def test_cli_parses_reference_style_flags(monkeypatch):
@@ -79,5 +93,5 @@ def test_in_engine_greedy_evaluation_runs_on_cpu_oracle_ops():
     tr._video_inputs = lambda ex: ([ex["video_frames"]], [2.0])
     m1, rec1 = E.evaluate_grounding(tr, D.RowDataset(rows), max_new_tokens=6)
     m2, rec2 = E.evaluate_grounding(tr, D.RowDataset(rows), max_new_tokens=6)
-    assert set(m1) == {"mIoU", "R1@0.3", "R1@0.5", "R1@0.7"} and len(rec1) == 2
+    assert set(m1) == {"mIoU", "R1@0.3", "R1@0.5", "R1@0.7", "avg"} and len(rec1) == 2
     assert [r["completion"] for r in rec1] == [r["completion"] for r in rec2], "greedy decoding is deterministic"

@@ -122,3 +122,22 @@ def test_deepspeed_zero_json_selects_the_sharded_optimizer():
     assert TimeR1_Trainer._wants_shard(GRPOConfig(deepspeed="scripts/zero3_offload.json"))
     assert not TimeR1_Trainer._wants_shard(GRPOConfig())
     assert not TimeR1_Trainer._wants_shard(GRPOConfig(deepspeed="scripts/zero3.json", shard_optimizer=False))
+
+
+def test_row_chunked_lm_head_equals_whole_head(monkeypatch):
+    """Config 4 (G*C = 16384 prediction rows) never holds [G*C, V] logits: the head runs in row chunks and the backward recomputes each
+    chunk's logits.  Same loss / metrics / gradients as the single-piece head."""
+    from helpers import frames_for
+    from time_r1_amd.model import Engine
+    fx = load_case("clip_beta")
+    out = []
+    for ch in (4096, 7):
+        monkeypatch.setattr(Engine, "HEAD_CHUNK_ROWS", ch)
+        cfg, tr = make_trainer(fx)
+        row = dict(fx["row"])
+        row["_forced_completion_ids"] = fx["completion_ids"].numpy()
+        tr._video_inputs = lambda ex: ([frames_for(fx)], [2.0])
+        loss = tr.compute_loss(tr.model, [row])
+        out.append((float(loss), dict(tr._metrics), tr.params.train.grad.clone()))
+    assert abs(out[0][0] - out[1][0]) < 1e-7 and out[0][1].keys() == out[1][1].keys()
+    assert torch.allclose(out[0][2], out[1][2], atol=1e-6), float((out[0][2] - out[1][2]).abs().max())

@@ -5,13 +5,18 @@ import re
 import numpy as np
 
 
+_SPAN = re.compile(r"(\d+\.?\d*) (to|and) (\d+\.?\d*)")
+
+
 def extract_answer_span(text):
-    """Last '<a> to <b>' (or 'and') pair inside <answer>..</answer>; falls back to the whole text when there are no tags."""
-    m = re.findall(r"<answer>(.*?)</answer>", text, re.DOTALL)
-    body = m[-1] if m else text
-    s = re.findall(r"(\d+\.?\d*) (to|and) (\d+\.?\d*)", body, re.IGNORECASE)
+    """The reference's `extract_answer(..., "tg")` (evaluate.py:125-149): the LAST 'a to b' / 'a and b' pair anywhere in the output
+    (case-sensitive); only when the whole string has none, the first <answer>..</answer> body (single line) is searched."""
+    s = _SPAN.findall(text)
     if not s:
-        return None
+        m = re.search(r"<answer>(.*?)</answer>", text)
+        s = _SPAN.findall(m.group(1).strip()) if m else []
+        if not s:
+            return None
     return float(s[-1][0]), float(s[-1][2])
 
 
@@ -29,7 +34,8 @@ def grounding_metrics(ious, thresholds=(0.3, 0.5, 0.7)):
     ious = np.asarray(ious, dtype=np.float64)
     out = {"mIoU": float(ious.mean() * 100) if ious.size else 0.0}
     for t in thresholds:
-        out["R1@%.1f" % t] = float((ious >= t).mean() * 100) if ious.size else 0.0
+        out["R1@%.1f" % t] = float((ious > t).mean() * 100) if ious.size else 0.0     # strict, like eval_all.py:129
+    out["avg"] = sum(out.values()) / len(out)                                          # eval_all.py:131
     return out
 
 

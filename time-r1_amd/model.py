@@ -344,6 +344,11 @@ class Engine:
         return None
 
     # ====================================================================================================== logprob head
+    # Logits exist at most for HEAD_CHUNK_ROWS prediction rows at a time.  Up to that many rows (config 3: G*C = 1600 rows, 0.49 GB of bf16
+    # logits) the policy path keeps them for the backward; beyond it (config 4: 16 x 1024 rows = 5 GB) both passes walk the rows in chunks
+    # and the backward recomputes a chunk's logits with one more lm_head GEMM (~1 ms per 1024 rows at 7B) instead of holding [G*C, V].
+    HEAD_CHUNK_ROWS = int(os.environ.get("TR1_HEAD_CHUNK_ROWS", "4096"))
+
     def head_fwd(self, arena: Arena, h_last, pred_rows, targets, save):
         """Final norm + lm_head on the rows that predict completion tokens only, then per-token log-prob and entropy
         (reference _get_per_token_logps materialises logits for all (G, L, V) - SURVEY 0.6)."""
@@ -351,18 +356,39 @@ class Engine:
         hp = ops.gather_rows(h_last, pred_rows)
         hn, rstd, _ = ops.rmsnorm_fwd(hp, arena.w("norm"), t.rms_eps, need_rstd=save)
         w = self.params.lm_head_w(arena)
-        logits = ops.gemm_nt(hn, w)
-        logp, ent, lse = ops.logp_entropy_fwd(logits, targets)
+        R, ch = hp.shape[0], self.HEAD_CHUNK_ROWS
+        if R <= ch:
+            logits = ops.gemm_nt(hn, w)
+            logp, ent, lse = ops.logp_entropy_fwd(logits, targets)
+        else:
+            logits, parts = None, []
+            for a in range(0, R, ch):
+                lg = ops.gemm_nt(hn[a:a + ch], w)
+                parts.append(ops.logp_entropy_fwd(lg, targets[a:a + ch].contiguous()))
+                del lg
+            logp, ent, lse = [torch.cat([p[i] for p in parts]) for i in range(3)]
         ctx = dict(hp=hp, hn=hn, rstd=rstd, logits=logits, lse=lse, targets=targets, pred_rows=pred_rows, M=h_last.shape[0]) if save else None
         return logp, ent, ctx
 
     def head_bwd(self, ctx, dlogp, n_dup):
         """dlogp: [R] fp32 in pred_rows order. The first n_dup pred rows all alias one hidden row (the last prompt token)."""
         ops, t, tr = self.ops, self.cfg.text, self.params.train
-        dlogits = ops.logp_bwd(ctx["logits"], ctx["targets"], ctx["lse"], dlogp, inplace=True)
-        self._wgrad(dlogits, ctx["hn"], self.params.lm_head_g())
-        dhn = self._dgrad(dlogits, self.params.lm_head_w(), key="lm_head")
-        ctx["logits"] = None
+        w, gw = self.params.lm_head_w(), self.params.lm_head_g()
+        if ctx["logits"] is not None:
+            dlogits = ops.logp_bwd(ctx["logits"], ctx["targets"], ctx["lse"], dlogp, inplace=True)
+            self._wgrad(dlogits, ctx["hn"], gw)
+            dhn = self._dgrad(dlogits, w, key="lm_head")
+            ctx["logits"] = None
+        else:           # chunked: recompute a chunk's logits, turn them into dlogits in place, feed both gradient GEMMs, drop them
+            hn, R, ch = ctx["hn"], ctx["hn"].shape[0], self.HEAD_CHUNK_ROWS
+            dhn = ops.empty(R, hn.shape[1])
+            for a in range(0, R, ch):
+                b = min(R, a + ch)
+                lg = ops.gemm_nt(hn[a:b], w)
+                dl = ops.logp_bwd(lg, ctx["targets"][a:b].contiguous(), ctx["lse"][a:b].contiguous(), dlogp[a:b].contiguous(), inplace=True)
+                self._wgrad(dl, hn[a:b], gw)
+                dhn[a:b] = self._dgrad(dl, w, key="lm_head")
+                del lg, dl
         dhp = ops.rmsnorm_bwd(dhn, ctx["hp"], tr.w("norm"), ctx["rstd"], dw=tr.g("norm"))
         d = dhp.shape[1]
         dh = ops.zeros(ctx["M"], d)
