@@ -74,8 +74,8 @@ class Workload:
         self.ref = self.params.train.clone_weights_only() if args.beta != 0.0 else None
         self.core = GRPOCore(self.eng, self.ref, args.G, args.C, beta=args.beta, use_grpo=not args.clip_loss, temperature=1.0, top_k=50,
                              seed=1234 + rank, rope_index_mode="hf4")
-        if args.rollout_fp8:
-            self.core.roll.weight_dtype = "fp8"
+        if args.rollout_fp8 or args.rollout_fp8_w8a16:
+            self.core.roll.weight_dtype = "fp8" if args.rollout_fp8_w8a16 else "fp8-mfma"
         from time_r1_amd.optim import AdamWFlat
         self.opt = AdamWFlat(self.params, ops, lr=1e-6, dp=dp, shard_optimizer=shard)
         tiny = args.model.startswith("tiny")
@@ -337,7 +337,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-peak-probe", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
-    ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only)")
+    ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only), fp8 MFMA (W8A8)")
+    ap.add_argument("--rollout-fp8-w8a16", action="store_true", help="fp8 weight copies converted to bf16 in registers (bf16 MFMA) instead of the fp8 MFMA")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
     ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
                     "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json)")
@@ -433,7 +434,8 @@ def main(argv=None):
                                    % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
                                       wl.prompts[0][1].shape[2], wl.prompts[0][1].shape[3]),
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
-                       "rollout_weight_dtype": "fp8-e4m3 (sampling policy only)" if args.rollout_fp8 else "bf16",
+                       "rollout_weight_dtype": ("fp8-e4m3 weights x e4m3 block-scaled activations, fp8 MFMA (sampling policy only)" if args.rollout_fp8 else
+                                                "fp8-e4m3 weights -> bf16 in registers, bf16 MFMA (sampling policy only)" if args.rollout_fp8_w8a16 else "bf16"),
                        "optimizer": "zero-sharded (reduce-scatter / local AdamW / all-gather)" if (args.shard_optimizer and world > 1) else "replicated AdamW + gradient all-reduce"},
         }
     # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step

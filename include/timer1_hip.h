@@ -125,6 +125,10 @@ int tr1_quantize_fp8_rows(const void* w_bf16, int64_t ldw, void* q_fp8, int64_t 
  * lnw != NULL folds rmsnorm(x; lnw, eps) into the operand load; glu != 0: W_fp8 is [2N, K] (gate rows then up rows), out = silu(gate)*up.
  * Same call sites as tr1_gemm_nt_bf16 / tr1_norm_gemm_skinny inside generate.  K % 128 == 0. */
 int tr1_gemm_skinny_w8(const void* x, const void* lnw, const void* W_fp8, const void* wscale, const void* bias, const void* residual, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, float eps, int glu, void* stream);
+/* W8A8, the "CDNA4 fp8 MFMA" form (BASELINE.json configs[4]): same arguments and call sites, but the fp8 weight codes feed
+ * v_mfma_scale_f32_16x16x128_f8f6f4 directly and the activations (after the optional rmsnorm weight) are quantised in the operand load to
+ * e4m3 with one power-of-two (E8M0) scale per row and per 32 consecutive k (OCP microscaling); weight row scale in the epilogue. */
+int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* W_fp8, const void* wscale, const void* bias, const void* residual, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, float eps, int glu, void* stream);
 
 /* ---- native decode-step driver ------------------------------------------------------------------------------------------------ */
 /* One call enqueues a whole rollout decode step for R <= 64 rows: embed gather -> n_layers x {norm+qkv, rope + KV append, split-KV attention,
@@ -140,6 +144,8 @@ int64_t tr1_decode_step_workspace_bytes(const int64_t* dims);
 /* Same step with fp8 weights (tr1_quantize_fp8_rows): 13 pointers per layer {ln1, qkv.q, qkv.b, o.q, ln2, gu.q, down.q, K cache, V^T cache,
  * qkv.scale, o.scale, gu.scale, down.scale}; lm_head_fp8 / lm_head_scale likewise.  Embedding, norms, biases, KV cache stay bf16. */
 int tr1_decode_step_w8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
+/* Same step, every projection through tr1_gemm_skinny_w8a8 (fp8 MFMA). */
+int tr1_decode_step_w8a8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 
 /* ---- video preprocessing (SURVEY 8f "next" row 1) ------------------------------------------------------------------------ */
 /* ref: torchvision resize(BICUBIC, antialias) at src/utils/vision_process.py:467-472 + Qwen2VLVideoProcessor rescale/normalize/patchify

@@ -161,11 +161,31 @@ class RefOps:
             scale.copy_(sc); sc = scale
         return qq, sc
 
-    def gemm_w8(self, x, q, scale, lnw=None, eps=1e-6, bias=None, residual=None, glu=False):
+    @staticmethod
+    def mx_quant_e4m3(x, block=32):
+        """OCP-microscaling style activation quantisation of the W8A8 decode GEMM: per row and per `block` consecutive k one power-of-two
+        scale 2^E, E = floor(log2(amax)) - 7 (values land in [128, 256) of e4m3's 448 range), elements rounded to e4m3 (nearest even);
+        blocks with amax < 2^-119 are zero.  Returns the dequantised fp32 tensor."""
+        M, K = x.shape
+        xb = x.float().reshape(M, K // block, block)
+        amax = xb.abs().amax(-1, keepdim=True)
+        be = (amax.view(torch.int32) >> 23) & 0xff
+        tiny = be < 8
+        e = (be - 127 - 7).float()
+        q = (xb * torch.exp2(-e)).to(torch.float8_e4m3fn).float() * torch.exp2(e)
+        return torch.where(tiny, torch.zeros_like(q), q).reshape(M, K)
+
+    def gemm_w8(self, x, q, scale, lnw=None, eps=1e-6, bias=None, residual=None, glu=False, a8=False):
         wd = q.view(torch.float8_e4m3fn).float()            # exactly representable in bf16: the kernel's register dequantisation is lossless
-        if lnw is not None:
+        if lnw is not None and a8:        # the fp8-MFMA kernel quantises x * lnw and applies the row's rstd to the accumulator
+            xf = x.float()
+            rstd = torch.rsqrt((xf * xf).mean(-1, keepdim=True) + eps)
+            y = (self.mx_quant_e4m3(xf * lnw.float()[None, :]) @ wd.t()) * rstd * scale.float()[None, :]
+        elif lnw is not None:
             x, _, _ = self.rmsnorm_fwd(x, lnw, eps, need_rstd=False)
-        y = (x.float() @ wd.t()) * scale.float()[None, :]
+            y = (x.float() @ wd.t()) * scale.float()[None, :]
+        else:
+            y = ((self.mx_quant_e4m3(x) if a8 else x.float()) @ wd.t()) * scale.float()[None, :]
         if bias is not None:
             y = y + bias.float()
         if residual is not None:

@@ -483,9 +483,14 @@ def test_quantize_fp8_rows_bit_exact(hip_ops, ref_ops, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(16, 4608, 3584, "norm"), (8, 512, 256, "plain"), (16, 3584, 18944, "res"), (16, 1024, 3584, "glu"),
-                                        (32, 4608, 3584, "norm"), (24, 512, 1536, "glu"), (64, 512, 3584, "res"), (5, 72, 384, "plain"), (40, 136, 1024, "glu")])
-def test_gemm_w8(hip_ops, ref_ops, M, N, K, mode):
-    """fp8-weight decode GEMM (register dequantisation, bf16 MFMA) vs the oracle on the SAME quantised weights."""
+                                        (32, 4608, 3584, "norm"), (24, 512, 1536, "glu"), (64, 512, 3584, "res"), (5, 72, 384, "plain"), (40, 136, 1024, "glu"),
+                                        # full-width 7B decode shapes: lm_head over V = 152064 and the gate/up projection
+                                        (16, 152064, 3584, "norm"), (16, 18944, 3584, "glu")])
+@pytest.mark.parametrize("a8", [False, True])
+def test_gemm_w8(hip_ops, ref_ops, M, N, K, mode, a8):
+    """fp8-weight decode GEMM vs the oracle on the SAME quantised weights.  a8=False: register dequantisation + bf16 MFMA (W8A16);
+    a8=True: fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) with the activations block-quantised to e4m3 in the operand load (W8A8) -
+    the oracle applies the same per-row / per-32-k power-of-two scaling and e4m3 rounding, so only the accumulation order differs."""
     glu = mode == "glu"
     x = rnd(M, K, seed=1, scale=2.0 if mode in ("norm", "glu") else 1.0)
     w = rnd(2 * N if glu else N, K, seed=3, scale=1.5 / math.sqrt(K) if glu else 0.1)
@@ -495,13 +500,13 @@ def test_gemm_w8(hip_ops, ref_ops, M, N, K, mode):
     q, sc = hip_ops.quantize_fp8_rows(w.cuda())
     c = lambda t: None if t is None else t.cuda()
     f = lambda t: None if t is None else t.float()
-    h = hip_ops.gemm_w8(x.cuda(), q, sc, lnw=c(lnw), eps=1e-6, bias=c(bias), residual=c(res), glu=glu)
-    r = ref_ops.gemm_w8(x.float(), q.cpu(), sc.cpu(), lnw=f(lnw), eps=1e-6, bias=f(bias), residual=f(res), glu=glu)
-    close(h, r, 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=0.02, what="gemm_w8 %s" % mode)
-    # the quantisation itself: within the e4m3 step of the bf16 GEMM (3 mantissa bits -> ~3 % rms per weight, averaged over K)
+    h = hip_ops.gemm_w8(x.cuda(), q, sc, lnw=c(lnw), eps=1e-6, bias=c(bias), residual=c(res), glu=glu, a8=a8)
+    r = ref_ops.gemm_w8(x.float(), q.cpu(), sc.cpu(), lnw=f(lnw), eps=1e-6, bias=f(bias), residual=f(res), glu=glu, a8=a8)
+    close(h, r, 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=0.02, what="gemm_w8 %s a8=%s" % (mode, a8))
+    # the quantisation itself: within the e4m3 step of the bf16 GEMM (3 mantissa bits -> ~3 % rms per weight / activation, averaged over K)
     if mode == "plain":
         full = x.float() @ w.float().t() + bias.float()
-        assert (h.float().cpu() - full).norm() / full.norm() < 0.05
+        assert (h.float().cpu() - full).norm() / full.norm() < (0.07 if a8 else 0.05)
 
 
 @pytest.mark.parametrize("R,nh,nkv,hd,K", [(16, 28, 4, 128, 3584), (8, 4, 2, 32, 128), (32, 12, 2, 128, 1536), (5, 4, 1, 64, 256), (64, 4, 2, 32, 128)])

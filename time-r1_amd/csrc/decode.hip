@@ -35,7 +35,7 @@ extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return
 
 // One decode step.  w8 = false: bf16 weights, 9 pointers per layer.  w8 = true: the four matrices are fp8 e4m3 with fp32 row scales
 // (csrc/gemm_w8.hip), 13 pointers per layer {ln1, qkv.q, qkv.b, o.q, ln2, gu.q, down.q, K cache, V^T cache, qkv.s, o.s, gu.s, down.s}.
-static int decode_step_impl(bool w8, const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head,
+static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head,
                             const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre,
                             const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream) {
     const int64_t L = dims[D_LAYERS], hid = dims[D_HIDDEN], nh = dims[D_HEADS], nkv = dims[D_KV], hd = dims[D_HEAD_DIM], inter = dims[D_INTER];
@@ -58,12 +58,14 @@ static int decode_step_impl(bool w8, const void* layer_ptrs, const int64_t* dims
     const void* const* lp = (const void* const*)layer_ptrs;
     const int stride = w8 ? 13 : 9;
 #define CK(call) do { int e__ = (call); if (e__) return e__; } while (0)
+    // w8 == 2: the fp8-MFMA (W8A8) projections; w8 == 1: W8A16 (fp8 codes converted to bf16 in registers)
+    auto gemm8 = w8 == 2 ? tr1_gemm_skinny_w8a8 : tr1_gemm_skinny_w8;
     CK(tr1_gather_rows(embed, ids, hA, R, hid, stream));
     void* h = hA; void* h2 = hB;
     for (int64_t i = 0; i < L; ++i) {
         const void* const* w = lp + i * stride;
         if (w8) {
-            CK(tr1_gemm_skinny_w8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
+            CK(gemm8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
         } else if (hd % 32 == 0) {      // norm + q/k/v projection + M-RoPE + KV append in one launch
             CK(tr1_norm_gemm_qkv(h, w[0], w[1], w[2], cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, hid, hid, hid,
@@ -74,15 +76,15 @@ static int decode_step_impl(bool w8, const void* layer_ptrs, const int64_t* dims
         }
         CK(tr1_attn_fwd(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
                         scap, stream));
-        if (w8) CK(tr1_gemm_skinny_w8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
+        if (w8) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
         else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
-        if (w8) CK(tr1_gemm_skinny_w8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
+        if (w8) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
         else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
-        if (w8) CK(tr1_gemm_skinny_w8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
+        if (w8) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
         else if (down_fixup) CK(tr1_gemm_skinny_fixup(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
     }
-    if (w8) CK(tr1_gemm_skinny_w8(h, final_norm, lm_head, lm_head_scale, nullptr, nullptr, logits, R, V, hid, hid, hid, V, 0, eps, 0, stream));
+    if (w8) CK(gemm8(h, final_norm, lm_head, lm_head_scale, nullptr, nullptr, logits, R, V, hid, hid, hid, V, 0, eps, 0, stream));
     else CK(tr1_norm_gemm_skinny(h, final_norm, lm_head, nullptr, logits, R, V, hid, hid, hid, V, eps, 0, stream));
 #undef CK
     return 0;
@@ -91,13 +93,20 @@ static int decode_step_impl(bool w8, const void* layer_ptrs, const int64_t* dims
 extern "C" int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head,
                                const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo,
                                const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream) {
-    return decode_step_impl(false, layer_ptrs, dims, embed, final_norm, lm_head, nullptr, ids, cosb, sinb, slots, pre, lo, hi, work, work_bytes, logits,
+    return decode_step_impl(0, layer_ptrs, dims, embed, final_norm, lm_head, nullptr, ids, cosb, sinb, slots, pre, lo, hi, work, work_bytes, logits,
                             eps, scale, stream);
 }
 
 extern "C" int tr1_decode_step_w8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8,
                                   const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre,
                                   const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream) {
-    return decode_step_impl(true, layer_ptrs, dims, embed, final_norm, lm_head_fp8, lm_head_scale, ids, cosb, sinb, slots, pre, lo, hi, work, work_bytes,
+    return decode_step_impl(1, layer_ptrs, dims, embed, final_norm, lm_head_fp8, lm_head_scale, ids, cosb, sinb, slots, pre, lo, hi, work, work_bytes,
+                            logits, eps, scale, stream);
+}
+
+extern "C" int tr1_decode_step_w8a8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8,
+                                    const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre,
+                                    const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream) {
+    return decode_step_impl(2, layer_ptrs, dims, embed, final_norm, lm_head_fp8, lm_head_scale, ids, cosb, sinb, slots, pre, lo, hi, work, work_bytes,
                             logits, eps, scale, stream);
 }

@@ -164,6 +164,185 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8_kernel(const bf16_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- W8A8: fp8 MFMA
+// BASELINE config 5 ("CDNA4 fp8 MFMA"): the same weight stream, but the fp8 codes go into the matrix core AS fp8 - no conversion VALU on
+// the weight path at all - through v_mfma_scale_f32_16x16x128_f8f6f4 (one instruction per 16 x 16 x 128 step; block-scaled "MX" form).
+// The activations are quantised on the fly, per row and per 32 consecutive k, to e4m3 with a power-of-two (E8M0) block scale - the
+// OCP microscaling recipe - so a block's range follows its own values and no row-wide amax pass over x is needed; the weight keeps its
+// per-output-row fp32 scale (applied to the accumulator in the epilogue) and enters the MFMA with block scale 1.
+// Operand layout of the instruction, probed on MI355X (tools/probe_mfma_f8.hip, tools/probe_mfma_f8_scale.hip): lane (u = lane % 16,
+// g = lane / 16) supplies row/column u; byte t of its 32 operand bytes is logical k = (t / 16) * 64 + g * 16 + t % 16 - i.e. two 16-byte
+// halves, exactly the two loads `k + h*64 + g*16` the W8A16 kernel already issues; the E8M0 scale of logical block b (k in [32b, 32b+32))
+// is read from byte 0 of the scale VGPR of lane (u, b).  Block b = half b/2 of the lane pair g in {2(b%2), 2(b%2)+1}.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+// 16 floats -> 16 e4m3 codes (4 dwords), v_cvt_pk_fp8_f32 rounds to nearest even
+TR1_DEV void quant16_fp8(const float (&v)[16], float mul, int (&o)[4]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d] * mul, v[4 * d + 1] * mul, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d + 2] * mul, v[4 * d + 3] * mul, w, true);
+        o[d] = w;
+    }
+}
+
+template <int WAVES, int UNROLL, int NCOL, int MG, bool NORM, bool GLU>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
+                                                                      const unsigned char* __restrict__ W, const float* __restrict__ wscale,
+                                                                      bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
+                                                                      const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
+                                                                      int64_t ldw, int64_t ldc, int64_t ldr, float eps, int64_t up_off) {
+    static_assert(!GLU || NCOL % 2 == 0, "GLU: NCOL/2 gate column groups + the matching NCOL/2 up groups");
+    constexpr int NOUT = GLU ? NCOL / 2 : NCOL;
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
+    __shared__ float ssred[WAVES][MG][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16 * NOUT;
+    const unsigned char* wp[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        int64_t wrow = n0 + (c % NOUT) * 16 + u;
+        if (wrow >= N) wrow = N - 1;
+        if (GLU && c >= NOUT) wrow += up_off;
+        wp[c] = W + wrow * ldw + g * 16;
+    }
+    const bf16_t* xp[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (int64_t)(mg * 16 + u < M ? mg * 16 + u : (M - 1)) * ldx + g * 16;
+    const bf16_t* lp = NORM ? lnw + g * 16 : nullptr;
+    const int64_t nsteps = K / 128;
+    const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
+    const int64_t s0 = wave * s_per;
+    int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
+    f32x4_t acc[NCOL][MG];
+    float ss[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        ss[mg] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[c][mg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // the lane that holds the other 16 values of my blocks, and the lane whose block exponents I have to present to the MFMA
+    const int partner = lane ^ 16;
+    const int src_lane = u + 16 * (2 * (g & 1));             // first lane of the pair that holds block g (its half g / 2)
+    for (int64_t s = s0; s < s1; s += UNROLL) {
+        u32x4_t wq[UNROLL][NCOL][2];
+        u32x4_t xa[UNROLL][MG][2][2], la[UNROLL][2][2];
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            const int64_t st = s + q < s1 ? s + q : s1 - 1;
+            const int64_t k = st * 128;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) wq[q][c][h] = *reinterpret_cast<const u32x4_t*>(wp[c] + k + h * 64);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    xa[q][mg][h][0] = *reinterpret_cast<const u32x4_t*>(xp[mg] + k + h * 64);
+                    xa[q][mg][h][1] = *reinterpret_cast<const u32x4_t*>(xp[mg] + k + h * 64 + 8);
+                }
+                if (NORM) {
+                    la[q][h][0] = *reinterpret_cast<const u32x4_t*>(lp + k + h * 64);
+                    la[q][h][1] = *reinterpret_cast<const u32x4_t*>(lp + k + h * 64 + 8);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            if (s + q < s1) {
+                i32x8_t xq[MG];
+                int xs[MG];
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    float v[2][16];
+                    float am[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        am[h] = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float a = bflo(xa[q][mg][h][j][e]), b = bfhi(xa[q][mg][h][j][e]);
+                                if (NORM) {
+                                    ss[mg] = fmaf(a, a, fmaf(b, b, ss[mg]));
+                                    a *= bflo(la[q][h][j][e]); b *= bfhi(la[q][h][j][e]);
+                                }
+                                v[h][j * 8 + 2 * e] = a; v[h][j * 8 + 2 * e + 1] = b;
+                                am[h] = fmaxf(am[h], fmaxf(fabsf(a), fabsf(b)));
+                            }
+                        am[h] = fmaxf(am[h], __shfl(am[h], partner, 64));             // the block = my 16 values + the partner lane's 16
+                    }
+                    // block exponent: values scaled into [0, 256) (e4m3 max 448): E8M0 byte = biased exponent of amax - 7; blocks below 2^-119 are zero
+                    int eb[2]; float mul[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int be = (int)(__float_as_uint(am[h]) >> 23);
+                        const bool tiny = be < 8;
+                        eb[h] = tiny ? 0 : be - 7;
+                        mul[h] = tiny ? 0.f : __uint_as_float((unsigned)(261 - be) << 23);
+                    }
+                    int o0[4], o1[4];
+                    quant16_fp8(v[0], mul[0], o0);
+                    quant16_fp8(v[1], mul[1], o1);
+                    xq[mg] = (i32x8_t){o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+                    const int both = __shfl(eb[0] | (eb[1] << 8), src_lane, 64);
+                    xs[mg] = (g >> 1) ? (both >> 8) & 0xff : both & 0xff;
+                }
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) {
+                    const i32x8_t wf = {(int)wq[q][c][0][0], (int)wq[q][c][0][1], (int)wq[q][c][0][2], (int)wq[q][c][0][3],
+                                        (int)wq[q][c][1][0], (int)wq[q][c][1][1], (int)wq[q][c][1][2], (int)wq[q][c][1][3]};
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg)
+                        acc[c][mg] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xq[mg], acc[c][mg], 0, 0, 0, 127, 0, xs[mg]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        if (NORM) {
+            float v = ss[mg];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) ssred[wave][mg][u] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][r];
+    }
+    __syncthreads();
+    const float inv_k = 1.f / (float)K;
+    for (int i = threadIdx.x; i < NOUT * MG * 256; i += WAVES * 64) {
+        const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
+        const int m = mg * 16 + mm;
+        const int64_t n = n0 + c * 16 + nn;
+        if (m < M && n < N) {
+            float sq = 0.f, v = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                if (NORM) sq += ssred[w][mg][mm];
+                v += red[w][c][mg][mm][nn];
+                if (GLU) v2 += red[w][NOUT + c][mg][mm][nn];
+            }
+            const float rstd = NORM ? rsqrtf(sq * inv_k + eps) : 1.f;
+            v *= rstd * wscale[n];
+            if (GLU) {
+                const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd * wscale[up_off + n]));
+                C[(int64_t)m * ldc + n] = f2bf(bf2f(f2bf(silu_w8(gt))) * up);
+            } else {
+                if (bias) v += bf2f(bias[n]);
+                if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
+                C[(int64_t)m * ldc + n] = f2bf(v);
+            }
+        }
+    }
+}
+
 // Per-row symmetric quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = fp8_e4m3(w * (448 / amax_n)), round to nearest even.
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ w, unsigned char* __restrict__ q, float* __restrict__ scale,
                                                              int64_t K, int64_t ldw, int64_t ldq) {
@@ -219,6 +398,55 @@ extern "C" int tr1_gemm_skinny_w8(const void* x, const void* lnw, const void* W_
     {   // tuning hook for tools/microbench.py w8: TR1_W8_CFG=<waves><unroll><ncol> (M <= 16 only)
         static int cfg = -1;
         if (cfg < 0) { const char* e = getenv("TR1_W8_CFG"); cfg = e ? atoi(e) : 0; }
+        if (cfg && !glu && M <= 16) {
+            const bool nrm = lnw != nullptr;
+#define W8C(WV, UN, NC) do { if (nrm) W8(WV, UN, NC, 1, true, false); else W8(WV, UN, NC, 1, false, false); TR1_LAUNCH_CHECK(); } while (0)
+            switch (cfg) {
+                case 442: W8C(4, 4, 2);
+                case 424: W8C(4, 2, 4);
+                case 444: W8C(4, 4, 4);
+                case 822: W8C(8, 2, 2);
+                case 824: W8C(8, 2, 4);
+                case 814: W8C(8, 1, 4);
+                case 842: W8C(8, 4, 2);
+                case 441: W8C(4, 4, 1);
+                case 841: W8C(8, 4, 1);
+                default: break;
+            }
+#undef W8C
+        }
+    }
+    // column groups per block: the activations are re-read from L2 by every block, and with fp8 weights they are as many bytes as a
+    // 2-group weight slab - 4 groups halve that traffic (measured, M = 16: lm_head 168 -> 140 us)
+    if (glu) { if (mg == 1) W8(4, 2, 4, 1, true, true); else if (mg == 2) W8(4, 2, 4, 2, true, true); else W8(4, 1, 2, 4, true, true); }
+    else if (lnw && N >= 100000) { if (mg == 1) W8(4, 2, 4, 1, true, false); else if (mg == 2) W8(4, 2, 4, 2, true, false); else W8(4, 1, 2, 4, true, false); }
+    else if (lnw) W8_MG(4, 2, 2, true, false);
+    else if (K >= 8192) W8_MG(8, 2, 1, false, false);
+    else W8_MG(4, 2, 1, false, false);
+#undef W8_MG
+#undef W8
+    TR1_LAUNCH_CHECK();
+}
+
+// W8A8: the same dispatch on the fp8-MFMA kernel (activations block-quantised to e4m3 in the operand load)
+extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* W_fp8, const void* wscale, const void* bias, const void* residual,
+                                  void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, float eps,
+                                  int glu, void* stream) {
+    TR1_CHECK_ARG(K % 128 == 0 && K >= 128, "gemm_skinny_w8a8: K must be a positive multiple of 128");
+    TR1_CHECK_ARG(M >= 1 && M <= 64, "gemm_skinny_w8a8: 1 <= M <= 64 (decode rows)");
+    TR1_CHECK_ARG(N % 8 == 0 && ldx % 8 == 0 && ldw % 16 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_skinny_w8a8: N%8, ldx%8, ldw%16, ldc%8");
+    TR1_CHECK_ARG(!glu || (lnw && !bias && !residual), "gemm_skinny_w8a8: the GLU form is norm + gate/up only");
+    hipStream_t s = (hipStream_t)stream;
+    const int mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+#define W8(WV, UN, NC, MGR, NRM, GL)                                                                                                       \
+    hipLaunchKernelGGL((gemm_skinny_w8a8_kernel<WV, UN, NC, MGR, NRM, GL>), dim3((unsigned)((N + (GL ? 8 * NC : 16 * NC) - 1) / (GL ? 8 * NC : 16 * NC))), \
+                       dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, (const unsigned char*)W_fp8, (const float*)wscale,       \
+                       (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, ldx, ldw, ldc, ldr, eps, N)
+#define W8_MG(WV, UN, NC, NRM, GL)                                                         \
+    do { if (mg == 1) W8(WV, UN, NC, 1, NRM, GL); else if (mg == 2) W8(WV, UN, NC, 2, NRM, GL); else W8(WV, 1, NC, 4, NRM, GL); } while (0)
+    {   // tuning hook for tools/microbench.py w8: TR1_W8A8_CFG=<waves><unroll><ncol> (M <= 16 only)
+        static int cfg = -1;
+        if (cfg < 0) { const char* e = getenv("TR1_W8A8_CFG"); cfg = e ? atoi(e) : 0; }
         if (cfg && !glu && M <= 16) {
             const bool nrm = lnw != nullptr;
 #define W8C(WV, UN, NC) do { if (nrm) W8(WV, UN, NC, 1, true, false); else W8(WV, UN, NC, 1, false, false); TR1_LAUNCH_CHECK(); } while (0)

@@ -147,19 +147,20 @@ class HipOps:
         self.L.call("tr1_quantize_fp8_rows", _p(w), w.stride(0), _p(q), q.stride(0), _p(scale), N, K, self._s())
         return q, scale
 
-    def gemm_w8(self, x, q, scale, lnw=None, eps=1e-6, bias=None, residual=None, glu=False):
-        """Decode rows x fp8 weights (W8A16): act(x) @ dequant(q)^T * scale (+bias)(+residual); lnw folds rmsnorm in; glu: silu(gate)*up."""
+    def gemm_w8(self, x, q, scale, lnw=None, eps=1e-6, bias=None, residual=None, glu=False, a8=False):
+        """Decode rows x fp8 weights: act(x) @ dequant(q)^T * scale (+bias)(+residual); lnw folds rmsnorm in; glu: silu(gate)*up.
+        a8=False: W8A16 (codes converted to bf16 in registers, bf16 MFMA); a8=True: W8A8 - fp8 MFMA, activations block-quantised to e4m3."""
         self._chk(x, lnw, bias, residual)
         M, K = x.shape
         N = q.shape[0] // 2 if glu else q.shape[0]
         assert q.dtype == torch.uint8 and q.shape[1] == K and x.stride(1) == 1 and q.stride(1) == 1 and scale.dtype == F32
         out = self.empty(M, N)
-        self.L.call("tr1_gemm_skinny_w8", _p(x), _p(lnw), _p(q), _p(scale), _p(bias), _p(residual), _p(out), M, N, K, x.stride(0), q.stride(0), N,
+        self.L.call("tr1_gemm_skinny_w8a8" if a8 else "tr1_gemm_skinny_w8", _p(x), _p(lnw), _p(q), _p(scale), _p(bias), _p(residual), _p(out), M, N, K, x.stride(0), q.stride(0), N,
                     residual.stride(0) if residual is not None else 0, float(eps), int(glu), self._s())
         return out
 
     # ---- native decode-step driver ------------------------------------------------------------------------------------
-    def decode_plan(self, layers, hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit):
+    def decode_plan(self, layers, hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit, a8=False):
         """layers: per decoder layer the 9 tensors (ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache, V^T cache).  Builds the host
         pointer table + device scratch once per rollout; decode_step then costs one C call per generated token."""
         import ctypes
@@ -172,14 +173,14 @@ class HipOps:
         work = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)     # zero: the split-K ticket counters inside start disarmed
         logits = self.empty(rows, vocab)
         return dict(ptrs=ptrs, ptrs_p=ctypes.cast(ptrs, ctypes.c_void_p), dims=dims, work=work, work_p=work.data_ptr(), nbytes=nbytes,
-                    logits=logits, logits_p=logits.data_ptr(), keep=flat, stream=self._s(), w8=per == 13)
+                    logits=logits, logits_p=logits.data_ptr(), keep=flat, stream=self._s(), w8=per == 13, a8=bool(a8))
 
     def decode_step(self, plan, embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p, eps, scale):
         """All arguments after `plan` are raw device addresses (ints): the caller precomputes row pointers into its step tables.
         Returns plan["logits"] [rows, vocab] (overwritten every step)."""
         if plan["w8"]:
             lm_q, lm_s = lm_head_p                  # (fp8 codes address, row scales address)
-            self.L.call("tr1_decode_step_w8", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_q, lm_s, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p,
+            self.L.call("tr1_decode_step_w8a8" if plan.get("a8") else "tr1_decode_step_w8", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_q, lm_s, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p,
                         hi_p, plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
         else:
             self.L.call("tr1_decode_step", plan["ptrs_p"], plan["dims"], embed_p, norm_p, lm_head_p, ids_p, cos_p, sin_p, slots_p, pre_p, lo_p, hi_p,

@@ -37,7 +37,9 @@ class Rollout:
         self._cache = None
         self.calls = 0
         self.native_decode = True     # one native call per decode step (HipOps); False = op-by-op from the host (tests compare the two)
-        self.weight_dtype = "bf16"    # "fp8": decode GEMMs read an e4m3 copy of the decoder matrices + lm_head (row scales), re-quantised per call
+        self.weight_dtype = "bf16"    # "fp8" / "fp8-mfma": decode GEMMs read an e4m3 copy of the decoder matrices + lm_head (row scales), re-quantised
+        #                               per call; "fp8" converts the codes to bf16 in registers (W8A16), "fp8-mfma" feeds them to the fp8 matrix
+        #                               instruction with block-quantised e4m3 activations (W8A8, BASELINE config "CDNA4 fp8 MFMA")
         self._w8 = None
 
     def _kv(self, B, s_cap):
@@ -127,7 +129,8 @@ class Rollout:
         fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set
         native = fused and self.native_decode and hasattr(ops, "decode_step")
         w8 = None
-        if self.weight_dtype == "fp8":
+        a8 = self.weight_dtype == "fp8-mfma"
+        if self.weight_dtype in ("fp8", "fp8-mfma"):
             assert fused and t.hidden % 128 == 0 and t.intermediate % 128 == 0 and t.q_dim % 128 == 0, "fp8 decode: <= 64 rows, K % 128 == 0"
             w8 = self._quantize(arena, w_lm)
         if native:
@@ -139,7 +142,7 @@ class Rollout:
                 return [arena.w("l%d.ln1" % i), Q["qkv.w"][0], arena.w("l%d.qkv.b" % i), Q["o.w"][0], arena.w("l%d.ln2" % i), Q["gu.w"][0], Q["down.w"][0],
                         cache.k[i], cache.vt[i], Q["qkv.w"][1], Q["o.w"][1], Q["gu.w"][1], Q["down.w"][1]]
             plan = ops.decode_plan([layer_tensors(i) for i in range(t.n_layers)], t.hidden, t.n_heads, t.n_kv_heads, hd, t.intermediate, t.vocab_size,
-                                   R, B, cache.s_cap, nsplit)
+                                   R, B, cache.s_cap, nsplit, a8=a8)
             embed_p, norm_p = arena.w("embed").data_ptr(), arena.w("norm").data_ptr()
             lm_p = w_lm.data_ptr() if w8 is None else (w8["lm"][0].data_ptr(), w8["lm"][1].data_ptr())
             cos_p, sin_p, slot_p, hi_p = cos_all.data_ptr(), sin_all.data_ptr(), abs_slots.data_ptr(), hi_all.data_ptr()
@@ -163,7 +166,7 @@ class Rollout:
                 p = "l%d." % i
                 Q = w8["layers"][i] if w8 is not None else None
                 if Q is not None:
-                    qkv = ops.gemm_w8(h, Q["qkv.w"][0], Q["qkv.w"][1], lnw=arena.w(p + "ln1"), eps=t.rms_eps, bias=arena.w(p + "qkv.b"))
+                    qkv = ops.gemm_w8(h, Q["qkv.w"][0], Q["qkv.w"][1], lnw=arena.w(p + "ln1"), eps=t.rms_eps, bias=arena.w(p + "qkv.b"), a8=a8)
                 elif fused and hd % 32 == 0:      # rmsnorm + q/k/v projection + M-RoPE + KV append: one launch (same choice as csrc/decode.hip)
                     qkv = None
                     q = ops.norm_gemm_qkv(h, arena.w(p + "ln1"), t.rms_eps, arena.w(p + "qkv.w"), arena.w(p + "qkv.b"), cs, sn, cache.k[i], cache.vt[i],
@@ -179,9 +182,9 @@ class Rollout:
                 o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
                                     nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap)
                 if Q is not None:
-                    h2 = ops.gemm_w8(o, Q["o.w"][0], Q["o.w"][1], residual=h)
-                    a = ops.gemm_w8(h2, Q["gu.w"][0], Q["gu.w"][1], lnw=arena.w(p + "ln2"), eps=t.rms_eps, glu=True)
-                    h = ops.gemm_w8(a, Q["down.w"][0], Q["down.w"][1], residual=h2)
+                    h2 = ops.gemm_w8(o, Q["o.w"][0], Q["o.w"][1], residual=h, a8=a8)
+                    a = ops.gemm_w8(h2, Q["gu.w"][0], Q["gu.w"][1], lnw=arena.w(p + "ln2"), eps=t.rms_eps, glu=True, a8=a8)
+                    h = ops.gemm_w8(a, Q["down.w"][0], Q["down.w"][1], residual=h2, a8=a8)
                     continue
                 h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
                 if fused:      # rmsnorm -> gate/up projection -> SwiGLU in one launch; the [R, 2I] intermediate never reaches HBM
@@ -194,7 +197,7 @@ class Rollout:
                 else:
                     h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
             if w8 is not None:
-                logits = ops.gemm_w8(h, w8["lm"][0], w8["lm"][1], lnw=arena.w("norm"), eps=t.rms_eps)
+                logits = ops.gemm_w8(h, w8["lm"][0], w8["lm"][1], lnw=arena.w("norm"), eps=t.rms_eps, a8=a8)
             elif fused:
                 logits = ops.norm_gemm(h, arena.w("norm"), t.rms_eps, w_lm)
             else:
