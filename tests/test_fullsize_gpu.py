@@ -51,6 +51,24 @@ def test_wgrad_accumulate_full_shape_vs_torch_fp32(hip_ops):
     assert rel_l2(out, ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(P + G * C, HID, INTER), (P + G * C, 2 * INTER // 4, HID), (1600, H * HD + 2 * NKV * HD, HID), (700, 512, 256)])
+def test_wgrad_k_major_form_reads_activation_as_stored(hip_ops, M, N, K):
+    """dW[N, K] (fp32) (+)= dy[M, N]^T x[M, K] with x read AS STORED (K-major B operand, transposing LDS reads): equal to the transposed-copy
+    path bit for bit (same tiles, same accumulation order), right against fp32 torch, for token counts that are not multiples of 64 (the
+    rows past M are re-reads of the last row against the zero padding of dy^T) and with x an exact-size allocation (nothing readable behind it)."""
+    dy, x = dev_rnd(M, N, seed=4, scale=0.05), dev_rnd(M, K, seed=5)
+    dyt = hip_ops.transpose(dy)
+    out = torch.zeros(N, K, device="cuda")
+    assert hip_ops.wgrad_nn(dyt, x, out, accumulate=False)
+    assert hip_ops.wgrad_nn(dyt, x, out, accumulate=True)
+    want = torch.zeros(N, K, device="cuda")
+    for acc in (False, True):
+        hip_ops.gemm_nt(dyt, hip_ops.transpose(x), out_f32=True, out=want, accumulate=acc)
+    assert torch.equal(out, want)
+    ref = 2.0 * (dy.float().t() @ x.float())
+    assert rel_l2(out, ref) < 2e-3
+
+
 def _replicated_attention(q, k, v, pre, lo, hi, scale):
     """fp32 reference of the two-interval mask on the GPU: softmax over visible keys, GQA by head repetition."""
     T, S = q.shape[0], k.shape[0]

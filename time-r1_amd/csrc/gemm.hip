@@ -416,14 +416,17 @@ TR1_DEV u32x2_t gemm_lds_read_tr16(const char* p) {
     return __builtin_bit_cast(u32x2_t, v);
 }
 TR1_DEV int keyKM(int krow) { return (krow & 1) | ((krow & 2) << 2); }
-TR1_DEV void stage_round_km(const bf16_t* __restrict__ g, int64_t ld, int64_t n0, int64_t n_valid, int64_t k0, char* lds_region, int round,
-                            int wave, int lane) {
+TR1_DEV void stage_round_km(const bf16_t* __restrict__ g, int64_t ld, int64_t n0, int64_t n_valid, int64_t k0, int64_t k_valid, char* lds_region,
+                            int round, int wave, int lane) {
     const int inst = round * 8 + wave;                                   // 2 k-rows (1 KiB) per wave-instruction
     const int krow = inst * 2 + (lane >> 5);
     const int logical = (lane & 31) ^ keyKM(krow);
     int64_t col = n0 + logical * 8;
     if (col + 8 > n_valid) col = n_valid - 8;                            // columns past N: any valid chunk (their outputs are never stored)
-    __builtin_amdgcn_global_load_lds((gptr_t)(g + (k0 + krow) * ld + col), (lptr_t)(lds_region + inst * 1024), 16, 0, 0);
+    int64_t kr = k0 + krow;
+    if (kr >= k_valid) kr = k_valid - 1;                                 // k rows past the operand (weight gradient: the token count is not a multiple
+    //                                                                      of 64): re-read the last row - the A side carries zeros there
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + kr * ld + col), (lptr_t)(lds_region + inst * 1024), 16, 0, 0);
 }
 
 template <bool IS_B, int REGION_ROWS>
@@ -484,9 +487,10 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
     // Lane group g takes the blocks of k rows g*8 .. +3 and g*8 + 4 .. +7, i.e. the standard k order of the MFMA, so the A side is unchanged.
     const int bkm_row = g * 8 + (u >> 2);                                   // + ks*32 (+4 for the second half)
     const int bkm_key = keyKM(bkm_row);                                     // depends on the row's low two bits only
+    const int64_t bkm_kvalid = (BKM && ldr > 0) ? ldr : K;                  // K-major B: `ldr` carries the number of valid k rows of B (no residual in this form)
 
 #define STAGE_A(t, r) stage_round<false, BMX>(A, lda, m0, M, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES, junk, (r), wave, lane)
-#define STAGE_B(t, r) do { if (BKM) stage_round_km(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, (r), wave, lane); \
+#define STAGE_B(t, r) do { if (BKM) stage_round_km(B, ldb, n0, N, (int64_t)(t) * BK, bkm_kvalid, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, (r), wave, lane); \
                            else stage_round<true, BN2>(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, junk, (r), wave, lane); } while (0)
     // prologue: tile 0 complete, B of tile 1 in flight
 #pragma unroll
@@ -1284,6 +1288,44 @@ extern "C" int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
                                        (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, (int64_t)0, (int)t2m, (int)t2n)
     if (rt == 7) LAUNCHNN(7); else if (rt == 9) LAUNCHNN(9); else if (rt == 10) LAUNCHNN(10); else LAUNCHNN(8);
 #undef LAUNCHNN
+    TR1_LAUNCH_CHECK();
+}
+
+// C[M,N] (fp32) (+)= A[M,K] * B[K,N] with B K-major and only its first `b_rows` k rows valid: the WEIGHT GRADIENT dW[n,k] += sum_t dY^T[n,t] X[t,k]
+// with A = dY^T (the transposed copy, zero-padded to a multiple of 64 tokens) and B = X AS STORED - no X^T copy (the 18944-column SwiGLU
+// output of the down projection was the largest transpose of the backward).  Same kernel, tiles and accumulation order as tr1_gemm_nn_bf16.
+extern "C" int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                   int accumulate, int64_t b_rows, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0, "gemm_nn_acc: K must be a multiple of 64");
+    TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nn_acc: N%8, lda%8, ldb%8, ldc%4 required");
+    TR1_CHECK_ARG(M >= 512 && N >= 256, "gemm_nn_acc: M >= 512 and N >= 256 required");
+    TR1_CHECK_ARG(b_rows >= 1 && b_rows <= K, "gemm_nn_acc: 1 <= b_rows <= K");
+    hipStream_t s = (hipStream_t)stream;
+    auto cost = [&](int64_t bm, double eff) {
+        const int64_t t = ((M + bm - 1) / bm) * ((N + BN2 - 1) / BN2);
+        return (double)((t + 255) / 256) * 256.0 * (double)(bm * BN2) / eff;
+    };
+    static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
+    int rt = 8; double best = cost(256, 1.0);
+    for (int r = 7; r <= 10; ++r) { const double c = cost(r * 32, eff[r - 7]); if (c < best) { best = c; rt = r; } }
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES)) + 4096;
+#define SETN(AC, R) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<true, AC, R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+        SETN(false, 7); SETN(false, 8); SETN(false, 9); SETN(false, 10); SETN(true, 7); SETN(true, 8); SETN(true, 9); SETN(true, 10);
+#undef SETN
+        attr_set = true;
+    }
+    dim3 grid2((unsigned)(t2m * t2n));
+#define LAUNCHNA(AC, R) hipLaunchKernelGGL((gemm_nt8p_kernel<true, AC, R, true>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, \
+                                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, b_rows, (int)t2m, (int)t2n)
+#define LAUNCHNAR(R) do { if (accumulate) LAUNCHNA(true, R); else LAUNCHNA(false, R); } while (0)
+    if (rt == 7) LAUNCHNAR(7); else if (rt == 9) LAUNCHNAR(9); else if (rt == 10) LAUNCHNAR(10); else LAUNCHNAR(8);
+#undef LAUNCHNAR
+#undef LAUNCHNA
     TR1_LAUNCH_CHECK();
 }
 

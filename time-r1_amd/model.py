@@ -33,6 +33,7 @@ class Engine:
         self.wgrad_on_main = os.environ.get("TR1_WGRAD_MAIN", "d")
         self.wgrad_overwrite_first = True    # see _wgrad: relies on the optimizer zeroing the gradient arena and bumping arena.version (AdamWFlat.step)
         self._gw_ver = {}
+        self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
         self._side = None
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
@@ -42,15 +43,18 @@ class Engine:
         version changed) overwrites gw instead of accumulating - AdamW left it at zero, so the result is identical and the GEMM epilogue skips
         reading 4 bytes per parameter (33 GB per accumulation window at 7B)."""
         ops = self.ops
-        dyt = ops.transpose(dy)          # [N, Mp]
-        xt = ops.transpose(x)            # [K, Mp]
+        dyt = ops.transpose(dy)          # [N, Mp], zero-padded columns
         acc = True
         if key is not None and self.wgrad_overwrite_first:
             ver = getattr(self.params.train, "version", None)
             if ver is not None and self._gw_ver.get(key) != ver:
                 self._gw_ver[key] = ver
                 acc = False
-        ops.gemm_nt(dyt, xt, out_f32=True, out=gw, accumulate=acc)
+        # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out)
+        nn = getattr(ops, "wgrad_nn", None)
+        if nn is not None and self.wgrad_nn and nn(dyt, x, gw, acc):
+            return
+        ops.gemm_nt(dyt, ops.transpose(x), out_f32=True, out=gw, accumulate=acc)
 
     # Weight gradients of the decoder layers on a second HIP stream: wgrad (dy^T x) and dgrad (dy W) of a Linear only share their input,
     # so the two GEMM chains run concurrently and each fills the CUs the other leaves idle in its last, partially filled round of tiles

@@ -98,6 +98,18 @@ class HipOps:
             return c
         return self.gemm_nt(a, self.transpose(b))
 
+    def wgrad_nn(self, dyt, x, gw, accumulate):
+        """gw[N,K] fp32 (+)= dyt[N, Mp] @ x[M, K]  (dyt = transpose(dy), zero-padded to Mp = M rounded up to 64; x as stored).  Returns False
+        when the K-major form does not cover the shape (the caller then transposes x and uses gemm_nt)."""
+        N, Mp = dyt.shape
+        M, K = x.shape
+        if not (N >= 512 and K >= 256 and K % 8 == 0 and Mp % 64 == 0 and Mp >= M and x.stride(1) == 1 and x.stride(0) % 8 == 0 and dyt.stride(1) == 1):
+            return False
+        self._chk(dyt, x)
+        assert gw.dtype == F32 and gw.shape == (N, K)
+        self.L.call("tr1_gemm_nn_acc_f32", _p(dyt), _p(x), _p(gw), N, K, Mp, _ld(dyt), _ld(x), _ld(gw), int(accumulate), M, self._s())
+        return True
+
     def gemm_nt(self, a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
         """C[M,N] = a[M,K] @ b[N,K]^T (+bias) (+residual); bf16 in, fp32 accumulate. K must be a multiple of 64."""
         self._chk(a, b, bias, residual)
