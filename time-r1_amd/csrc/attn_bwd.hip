@@ -19,15 +19,18 @@
 TR1_DEV void attn_qmeta_tile(const int* __restrict__ pre, const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta,
                              int T, int group, int tile, int lane) {
     const int64_t R = (int64_t)tile * 64 + lane;
-    int mp = 0, ml = 0x7fffffff, mh = -1;
+    int mp = 0, ml = 0x7fffffff, mh = -1, mnp = 0x7fffffff;
     if (R < (int64_t)T * group) {
         const int t = (int)((unsigned)R / (unsigned)group);
-        mp = pre[t];
+        mp = pre[t]; mnp = pre[t];
         if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; }
     }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { mp = max(mp, __shfl_xor(mp, o, 64)); ml = min(ml, __shfl_xor(ml, o, 64)); mh = max(mh, __shfl_xor(mh, o, 64)); }
-    if (lane == 0) { qmeta[tile * 3 + 0] = mp; qmeta[tile * 3 + 1] = ml; qmeta[tile * 3 + 2] = mh; }
+    for (int o = 1; o < 64; o <<= 1) {
+        mp = max(mp, __shfl_xor(mp, o, 64)); ml = min(ml, __shfl_xor(ml, o, 64)); mh = max(mh, __shfl_xor(mh, o, 64)); mnp = min(mnp, __shfl_xor(mnp, o, 64));
+    }
+    // [3]: the smallest prefix length among the tile's rows - keys below it are visible to EVERY row of the tile (mask-free fast path)
+    if (lane == 0) { qmeta[tile * 4 + 0] = mp; qmeta[tile * 4 + 1] = ml; qmeta[tile * 4 + 2] = mh; qmeta[tile * 4 + 3] = mnp; }
 }
 
 // delta[h][t] = sum_d dO[t,h,d] * O[t,h,d].  16 lanes per (t, h) row, 16 bytes per lane: consecutive rows are consecutive in memory, so a
@@ -35,7 +38,7 @@ TR1_DEV void attn_qmeta_tile(const int* __restrict__ pre, const int* __restrict_
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, int64_t do_ld, const bf16_t* __restrict__ O, int64_t o_ld,
                                                          float* __restrict__ delta, int T, int n_heads, int d, const int* __restrict__ pre,
                                                          const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta, int group,
-                                                         int n_qtiles) {
+                                                         int n_qtiles, const float* __restrict__ lse, float* __restrict__ lse2) {
     if ((int)blockIdx.x < n_qtiles && threadIdx.x < 64) attn_qmeta_tile(pre, lo, hi, qmeta, T, group, (int)blockIdx.x, (int)threadIdx.x);
     const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
@@ -54,7 +57,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     s += __shfl_xor(s, 4, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 1, 64);
-    if (ok && sub == 0) delta[(int64_t)h * T + t] = s;
+    if (ok && sub == 0) {
+        delta[(int64_t)h * T + t] = s;
+        // log2-scaled LSE for the DMA-staged dK/dV kernel (exp2 argument = s * scale_log2 - lse2); rows that saw no key carry +inf -> p = 0
+        const float l0 = lse[(int64_t)h * T + t];
+        lse2[(int64_t)h * T + t] = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
+    }
 }
 
 // Transposed MFMA operands straight from a ROW-major LDS tile: ds_read_b64_tr_b16.  Every lane supplies its own 8-byte address; inside a 16-lane
@@ -260,8 +268,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
     int* lds_tiles = reinterpret_cast<int*>(dyn_lds + 2 * BUF);      // [DKDV_MAXT + 1]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int kvh = blockIdx.y, qz = blockIdx.z, QS = gridDim.z;
-    const int kvb0 = blockIdx.x * KB;
+    // grid = (n_kv * QS, 1, key blocks): the dispatcher walks x fastest and z slowest, so blocks leave in order of their key block.  Low key
+    // blocks are the heavy ones (every later query tile sees them; the completion keys at the end see a single group), so the long blocks
+    // start first and the short ones fill the tail (with key blocks on x the last query slice's heavy blocks started last: 34 % idle CUs)
+    const int QS = gridDim.x / p.n_kv;
+    const int kvh = blockIdx.x % p.n_kv, qz = blockIdx.x / p.n_kv;
+    const int kvb0 = blockIdx.z * KB;
     int kv[KT]; bool kv_ok[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { kv[kt] = kvb0 + (wave * KT + kt) * 16 + u; kv_ok[kt] = kv[kt] < p.n_slots; }
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             const int c = base + lane, qi = qz + c * QS;
             bool rel = false;
             if (c < n_cand) {
-                const int mp = p.qmeta[qi * 3], ml = p.qmeta[qi * 3 + 1], mh = p.qmeta[qi * 3 + 2];
+                const int mp = p.qmeta[qi * 4], ml = p.qmeta[qi * 4 + 1], mh = p.qmeta[qi * 4 + 2];
                 rel = (kvb0 < mp) || (kvb0 + KB - 1 >= ml && kvb0 <= mh);
             }
             const unsigned long long mask = __ballot(rel);
@@ -527,6 +539,271 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
     }
 }
 
+// -------------------------------------------------------------------------------------------------- dK/dV, LDS-DMA staged (head dim 128)
+// Same decomposition (block = KB keys of one kv head x one slice of the query tiles, K/V fragments stationary in registers, transposed
+// operands read from the row-major tiles with ds_read_b64_tr_b16), but the 64-row Q / dO tiles and their row statistics travel
+// global -> LDS with global_load_lds (no staging registers, no ds_write): a ring of NB tile buffers keeps NB-1 query tiles in flight per
+// block whatever the register budget, which is what lets a wave own 32 keys (KT = 2: every Q / dO / Q^T / dO^T fragment read from LDS
+// feeds two MFMAs - half the LDS traffic per FLOP of the 16-key form, whose LDS read time equalled its MFMA time).
+// Tile image: 64 rows x 256 bytes, no padding; row r keeps its logical 16-byte chunk c at c ^ dkey(r & 15).  dkey spreads the 16 rows of a
+// b128 fragment read over all 16 chunk positions and the 8 rows x 2 chunks of a 32-lane transposing read over 16 distinct positions:
+// both read shapes are bank-conflict free.  One DMA instruction = 4 rows (1 KiB, lane -> row lane / 16, physical chunk lane % 16).
+// Row statistics (log2-scaled LSE from attn_delta_kernel, delta, pre / lo / hi) follow as five 256-byte dword DMAs issued by wave 0.
+// Ordering: each wave counts its own DMA instructions (s_waitcnt vmcnt(n)), then ONE barrier per tile publishes the tile to the block and
+// retires the buffer consumed in the previous iteration, which is refilled right behind the barrier.
+TR1_DEV int dkey(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+
+template <int NW, int KT, int NB>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_dma_kernel(AttnParams p, int n_qtiles, const float* __restrict__ lse2, float* __restrict__ part_k,
+                                                                    float* __restrict__ part_v) {
+    constexpr int D = 128, KB = NW * 16 * KT;
+    constexpr int TILE = 64 * 256, META = 64 * 5 * 4, BUF = 2 * TILE + META;
+    constexpr int IPW = 16 / NW;                                      // 4-row groups per wave: IPW Q + IPW dO instructions per tile
+    constexpr int PER = 2 * IPW, PER0 = PER + 5;                      // DMA instructions per tile: waves 1.., wave 0 (+ row statistics)
+    static_assert(NB >= 3 && NB <= 5 && (NB - 2) * PER0 <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // [NB][Q rows | dO rows | lse2, delta, pre, lo, hi] + tile list
+    int* lds_tiles = reinterpret_cast<int*>(dyn_lds + NB * BUF);      // [DKDV_MAXT + 1] tile ids, then [DKDV_MAXT] their smallest prefix length
+    int* lds_minpre = lds_tiles + DKDV_MAXT + 1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    // grid = (n_kv * QS, 1, key blocks): the dispatcher walks x fastest and z slowest, so blocks leave in order of their key block.  Low key
+    // blocks are the heavy ones (every later query tile sees them; the completion keys at the end see a single group), so the long blocks
+    // start first and the short ones fill the tail (with key blocks on x the last query slice's heavy blocks started last: 34 % idle CUs)
+    const int QS = gridDim.x / p.n_kv;
+    const int kvh = blockIdx.x % p.n_kv, qz = blockIdx.x / p.n_kv;
+    const int kvb0 = blockIdx.z * KB;
+    int kv[KT]; bool kv_ok[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { kv[kt] = kvb0 + (wave * KT + kt) * 16 + u; kv_ok[kt] = kv[kt] < p.n_slots; }
+    const int64_t nR = (int64_t)p.T * p.group;
+
+    if (wave == 0) {      // this block's list of relevant query tiles (qi = qz, qz+QS, ...)
+        int count = 0;
+        const int n_cand = (n_qtiles - qz + QS - 1) / QS;
+        for (int base = 0; base < n_cand; base += 64) {
+            const int c = base + lane, qi = qz + c * QS;
+            bool rel = false;
+            int mnp = 0;
+            if (c < n_cand) {
+                const int mp = p.qmeta[qi * 4], ml = p.qmeta[qi * 4 + 1], mh = p.qmeta[qi * 4 + 2];
+                mnp = p.qmeta[qi * 4 + 3];
+                rel = (kvb0 < mp) || (kvb0 + KB - 1 >= ml && kvb0 <= mh);
+            }
+            const unsigned long long mask = __ballot(rel);
+            if (rel) { const int at = count + __popcll(mask & ((1ull << lane) - 1ull)); lds_tiles[at] = qi; lds_minpre[at] = mnp; }
+            count += __popcll(mask);
+        }
+        if (lane == 0) lds_tiles[DKDV_MAXT] = count;
+    }
+    bf16x8_t kf[KT][D / 32], vf[KT][D / 32];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const bf16_t* krow = p.K + (int64_t)(kv_ok[kt] ? kv[kt] : 0) * p.k_ld + (int64_t)kvh * D;
+        const bf16_t* vrow = p.V + (int64_t)(kv_ok[kt] ? kv[kt] : 0) * p.v_ld + (int64_t)kvh * D;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+            kf[kt][ks] = load_row_frag(krow, ks * 32 + g * 8, D, kv_ok[kt]);
+            vf[kt][ks] = load_row_frag(vrow, ks * 32 + g * 8, D, kv_ok[kt]);
+        }
+    }
+    f32x4_t dk[KT][D / 16], dv[KT][D / 16];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) { dk[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the K / V fragments are in registers: from here on vmcnt counts DMA only
+    __syncthreads();
+    const int n_my = lds_tiles[DKDV_MAXT];
+
+    // ---- DMA of one query tile into ring slot `slot`
+    auto issue_tile = [&](int qi, int slot) {
+        char* buf = dyn_lds + slot * BUF;
+        const int64_t Rq0 = (int64_t)qi * 64;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int i = wave * IPW + j;                             // rows 4i .. 4i+3
+            const int row = 4 * i + (lane >> 4);
+            int64_t R = Rq0 + row; if (R > nR - 1) R = nR - 1;
+            const unsigned ru = (unsigned)R, tu = p.group == 1 ? ru : __umulhi(ru, p.group_magic);
+            const int hq = (int)(ru - tu * (unsigned)p.group);
+            const int64_t hoff = (int64_t)(kvh * p.group + hq) * D + (((lane & 15) ^ dkey(row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(p.Q + (int64_t)tu * p.q_ld + hoff), (att_lptr_t)(buf + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(p.dO + (int64_t)tu * p.do_ld + hoff), (att_lptr_t)(buf + TILE + i * 1024), 16, 0, 0);
+        }
+        if (wave == 0) {
+            int64_t R = Rq0 + lane; if (R > nR - 1) R = nR - 1;
+            const unsigned ru = (unsigned)R, tu = p.group == 1 ? ru : __umulhi(ru, p.group_magic);
+            const int hq = (int)(ru - tu * (unsigned)p.group);
+            const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + tu;
+            char* mb = buf + 2 * TILE;
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(lse2 + si), (att_lptr_t)(mb), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(p.delta + si), (att_lptr_t)(mb + 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(p.pre + tu), (att_lptr_t)(mb + 512), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(p.lo + tu), (att_lptr_t)(mb + 768), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(p.hi + tu), (att_lptr_t)(mb + 1024), 4, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j)
+        if (j < n_my) issue_tile(__builtin_amdgcn_readfirstlane(lds_tiles[j]), j);
+
+    // per-lane fragment addresses inside a tile (swizzled); qt / dt / half offsets are added in the loops
+    const int keyu = dkey(u);
+    const int trow = g * 4 + (u >> 2);                                // row (mod 16) of this lane's transposing reads
+    const int keyt = dkey(trow);
+    const int tr_lo = trow * 256 + (u & 1) * 8, tr_c = (u & 3) >> 1;  // + ((dt*2 + tr_c) ^ keyt) * 16 + qb * 256
+
+    for (int it = 0; it < n_my; ++it) {
+        // my DMA share of tile `it` has landed when at most (tiles issued after it) x (my instructions per tile) are outstanding
+        {
+            const int after = (n_my - 1 - it) < (NB - 2) ? (n_my - 1 - it) : (NB - 2);
+            if (wave == 0) {
+                if (after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER0 > 63 ? 63 : 3 * PER0) : "memory");
+                else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER0) : "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+                else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_s_barrier();                                 // tile `it` is complete for everybody; everybody is done with tile it-1
+        asm volatile("" ::: "memory");
+        if (it + NB - 1 < n_my) issue_tile(__builtin_amdgcn_readfirstlane(lds_tiles[it + NB - 1]), (it + NB - 1) % NB);     // = the slot of tile it-1
+
+        const int qi = __builtin_amdgcn_readfirstlane(lds_tiles[it]);
+        const int tile_minpre = __builtin_amdgcn_readfirstlane(lds_minpre[it]);
+        const char* buf = dyn_lds + (it % NB) * BUF;
+        const char* lds_q = buf;
+        const char* lds_do = buf + TILE;
+        const float* lds_lse = reinterpret_cast<const float*>(buf + 2 * TILE);
+        const float* lds_dlt = lds_lse + 64;
+        const int* lds_pre = reinterpret_cast<const int*>(lds_lse + 128);
+        const int* lds_lo = lds_pre + 64;
+        const int* lds_hi = lds_pre + 128;
+
+        f32x4_t s[KT][4], dp[KT][4];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) { s[kt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const int off = (qt * 16 + u) * 256 + (((ks * 4 + g) ^ keyu) << 4);
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(lds_q + off);
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(lds_do + off);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt][qt], 0, 0, 0);
+                    dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt][qt], 0, 0, 0);
+                }
+            }
+        }
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        bf16x8_t pf0[KT], pf1[KT], df0[KT], df1[KT];
+        const int rows_valid = (int)((nR - (int64_t)qi * 64) < 64 ? (nR - (int64_t)qi * 64) : 64);
+        const bool full = (kvb0 + KB <= tile_minpre) && (kvb0 + KB <= p.n_slots) && rows_valid == 64;      // block-uniform
+        if (full) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4_t l4[2], d4[2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    l4[q2] = *reinterpret_cast<const f32x4_t*>(lds_lse + (2 * h + q2) * 16 + g * 4);
+                    d4[q2] = *reinterpret_cast<const f32x4_t*>(lds_dlt + (2 * h + q2) * 16 + g * 4);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    f32x4_t pr[2], ds[2];
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][2 * h + q2][r], p.scale_log2, -l4[q2][r]));
+                            pr[q2][r] = pv; ds[q2][r] = pv * (dp[kt][2 * h + q2][r] - d4[q2][r]);
+                        }
+                    if (h == 0) { pf0[kt] = pack_frag(pr[0], pr[1]); df0[kt] = pack_frag(ds[0], ds[1]); }
+                    else { pf1[kt] = pack_frag(pr[0], pr[1]); df1[kt] = pack_frag(ds[0], ds[1]); }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4_t l4[2], d4[2];
+                i32x4_t p4[2], lo4[2], hi4[2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int o = (2 * h + q2) * 16 + g * 4;
+                    l4[q2] = *reinterpret_cast<const f32x4_t*>(lds_lse + o); d4[q2] = *reinterpret_cast<const f32x4_t*>(lds_dlt + o);
+                    p4[q2] = *reinterpret_cast<const i32x4_t*>(lds_pre + o); lo4[q2] = *reinterpret_cast<const i32x4_t*>(lds_lo + o);
+                    hi4[q2] = *reinterpret_cast<const i32x4_t*>(lds_hi + o);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    f32x4_t pr[2], ds[2];
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool ok = kv_ok[kt] & att_visible_nb(kv[kt], p4[q2][r], lo4[q2][r], hi4[q2][r]) & ((2 * h + q2) * 16 + g * 4 + r < rows_valid);
+                            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][2 * h + q2][r], p.scale_log2, -l4[q2][r]));
+                            const float pv = ok ? e : 0.f;
+                            pr[q2][r] = pv; ds[q2][r] = ok ? pv * (dp[kt][2 * h + q2][r] - d4[q2][r]) : 0.f;
+                        }
+                    if (h == 0) { pf0[kt] = pack_frag(pr[0], pr[1]); df0[kt] = pack_frag(ds[0], ds[1]); }
+                    else { pf1[kt] = pack_frag(pr[0], pr[1]); df1[kt] = pack_frag(ds[0], ds[1]); }
+                }
+            }
+        }
+        // transposed fragments: rows qb + trow (first 8 bytes) and qb + 16 + trow (second), feature chunk dt*2 + tr_c
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const int off = hh * 32 * 256 + tr_lo + (((dt * 2 + tr_c) ^ keyt) << 4);
+                const bf16x8_t q0 = make_frag(lds_read_tr16(lds_q + off), lds_read_tr16(lds_q + off + 16 * 256));
+                const bf16x8_t o0 = make_frag(lds_read_tr16(lds_do + off), lds_read_tr16(lds_do + off + 16 * 256));
+                _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, hh ? pf1[kt] : pf0[kt], dv[kt][dt], 0, 0, 0);
+                _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, hh ? df1[kt] : df0[kt], dk[kt][dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // all LDS reads of this tile have returned before the barrier that frees its slot
+    }
+    // lane holds dK^T/dV^T[d = dt*16 + g*4 + r][kv]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+    if (kv_ok[kt]) {
+        if (part_k) {
+            const int64_t kvd = (int64_t)p.n_kv * D;
+            float* pk = part_k + ((int64_t)qz * p.n_slots + kv[kt]) * kvd + (int64_t)kvh * D;
+            float* pv = part_v + ((int64_t)qz * p.n_slots + kv[kt]) * kvd + (int64_t)kvh * D;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                *reinterpret_cast<f32x4_t*>(pk + d) = dk[kt][dt]; *reinterpret_cast<f32x4_t*>(pv + d) = dv[kt][dt];
+            }
+        } else {
+            const float scale = p.scale_log2 * 0.6931471805599453f;
+            bf16_t* kr = p.dK + (int64_t)kv[kt] * p.dk_ld + (int64_t)kvh * D;
+            bf16_t* vr = p.dV + (int64_t)kv[kt] * p.dv_ld + (int64_t)kvh * D;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const int d = dt * 16 + g * 4;
+                u32x2_t wk = {pack2bf(dk[kt][dt][0] * scale, dk[kt][dt][1] * scale), pack2bf(dk[kt][dt][2] * scale, dk[kt][dt][3] * scale)};
+                u32x2_t wv = {pack2bf(dv[kt][dt][0], dv[kt][dt][1]), pack2bf(dv[kt][dt][2], dv[kt][dt][3])};
+                *reinterpret_cast<u32x2_t*>(kr + d) = wk;
+                *reinterpret_cast<u32x2_t*>(vr + d) = wv;
+            }
+        }
+    }
+}
+
 // dK = scale * sum_z part_k[z], dV = sum_z part_v[z]  -> bf16
 __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const float* __restrict__ part_v, bf16_t* __restrict__ dK, int64_t dk_ld,
                                        bf16_t* __restrict__ dV, int64_t dv_ld, int n_slots, int kvd, int QS, float scale) {
@@ -560,7 +837,7 @@ static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) 
 }
 
 template <int D>
-static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_floats) {
+static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_floats, const float* lse2) {
     const int64_t nR = (int64_t)p.T * p.group;
     const int n_qtiles = (int)((nR + 63) / 64);
     constexpr int KSTR = 2 * D + 16;
@@ -580,6 +857,18 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
+    // head dim 128: the LDS-DMA staged forms.  TR1_DKDV_DMA = 0: register-staged 8 waves x 16 keys; 1: DMA, 4 waves x 32 keys; 2: DMA, 8 waves x 16 keys
+    static int dma = -1;
+    if (dma < 0) { const char* e = getenv("TR1_DKDV_DMA"); dma = e ? atoi(e) : 2; }
+    constexpr int DMA_NB = 4;
+    const size_t dyn_dma = DMA_NB * (2 * 64 * 256 + 64 * 5 * 4) + (2 * DKDV_MAXT + 2) * 4;
+    static bool dma_attr = false;
+    if (D == 128 && !dma_attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dma);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dma);
+        dma_attr = true;
+    }
+    const bool use_dma = D == 128 && p.d_real == 128 && dma > 0 && lse2 != nullptr;
     const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots, KB);
     const int64_t kvd = (int64_t)p.n_kv * p.d_real;
     float *pk = nullptr, *pv = nullptr;
@@ -588,8 +877,10 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
         pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
     }
-    if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)((p.n_slots + KB - 1) / KB), p.n_kv, QS), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
-    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)((p.n_slots + KB - 1) / KB), p.n_kv, QS), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
+    if (use_dma && dma == 2) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
+    else if (use_dma) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(256), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
+    else if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
+    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
     if (QS > 1) {
         const float scale = p.scale_log2 * 0.6931471805599453f;
         hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(tr1_grid_1d(p.n_slots * kvd / 4, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
@@ -604,7 +895,7 @@ extern "C" int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int
     return QS > 1 ? 2 * (int64_t)QS * n_slots * n_kv * head_dim : 0;
 }
 
-// Scratch: qmeta_ws int32 [3*ceil(T*group/64)], delta fp32 [n_heads*T], ws_f32 of tr1_attn_bwd_workspace_floats() floats.
+// Scratch: qmeta_ws int32 [4*ceil(T*group/64)], delta fp32 [2*n_heads*T] (delta | log2-scaled LSE), ws_f32 of tr1_attn_bwd_workspace_floats() floats.
 extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
                             int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
                             const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,
@@ -633,16 +924,17 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     if (T == 0 || n_slots == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int n_qtiles = (int)((T * p.group + 63) / 64);
+    float* lse2 = (float*)delta + T * n_heads;                                   // second half of the delta scratch: log2-scaled LSE
     const unsigned delta_blocks = (unsigned)((T * n_heads + 15) / 16);          // >= 4 * n_qtiles (n_heads >= group)
     hipLaunchKernelGGL(attn_delta_kernel, dim3(delta_blocks > (unsigned)n_qtiles ? delta_blocks : (unsigned)n_qtiles), dim3(256), 0, s,
                        (const bf16_t*)dO, do_ld, (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim, p.pre, p.lo, p.hi,
-                       (int*)qmeta_ws, p.group, n_qtiles);
+                       (int*)qmeta_ws, p.group, n_qtiles, (const float*)lse, lse2);
     int rc = 0;
     switch (d_pad) {
-        case 32: rc = launch_bwd<32>(p, s, (float*)ws_f32, ws_floats); break;
-        case 64: rc = launch_bwd<64>(p, s, (float*)ws_f32, ws_floats); break;
-        case 96: rc = launch_bwd<96>(p, s, (float*)ws_f32, ws_floats); break;
-        default: rc = launch_bwd<128>(p, s, (float*)ws_f32, ws_floats); break;
+        case 32: rc = launch_bwd<32>(p, s, (float*)ws_f32, ws_floats, lse2); break;
+        case 64: rc = launch_bwd<64>(p, s, (float*)ws_f32, ws_floats, lse2); break;
+        case 96: rc = launch_bwd<96>(p, s, (float*)ws_f32, ws_floats, lse2); break;
+        default: rc = launch_bwd<128>(p, s, (float*)ws_f32, ws_floats, lse2); break;
     }
     if (rc) return rc;
     TR1_LAUNCH_CHECK();

@@ -50,9 +50,12 @@ class Engine:
             if ver is not None and self._gw_ver.get(key) != ver:
                 self._gw_ver[key] = ver
                 acc = False
-        # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out)
+        # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out).
+        # Its transposing LDS reads cost 8-17 % of the GEMM rate (tools/bench_wgrad.py: 1060 against 1244 TFLOP/s at the down-projection
+        # shape), so it only pays where the saved transpose is the larger piece: x at least twice as wide as dy (the down projection,
+        # x = the 18944-column SwiGLU output: 735 -> 650 us per layer; gate/up, o, qkv and the lm_head stay on the transposed copy).
         nn = getattr(ops, "wgrad_nn", None)
-        if nn is not None and self.wgrad_nn and nn(dyt, x, gw, acc):
+        if nn is not None and self.wgrad_nn and x.shape[1] >= 2 * dy.shape[1] and nn(dyt, x, gw, acc):
             return
         ops.gemm_nt(dyt, ops.transpose(x), out_f32=True, out=gw, accumulate=acc)
 
