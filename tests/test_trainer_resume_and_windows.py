@@ -141,3 +141,20 @@ def test_row_chunked_lm_head_equals_whole_head(monkeypatch):
         out.append((float(loss), dict(tr._metrics), tr.params.train.grad.clone()))
     assert abs(out[0][0] - out[1][0]) < 1e-7 and out[0][1].keys() == out[1][1].keys()
     assert torch.allclose(out[0][2], out[1][2], atol=1e-6), float((out[0][2] - out[1][2]).abs().max())
+
+
+def test_stashed_prefill_window_equals_full_slot_window(monkeypatch):
+    """Config 4 memory scheme: later prompts of a batched window keep only their prompt rows (stash) and move them into the ONE full
+    saved-activation set when their update starts.  Same gradients as one full set per prompt."""
+    from time_r1_amd.model import Engine
+    fx = load_case("grpo_beta")
+    grads = []
+    for gb in (40.0, 0.0):           # 0 GB threshold: every sequence counts as large -> slot 1 is stashed
+        monkeypatch.setattr(Engine, "CTX_STASH_GB", gb)
+        cfg, tr = make_trainer(fx, ga=2, rollout_batching=True)
+        tr.train_dataset = _dataset(fx, 2)
+        tr.accumulation_window([[tr.train_dataset[0]], [tr.train_dataset[1]]])
+        pool = tr.engine._ctx_pool
+        assert (("stash", 1) in pool) == (gb == 0.0) and ((1 in pool) == (gb != 0.0))
+        grads.append(tr.params.train.grad.clone())
+    assert float(grads[0].abs().max()) > 0 and torch.equal(grads[0], grads[1])

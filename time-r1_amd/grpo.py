@@ -123,6 +123,8 @@ class GRPOCore:
             # continuation: only the G*C completion rows; the prompt rows' activations and K/V come from the rollout's prefill
             P, M = st.P, st.layout.M
             pctx, kv = pf
+            if pctx.get("stash"):            # large sequences: this prompt's prefill rows were parked; the one full buffer set is free now
+                pctx = eng.unstash_ctx(pctx, P, M)
             hc = ops.gather_rows(tr.w("embed"), st.ids_packed[P:].contiguous())
             cmask = [m[P:].contiguous() for m in st.masks]
             hLc, cctx = eng.llm_fwd(tr, hc, st.cos[P:].contiguous(), st.sin[P:].contiguous(), cmask, save=True, kv_cache=kv, row0=P,

@@ -199,18 +199,31 @@ class Engine:
 
     SAVED = ("h", "xn", "qkv", "q", "o", "h2", "xn2", "gu", "a")
 
-    def alloc_ctx_bufs(self, total_rows, slot=0):
+    # A full set of saved-activation buffers above this size is kept ONCE: further prompts of the accumulation window stash only their
+    # prompt rows (written by the rollout prefill) and move them into the one full set when their update starts (unstash_ctx).
+    CTX_STASH_GB = float(os.environ.get("TR1_CTX_STASH_GB", "40"))
+
+    def ctx_bytes(self, rows):
+        t = self.cfg.text
+        return rows * t.n_layers * (2 * (4 * t.hidden + t.qkv_dim + 2 * t.q_dim + 3 * t.intermediate) + 8)
+
+    def alloc_ctx_bufs(self, total_rows, slot=0, prefill_rows=None):
         """Saved-activation buffers for a packed sequence of `total_rows` rows that is run in two pieces (prompt rows during the rollout
         prefill, completion rows in the update's continuation forward): both pieces write their rows in place, so the backward gets
         [M, .] tensors without a concatenation pass (that pass cost ~25 GB of copies per 7B micro-step).
         The buffers are owned by the engine and recycled: `slot` = index of the prompt inside the accumulation window; a slot is free
-        again once that prompt's backward has been enqueued (same stream), and it only grows (no allocator churn of 24 GB blocks)."""
+        again once that prompt's backward has been enqueued (same stream), and it only grows (no allocator churn of 24 GB blocks).
+        Large sequences (config 4: 19 650 rows = 92 GB per set): slots >= 1 get a STASH of `prefill_rows` rows only - the window's rollouts
+        are still decoded together (all prefills run first), but only one full set exists; returns (bufs, is_stash)."""
         ops, t = self.ops, self.cfg.text
+        stash = slot > 0 and prefill_rows is not None and self.ctx_bytes(total_rows) > self.CTX_STASH_GB * 1e9
+        rows = prefill_rows if stash else total_rows
         pool = self.__dict__.setdefault("_ctx_pool", {})
-        ent = pool.get(slot)
-        if ent is None or ent[0] < total_rows:
-            pool[slot] = None          # release the smaller set before allocating the larger one
-            cap = (total_rows + 255) // 256 * 256
+        key = ("stash", slot) if stash else slot
+        ent = pool.get(key)
+        if ent is None or ent[0] < rows:
+            pool[key] = None          # release the smaller set before allocating the larger one
+            cap = (rows + 255) // 256 * 256
             cols = dict(h=t.hidden, xn=t.hidden, qkv=t.qkv_dim, q=t.q_dim, o=t.q_dim, h2=t.hidden, xn2=t.hidden, gu=2 * t.intermediate, a=t.intermediate)
             full = []
             for _ in range(t.n_layers):
@@ -218,8 +231,21 @@ class Engine:
                 L["rstd1"] = ops.empty(cap, dtype=F32)
                 L["rstd2"] = ops.empty(cap, dtype=F32)
                 full.append(L)
-            ent = pool[slot] = (cap, full)
-        return [{k: v[:total_rows] for k, v in L.items()} for L in ent[1]]
+            ent = pool[key] = (cap, full)
+        bufs = [{k: v[:rows] for k, v in L.items()} for L in ent[1]]
+        return (bufs, stash) if prefill_rows is not None else bufs
+
+    def unstash_ctx(self, pctx, prefill_rows, total_rows):
+        """Move a stashed prefill (prompt rows of a later prompt of the window) into the one full buffer set; the previous prompt's backward has
+        been enqueued on this stream, so the set is free.  ~1 read + 1 write of the prompt rows (config 4: 15 GB, 6 ms on a 3.4 s micro-step)."""
+        full = self.alloc_ctx_bufs(total_rows, slot=0)
+        P = prefill_rows
+        for dst, src in zip(full, pctx["bufs"]):
+            for k, v in src.items():
+                dst[k][:P].copy_(v[:P])
+        pctx["bufs"] = full
+        pctx["stash"] = False
+        return pctx
 
     def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0, bufs=None):
         """Decoder stack over a packed sequence of M rows. masks = (pre, lo, hi) int32 [M] over slots == rows.

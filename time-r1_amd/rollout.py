@@ -100,8 +100,10 @@ class Rollout:
             masks = [ops.tensor(a, I32) for a in lay.prompt_masks()]
             h = eng.embed(arena, prompt_ids, vid_embeds, vid_rows)
             # save_prefill: the prompt rows' activations go straight into [P + G*C, .] buffers that the update's continuation forward completes
-            hL, pctx = eng.llm_fwd(arena, h, cos, sin, masks, save=save_prefill, kv_cache=kv_views,
-                                   bufs=eng.alloc_ctx_bufs(lay.M, slot=b) if save_prefill else None)
+            bufs, is_stash = eng.alloc_ctx_bufs(lay.M, slot=b, prefill_rows=P) if save_prefill else (None, False)
+            hL, pctx = eng.llm_fwd(arena, h, cos, sin, masks, save=save_prefill, kv_cache=kv_views, bufs=bufs)
+            if is_stash:
+                pctx["stash"] = True
             hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
             logits = ops.gemm_nt(hn, w_lm)  # [1, V]
             tokens = tokens_all[b * G:(b + 1) * G]
