@@ -320,6 +320,55 @@ def cpu_baseline(args, budget_note=True):
             "seconds_per_sample_est": est}
 
 
+def cpu_config1(n_prompts=1):
+    """BASELINE.json configs[0] timed for real on the host cores (no extrapolation): Qwen2-VL-2B architecture at FULL depth, 8 frames of
+    360x640 (grid 4x26x46, 1196 video tokens), G = 4, C = 64, beta = 0.04, fp32, the CPU oracle ops (kind "port").  One micro-step per
+    prompt: preprocessing, vision tower, prefill + 64 decode steps, policy and reference log-probs, loss, backward; the optimizer step is
+    timed once.  `python bench.py --cpu-config1 [--cpu-config1-prompts N]` prints this leg only (about 1 minute per prompt on 128 cores)."""
+    from oracle.ref_ops import RefOps  # noqa: checker/baseline only
+    cfg = PRESETS["qwen2-vl-2b"]()
+    ops = RefOps(act_dtype=torch.float32)
+    G, C, grid = 4, 64, GRIDS[8]
+    t_all = time.time()
+    params = ModelParams(cfg, ops, init="none")
+    chunk = torch.empty(1 << 24).uniform_(-0.03, 0.03)
+    for arena in (params.train, params.frozen):
+        flat = arena.w16
+        for a0 in range(0, flat.numel(), chunk.numel()):
+            b0 = min(flat.numel(), a0 + chunk.numel())
+            flat[a0:b0].copy_(chunk[: b0 - a0])
+        for name, _ in arena.specs:
+            if name.endswith("ln1") or name.endswith("ln2") or name == "norm" or name.endswith("ln.w") or name.endswith("n1.w") or name.endswith("n2.w"):
+                arena.w(name).fill_(1.0)
+    params.train.sync_master_from_w16()
+    eng = Engine(cfg, ops, params)
+    ref = params.train.clone_weights_only()
+    core = GRPOCore(eng, ref, G, C, beta=0.04, use_grpo=True, seed=1, rope_index_mode="hf4")
+    from time_r1_amd.optim import AdamWFlat
+    opt = AdamWFlat(params, ops, lr=1e-6)
+    v = cfg.vision
+    ph = {"preprocess": 0.0, "vision": 0.0, "rollout": 0.0, "logps": 0.0, "backward": 0.0}
+    toks = 0
+    for i in range(n_prompts):
+        ids, _, g = synthetic_prompt(cfg, grid, 64, 64, seed=i)
+        frames = torch.randint(0, 256, (8, 3) + SRC_HW, generator=torch.Generator().manual_seed(7 + i), dtype=torch.uint8)
+        t0 = time.time(); pix, gg = ops.video_preprocess(frames, VP.video_target_size(VIDEO_ELE, 8, *SRC_HW), v.patch_dim_padded); ph["preprocess"] += time.time() - t0
+        t0 = time.time(); st = core.prepare(ids, pix[:, : v.patch_dim], g); ph["vision"] += time.time() - t0
+        t0 = time.time(); core.rollout(st); ph["rollout"] += time.time() - t0
+        t0 = time.time(); core.forward_logps(st); ph["logps"] += time.time() - t0
+        mask = torch.ones(G, C, dtype=torch.int32)
+        t0 = time.time(); core.loss_backward(st, mask, torch.linspace(-1, 1, G), 1.0); ph["backward"] += time.time() - t0
+        toks += G * C
+    t0 = time.time(); opt.step(); t_opt = time.time() - t0
+    per = sum(ph.values()) / n_prompts + t_opt / 2.0          # gradient_accumulation_steps = 2: half an optimizer step per micro-step
+    return {"value": 1.0 / per, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "generated_tokens_per_sec": toks / ph["rollout"],
+            "sample": "BASELINE configs[0] measured, not extrapolated: Qwen2-VL-2B full depth, 8 frames (grid %s), G=4, C=64, beta=0.04, fp32 CPU oracle ops, "
+                      "%d prompt(s); seconds per prompt by phase %s, optimizer step %.1f s (amortised over GA=2); %.0f s of CPU work in total"
+                      % (str(grid), n_prompts, {k: round(x / n_prompts, 1) for k, x in ph.items()}, t_opt, time.time() - t_all),
+            "seconds_per_sample": per}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,6 +383,8 @@ def parse_args(argv=None):
     ap.add_argument("--clip-loss", action="store_true", help="PPO-clip branch (use_grpo=False) instead of the sequence-mean GRPO loss")
     ap.add_argument("--n-prompts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-config1", action="store_true", help="only time BASELINE configs[0] (2B, 8 frames, G=4, C=64) on the host cores with the CPU oracle and print it")
+    ap.add_argument("--cpu-config1-prompts", type=int, default=1)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-peak-probe", action="store_true")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
@@ -370,6 +421,9 @@ def resolve_launch(args, env, device_count):
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.cpu_config1:
+        print(json.dumps({"metric": "grpo_samples_per_sec", "config": {"workload": "BASELINE configs[0], CPU only"}, "cpu_baseline": cpu_config1(args.cpu_config1_prompts)}))
+        return
     mode, cmd = resolve_launch(args, os.environ, torch.cuda.device_count())
     if mode == "spawn":
         import subprocess

@@ -9,6 +9,7 @@
 //   lane (u, g) of a 16-row weight fragment loads W[row u][k0 + h*64 + g*16 .. +16] (h = 0, 1) and splits it into two bf16x8 MFMA operands
 //   (bytes 0-7, bytes 8-15); the activation fragments are loaded from the same k positions, so any k permutation cancels.
 #include "tr1_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
@@ -343,6 +344,169 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16
     }
 }
 
+// ------------------------------------------------------------------------------------------------ W8A8, LDS-streamed gate/up (M <= 16)
+// The fp8 twin of norm_glu_lds_kernel (gemm.hip): weights travel HBM -> LDS in full 128-byte row runs (global_load_lds, 8 rows per wave
+// instruction) - with 1-byte codes a run is 128 k = exactly one 16x16x128 MFMA step; each of the NW waves owns a K/NW = 512-wide slice
+// (4 stages), its own ring of R stages and a counted vmcnt, no barrier in the stream.  A block is persistent over a range of 16-column
+// pairs (16 gate rows + 16 up rows): the block-quantised activation fragments x' = e4m3(x * lnw / 2^E) of the wave's k-slice and their
+// E8M0 scales are built ONCE and stay in registers (4 x (8 + 1) VGPRs), sum x^2 once per block.  Stage image, swizzle (keyA8 on the DMA's
+// SOURCE address) and the two ds_read_b128 per operand are those of the bf16 kernel: chunk h*4 + g of row u = the lane's half h.
+typedef const __attribute__((address_space(1))) void* w8_gptr_t;
+typedef __attribute__((address_space(3))) void* w8_lptr_t;
+TR1_DEV int keyA8(int row) { return (row >> 1) & 7; }
+#define W8_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int NW, int R>
+__global__ __launch_bounds__(NW * 64) void norm_glu_lds_f8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const unsigned char* __restrict__ W,
+                                                                  const float* __restrict__ wscale, bf16_t* __restrict__ C, int M, int64_t N, int64_t K,
+                                                                  int64_t ldx, int64_t ldw, int64_t ldc, float eps, int64_t up_off) {
+    constexpr int NST = 4, STAGE = 4096, REDW = 2 * 16 * 17;
+    extern __shared__ __attribute__((aligned(16))) char glu8_lds[];       // red[2][NW][REDW] f32 | ssq[NW][16] | [NW waves][R stages][4 KiB]
+    float* red = reinterpret_cast<float*>(glu8_lds);
+    float* ssq = red + 2 * NW * REDW;
+    char* rings = glu8_lds + (2 * NW * REDW + NW * 16) * sizeof(float);
+    static_assert(((2 * NW * REDW + NW * 16) * sizeof(float)) % 16 == 0 && (2 * NW * REDW + NW * 16) * sizeof(float) >= 3 * 128, "ring base");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    const int64_t NP = (N + 15) / 16;
+    const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
+    const int npair = (int)(p1 - p0);
+    const int64_t kb = (int64_t)wave * 512;
+    char* ring = rings + wave * R * STAGE;
+    const int total = npair * NST;
+    const unsigned char* pg[2]; const unsigned char* pu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        pg[j] = W + (p0 * 16 + r) * ldw + kb + (((lane & 7) ^ keyA8(r)) << 4);
+        pu[j] = pg[j] + up_off * ldw;
+    }
+    const int64_t pair_step = 16 * ldw;
+    int islot = 0;
+#define G8_ISSUE(ST) do {                                                                                                \
+        char* dst__ = ring + islot * STAGE - (ST) * 128;   /* the instruction offset is added to the LDS address as well */  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            __builtin_amdgcn_global_load_lds((w8_gptr_t)pg[j], (w8_lptr_t)(dst__ + j * 1024), 16, (ST) * 128, 2);        \
+            __builtin_amdgcn_global_load_lds((w8_gptr_t)pu[j], (w8_lptr_t)(dst__ + 2048 + j * 1024), 16, (ST) * 128, 2); \
+        }                                                                                                                \
+        islot = (islot + 1 == R) ? 0 : islot + 1;                                                                        \
+    } while (0)
+#define G8_ISSUE_ST(ST) do { switch (ST) { case 0: G8_ISSUE(0); break; case 1: G8_ISSUE(1); break; case 2: G8_ISSUE(2); break; default: G8_ISSUE(3); break; } } while (0)
+#define G8_NEXT_PAIR() do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { pg[j] += pair_step; pu[j] += pair_step; } } while (0)
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) {
+        if (i < total) {
+            if (i > 0 && i % NST == 0) G8_NEXT_PAIR();
+            G8_ISSUE_ST(i % NST);
+        }
+    }
+    // ---- block-quantised activation fragments of this wave's k-slice (once per block), built behind the first weight stages
+    i32x8_t xq[NST]; int xs[NST];
+    {
+        float ss = 0.f;
+        const int partner = lane ^ 16, src_lane = u + 16 * (2 * (g & 1));
+        const bf16_t* xp = X + (int64_t)(u < M ? u : M - 1) * ldx + kb + g * 16;
+        const bf16_t* lp = lnw + kb + g * 16;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            float v[2][16], am[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                am[h] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xp + st * 128 + h * 64 + j * 8), lv = *reinterpret_cast<const u32x4_t*>(lp + st * 128 + h * 64 + j * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = bflo(xv[e]), b = bfhi(xv[e]);
+                        ss = fmaf(a, a, fmaf(b, b, ss));
+                        a *= bflo(lv[e]); b *= bfhi(lv[e]);
+                        v[h][j * 8 + 2 * e] = a; v[h][j * 8 + 2 * e + 1] = b;
+                        am[h] = fmaxf(am[h], fmaxf(fabsf(a), fabsf(b)));
+                    }
+                }
+                am[h] = fmaxf(am[h], __shfl(am[h], partner, 64));
+            }
+            int eb[2]; float mul[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int be = (int)(__float_as_uint(am[h]) >> 23);
+                const bool tiny = be < 8;
+                eb[h] = tiny ? 0 : be - 7;
+                mul[h] = tiny ? 0.f : __uint_as_float((unsigned)(261 - be) << 23);
+            }
+            int o0[4], o1[4];
+            quant16_fp8(v[0], mul[0], o0);
+            quant16_fp8(v[1], mul[1], o1);
+            xq[st] = (i32x8_t){o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+            const int both = __shfl(eb[0] | (eb[1] << 8), src_lane, 64);
+            xs[st] = (g >> 1) ? (both >> 8) & 0xff : both & 0xff;
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (g == 0) ssq[wave * 16 + u] = ss;
+    }
+    W8_BARRIER();
+    float rstd;
+    {
+        float sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sq += ssq[w * 16 + ((threadIdx.x >> 4) & 15)];
+        rstd = rsqrtf(sq * (1.f / (float)K) + eps);
+    }
+    const int rd_off = u * 128;
+    const int kA = keyA8(u);
+    int cslot = 0;
+    for (int pi = 0; pi < npair; ++pi) {
+        f32x4_t ag = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int item = pi * NST + st;
+            if (item + R - 1 < total) {
+                if ((st + R - 1) % NST == 0) G8_NEXT_PAIR();
+                G8_ISSUE_ST((st + R - 1) % NST);
+            }
+            const int rem = total - 1 - item;
+            if (rem >= R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (R - 1)) : "memory");
+            else if (rem == 2 && R > 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1 && R > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* sb = ring + cslot * STAGE + rd_off;
+            cslot = (cslot + 1 == R) ? 0 : cslot + 1;
+            const u32x4_t g0 = *reinterpret_cast<const u32x4_t*>(sb + ((g ^ kA) << 4)), g1 = *reinterpret_cast<const u32x4_t*>(sb + (((4 + g) ^ kA) << 4));
+            const u32x4_t u0 = *reinterpret_cast<const u32x4_t*>(sb + 2048 + ((g ^ kA) << 4)), u1 = *reinterpret_cast<const u32x4_t*>(sb + 2048 + (((4 + g) ^ kA) << 4));
+            const i32x8_t wg = {(int)g0[0], (int)g0[1], (int)g0[2], (int)g0[3], (int)g1[0], (int)g1[1], (int)g1[2], (int)g1[3]};
+            const i32x8_t wu = {(int)u0[0], (int)u0[1], (int)u0[2], (int)u0[3], (int)u1[0], (int)u1[1], (int)u1[2], (int)u1[3]};
+            ag = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wg, xq[st], ag, 0, 0, 0, 127, 0, xs[st]);
+            au = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wu, xq[st], au, 0, 0, 0, 127, 0, xs[st]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        float* rw = red + ((pi & 1) * NW + wave) * REDW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rw[u * 17 + g * 4 + r] = ag[r];
+            rw[16 * 17 + u * 17 + g * 4 + r] = au[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W8_BARRIER();
+        if (threadIdx.x < 256) {
+            const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
+            const float* rb = red + (pi & 1) * NW * REDW;
+            float v = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { v += rb[w * REDW + mm * 17 + nn]; v2 += rb[w * REDW + 16 * 17 + mm * 17 + nn]; }
+            const int64_t n = (p0 + pi) * 16 + nn;
+            if (mm < M && n < N) {
+                v *= rstd * wscale[n];
+                const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd * wscale[up_off + n]));
+                C[(int64_t)mm * ldc + n] = f2bf(bf2f(f2bf(silu_w8(gt))) * up);
+            }
+        }
+    }
+#undef G8_ISSUE
+#undef G8_ISSUE_ST
+#undef G8_NEXT_PAIR
+}
+
 // Per-row symmetric quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = fp8_e4m3(w * (448 / amax_n)), round to nearest even.
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ w, unsigned char* __restrict__ q, float* __restrict__ scale,
                                                              int64_t K, int64_t ldw, int64_t ldq) {
@@ -467,6 +631,32 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
     }
     // column groups per block: the activations are re-read from L2 by every block, and with fp8 weights they are as many bytes as a
     // 2-group weight slab - 4 groups halve that traffic (measured, M = 16: lm_head 168 -> 140 us)
+    {   // gate/up at <= 16 rows, hidden 3584 / 2048 / 1536: the LDS-streamed form (TR1_W8_GLU_LDS=0: register-fragment form, A/B runs)
+        static int glu_lds = -1;
+        if (glu_lds < 0) { const char* e = getenv("TR1_W8_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
+        const int64_t nw = K / 512;
+        if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nw == 7 || nw == 4 || nw == 3) && N % 16 == 0) {
+            constexpr int RING = 3;
+            static int n_cu = 0;
+            const size_t dyn = (size_t)nw * RING * 4096 + (2 * nw * 2 * 16 * 17 + nw * 16) * sizeof(float);
+            if (!n_cu) {
+                hipDeviceProp_t prop; int dev = 0;
+                hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
+                n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+                const int mx = 7 * RING * 4096 + (2 * 7 * 2 * 16 * 17 + 7 * 16) * (int)sizeof(float);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_f8_kernel<7, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_f8_kernel<4, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_f8_kernel<3, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            }
+            const int64_t NP = N / 16;
+            const unsigned grid = (unsigned)(NP < n_cu ? NP : n_cu);
+#define G8L(NWV) hipLaunchKernelGGL((norm_glu_lds_f8_kernel<NWV, RING>), dim3(grid), dim3(NWV * 64), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, \
+                                    (const unsigned char*)W_fp8, (const float*)wscale, (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N)
+            if (nw == 7) G8L(7); else if (nw == 4) G8L(4); else G8L(3);
+#undef G8L
+            TR1_LAUNCH_CHECK();
+        }
+    }
     if (glu) { if (mg == 1) W8(4, 2, 4, 1, true, true); else if (mg == 2) W8(4, 2, 4, 2, true, true); else W8(4, 1, 2, 4, true, true); }
     else if (lnw && N >= 100000) { if (mg == 1) W8(4, 2, 4, 1, true, false); else if (mg == 2) W8(4, 2, 4, 2, true, false); else W8(4, 1, 2, 4, true, false); }
     else if (lnw) W8_MG(4, 2, 2, true, false);
