@@ -132,6 +132,8 @@ int tr1_gemm_skinny_w8(const void* x, const void* lnw, const void* W_fp8, const 
  * v_mfma_scale_f32_16x16x128_f8f6f4 directly and the activations (after the optional rmsnorm weight) are quantised in the operand load to
  * e4m3 with one power-of-two (E8M0) scale per row and per 32 consecutive k (OCP microscaling); weight row scale in the epilogue. */
 int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* W_fp8, const void* wscale, const void* bias, const void* residual, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, float eps, int glu, void* stream);
+/* W8A8 split-K + in-kernel fixup form (decode down projection, M <= 16, K % 512 == 0, N % 64 == 0); workspace as tr1_gemm_skinny_fixup. */
+int tr1_gemm_skinny_fixup_w8a8(const void* x, const void* W_fp8, const void* wscale, void* out, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream);
 
 /* ---- native decode-step driver ------------------------------------------------------------------------------------------------ */
 /* One call enqueues a whole rollout decode step for R <= 64 rows: embed gather -> n_layers x {norm+qkv, rope + KV append, split-KV attention,

@@ -487,7 +487,7 @@ def test_quantize_fp8_rows_bit_exact(hip_ops, ref_ops, N, K):
                                         # full-width 7B decode shapes: lm_head over V = 152064 and the gate/up projection
                                         (16, 152064, 3584, "norm"), (16, 18944, 3584, "glu"),
                                         # LDS-streamed fp8 gate/up (a8, M <= 16, hidden 3584 / 2048 / 1536): ragged rows, fewer pairs than CUs
-                                        (5, 18944, 3584, "glu"), (16, 8960, 1536, "glu"), (9, 4112, 1536, "glu"), (16, 11008, 2048, "glu"), (1, 48, 3584, "glu")])
+                                        (5, 18944, 3584, "glu"), (7, 3584, 18944, "res"), (16, 8960, 1536, "glu"), (9, 4112, 1536, "glu"), (16, 11008, 2048, "glu"), (1, 48, 3584, "glu")])
 @pytest.mark.parametrize("a8", [False, True])
 def test_gemm_w8(hip_ops, ref_ops, M, N, K, mode, a8):
     """fp8-weight decode GEMM vs the oracle on the SAME quantised weights.  a8=False: register dequantisation + bf16 MFMA (W8A16);

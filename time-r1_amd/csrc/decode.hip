@@ -54,6 +54,7 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     const int64_t fix_floats = tr1_gemm_skinny_fixup_workspace_floats(R, hid, inter);
     void* fix = c.take(fix_floats * 4);
     const bool down_fixup = !w8 && R >= 16 && inter >= 8192;
+    const bool down_fixup8 = w8 == 2 && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
     TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");
     const void* const* lp = (const void* const*)layer_ptrs;
     const int stride = w8 ? 13 : 9;
@@ -80,7 +81,8 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
         else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
         if (w8) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
         else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
-        if (w8) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
+        if (w8 == 2 && down_fixup8) CK(tr1_gemm_skinny_fixup_w8a8(a, w[6], w[12], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
+        else if (w8) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
         else if (down_fixup) CK(tr1_gemm_skinny_fixup(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
     }

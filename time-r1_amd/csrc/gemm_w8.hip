@@ -488,16 +488,18 @@ __global__ __launch_bounds__(NW * 64) void norm_glu_lds_f8_kernel(const bf16_t* 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W8_BARRIER();
-        if (threadIdx.x < 256) {
-            const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
+        for (int i = threadIdx.x; i < 256; i += NW * 64) {              // 256 outputs of the pair; blocks of 3 waves take two trips
+            const int mm = i >> 4, nn = i & 15;
             const float* rb = red + (pi & 1) * NW * REDW;
             float v = 0.f, v2 = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) { v += rb[w * REDW + mm * 17 + nn]; v2 += rb[w * REDW + 16 * 17 + mm * 17 + nn]; }
             const int64_t n = (p0 + pi) * 16 + nn;
             if (mm < M && n < N) {
-                v *= rstd * wscale[n];
-                const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd * wscale[up_off + n]));
+                float rs = rstd;
+                if (NW * 64 < 256) { float sq = 0.f; _Pragma("unroll") for (int w = 0; w < NW; ++w) sq += ssq[w * 16 + mm]; rs = rsqrtf(sq * (1.f / (float)K) + eps); }
+                v *= rs * wscale[n];
+                const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rs * wscale[up_off + n]));
                 C[(int64_t)mm * ldc + n] = f2bf(bf2f(f2bf(silu_w8(gt))) * up);
             }
         }
@@ -505,6 +507,137 @@ __global__ __launch_bounds__(NW * 64) void norm_glu_lds_f8_kernel(const bf16_t* 
 #undef G8_ISSUE
 #undef G8_ISSUE_ST
 #undef G8_NEXT_PAIR
+}
+
+// ------------------------------------------------------------------------------- W8A8, LDS-streamed split-K + fixup projection (M <= 16)
+// The fp8 twin of gemm_skinny_lds_fix_kernel (gemm.hip; decode down projection: N = 3584 columns, K = 18944): a block owns 64 output columns
+// and one of gridDim.y K-slabs; its waves take the slab's 128-wide stages round-robin, each with a two-slot ring: 64 weight rows x 128 bytes
+// of fp8 (8 KiB) + the 16 activation rows x 128 k of bf16 (2 x 16 x 128 bytes, quantised per lane pair right before the MFMA).  The partial
+// tiles go through the same workspace and ticket protocol (the last-arriving slab sums the tiles in slab order); the weight's row scale is
+// applied once, to the summed tile.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(const bf16_t* __restrict__ X, const unsigned char* __restrict__ W,
+                                                                            const float* __restrict__ wscale, bf16_t* __restrict__ C,
+                                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int M,
+                                                                            int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr,
+                                                                            float* __restrict__ fix_ws, int* __restrict__ fix_cnt) {
+    constexpr int NC = 4, STAGE = NC * 2048 + 4096, TILE = NC * 256;
+    extern __shared__ __attribute__((aligned(16))) char sk8_lds[];         // [WAVES][2][STAGE]; afterwards red[WAVES][NC][16][17] f32; ticket at the end
+    int* s_ticket = reinterpret_cast<int*>(sk8_lds + WAVES * 2 * STAGE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * (16 * NC);
+    const int64_t kslab = K / gridDim.y, k0 = (int64_t)blockIdx.y * kslab;
+    const int nst = (int)(kslab / 128);
+    const int n_my = wave < nst ? (nst - wave + WAVES - 1) / WAVES : 0;
+    char* ring = sk8_lds + wave * 2 * STAGE;
+    const unsigned char* pw[8]; const bf16_t* px[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        int64_t row = n0 + r; if (row >= N) row = N - 1;
+        pw[j] = W + row * ldw + k0 + (int64_t)wave * 128 + (((lane & 7) ^ keyA8(r)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {            // activation stage = 32 "rows" of 128 bytes: row rho = h * 16 + m holds x[m][k + h*64 .. +64]
+        const int rho = 8 * j + (lane >> 3), m = rho & 15, h = rho >> 4;
+        px[j] = X + (int64_t)(m < M ? m : M - 1) * ldx + k0 + (int64_t)wave * 128 + h * 64 + (((lane & 7) ^ keyA8(rho)) << 3);
+    }
+#define SK8_ISSUE(SLOT) do {                                                                                              \
+        char* dst__ = ring + (SLOT) * STAGE;                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { __builtin_amdgcn_global_load_lds((w8_gptr_t)pw[j], (w8_lptr_t)(dst__ + j * 1024), 16, 0, 2); pw[j] += WAVES * 128; } \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { __builtin_amdgcn_global_load_lds((w8_gptr_t)px[j], (w8_lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 128; } \
+    } while (0)
+    f32x4_t acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int rd_w = u * 128, kA = keyA8(u);
+    const int partner = lane ^ 16, src_lane = u + 16 * (2 * (g & 1));
+    auto consume = [&](int slot) {
+        const char* sb = ring + slot * STAGE;
+        const char* xb = sb + NC * 2048;
+        float v[2][16], am[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            am[h] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xb + (h * 16 + u) * 128 + (((2 * g + j) ^ kA) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bflo(xv[e]), b = bfhi(xv[e]);
+                    v[h][j * 8 + 2 * e] = a; v[h][j * 8 + 2 * e + 1] = b;
+                    am[h] = fmaxf(am[h], fmaxf(fabsf(a), fabsf(b)));
+                }
+            }
+            am[h] = fmaxf(am[h], __shfl(am[h], partner, 64));
+        }
+        int eb[2]; float mul[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int be = (int)(__float_as_uint(am[h]) >> 23);
+            const bool tiny = be < 8;
+            eb[h] = tiny ? 0 : be - 7;
+            mul[h] = tiny ? 0.f : __uint_as_float((unsigned)(261 - be) << 23);
+        }
+        int o0[4], o1[4];
+        quant16_fp8(v[0], mul[0], o0);
+        quant16_fp8(v[1], mul[1], o1);
+        const i32x8_t xq = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+        const int both = __shfl(eb[0] | (eb[1] << 8), src_lane, 64);
+        const int xs = (g >> 1) ? (both >> 8) & 0xff : both & 0xff;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32x4_t w0 = *reinterpret_cast<const u32x4_t*>(sb + c * 2048 + rd_w + ((g ^ kA) << 4));
+            const u32x4_t w1 = *reinterpret_cast<const u32x4_t*>(sb + c * 2048 + rd_w + (((4 + g) ^ kA) << 4));
+            const i32x8_t wf = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+            acc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xq, acc[c], 0, 0, 0, 127, 0, xs);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if (n_my > 0) SK8_ISSUE(0);
+    for (int i = 0; i < n_my; i += 2) {
+        if (i + 1 < n_my) { SK8_ISSUE(1); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        consume(0);
+        if (i + 1 < n_my) {
+            if (i + 2 < n_my) { SK8_ISSUE(0); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            consume(1);
+        }
+    }
+#undef SK8_ISSUE
+    W8_BARRIER();
+    float* red = reinterpret_cast<float*>(sk8_lds);                         // [WAVES][NC][16][17]
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NC + c) * 16 + u) * 17 + g * 4 + r] = acc[c][r];
+    __syncthreads();
+    float* mine = fix_ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * TILE;
+    for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
+        const int c = i >> 8, mm = (i >> 4) & 15, nn = i & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += red[((w * NC + c) * 16 + mm) * 17 + nn];
+        __hip_atomic_store(mine + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(&fix_cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_ticket != (int)gridDim.y - 1) return;
+    for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
+        const int c = i >> 8, mm = (i >> 4) & 15, nn = i & 15;
+        const int64_t n = n0 + c * 16 + nn;
+        float v = 0.f;
+        for (int ks = 0; ks < (int)gridDim.y; ++ks)
+            v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mm < M && n < N) {
+            v *= wscale[n];
+            if (bias) v += bf2f(bias[n]);
+            if (residual) v += bf2f(residual[(int64_t)mm * ldr + n]);
+            C[(int64_t)mm * ldc + n] = f2bf(v);
+        }
+    }
+    if (threadIdx.x == 0) fix_cnt[blockIdx.x] = 0;
 }
 
 // Per-row symmetric quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = fp8_e4m3(w * (448 / amax_n)), round to nearest even.
@@ -664,5 +797,26 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
     else W8_MG(4, 2, 1, false, false);
 #undef W8_MG
 #undef W8
+    TR1_LAUNCH_CHECK();
+}
+
+// Split-K + fixup form of the W8A8 projection for M <= 16 rows and wide K (decode down projection).  Workspace = the one of
+// tr1_gemm_skinny_fixup for the same (M, N, K) (fp32 tiles + self re-arming ticket counters, zero-filled once by the caller).
+extern "C" int tr1_gemm_skinny_fixup_w8a8(const void* x, const void* W_fp8, const void* wscale, void* out, const void* bias, const void* residual,
+                                          int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr, void* ws_f32,
+                                          int64_t ws_floats, void* stream) {
+    constexpr int KS = 4, WV = 6;
+    TR1_CHECK_ARG(M >= 1 && M <= 16 && K % (KS * 128) == 0 && N % 64 == 0, "gemm_skinny_fixup_w8a8: 1 <= M <= 16, K % 512 == 0, N % 64 == 0");
+    TR1_CHECK_ARG(ldx % 8 == 0 && ldw % 16 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_skinny_fixup_w8a8: ldx%8, ldw%16, ldc%8");
+    const int64_t groups = N / 64;
+    TR1_CHECK_ARG(ws_f32 && ws_floats >= KS * groups * 4 * 256 + groups, "gemm_skinny_fixup_w8a8: workspace too small");
+    float* tiles = (float*)ws_f32;
+    int* cnt = (int*)(tiles + KS * groups * 4 * 256);
+    const size_t dyn = WV * 2 * 12288 + 16;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_f8_kernel<WV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); attr_set = true; }
+    hipLaunchKernelGGL((gemm_skinny_lds_fix_f8_kernel<WV>), dim3((unsigned)groups, KS), dim3(WV * 64), dyn, (hipStream_t)stream, (const bf16_t*)x,
+                       (const unsigned char*)W_fp8, (const float*)wscale, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, ldx,
+                       ldw, ldc, ldr, tiles, cnt);
     TR1_LAUNCH_CHECK();
 }

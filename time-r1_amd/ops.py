@@ -167,6 +167,15 @@ class HipOps:
         N = q.shape[0] // 2 if glu else q.shape[0]
         assert q.dtype == torch.uint8 and q.shape[1] == K and x.stride(1) == 1 and q.stride(1) == 1 and scale.dtype == F32
         out = self.empty(M, N)
+        if a8 and lnw is None and not glu and M <= 16 and K >= 8192 and K % 512 == 0 and N % 64 == 0:     # same choice as csrc/decode.hip (bitwise-equal paths)
+            n = int(self.L.raw("tr1_gemm_skinny_fixup_workspace_floats")(M, N, K))
+            key = "skinny_fix8_%d_%d_%d" % (M, N, K)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.zeros(n, dtype=F32, device=self.device)
+            self.L.call("tr1_gemm_skinny_fixup_w8a8", _p(x), _p(q), _p(scale), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), q.stride(0), N,
+                        residual.stride(0) if residual is not None else 0, _p(ws), n, self._s())
+            return out
         self.L.call("tr1_gemm_skinny_w8a8" if a8 else "tr1_gemm_skinny_w8", _p(x), _p(lnw), _p(q), _p(scale), _p(bias), _p(residual), _p(out), M, N, K, x.stride(0), q.stride(0), N,
                     residual.stride(0) if residual is not None else 0, float(eps), int(glu), self._s())
         return out
