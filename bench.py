@@ -101,8 +101,15 @@ class Workload:
     def _finish(self, st, last, mark, n_in_window):
         """Policy / reference log-probs, host rewards, loss gradient and backward of one prompt."""
         a, core = self.args, self.core
-        core.forward_logps(st)          # enqueued asynchronously; the host work below overlaps with it
-        toks_host = st.completion_ids.cpu().numpy()
+        # the sampled tokens come to the host BEFORE the log-prob forwards are enqueued (a copy on the same stream waits for everything
+        # queued in front of it): the decode / reward / advantage work below then runs on the host WHILE the GPU computes the log-probs
+        toks_host = getattr(st, "completion_ids_host", None)
+        late = toks_host is None and os.environ.get("TR1_BENCH_TOKENS_LATE") == "1"
+        if toks_host is None and not late:
+            toks_host = st.completion_ids.cpu().numpy()
+        core.forward_logps(st)
+        if late:
+            toks_host = st.completion_ids.cpu().numpy()
         completions = [fake_decode(r) for r in toks_host]
         mask = eos_mask(toks_host, self.cfg.eos_token_id)
         rew = torch.zeros(a.G, len(self.reward_funcs))
@@ -153,6 +160,9 @@ class Workload:
         else:
             states = [prepare(j) for j in range(n)]
             core.rollout_many(states)
+            if os.environ.get("TR1_BENCH_TOKENS_LATE") != "1":                 # (A/B switch: the round-1 order fetched them after enqueuing the forwards)
+                for st in states:
+                    st.completion_ids_host = st.completion_ids.cpu().numpy()     # one wait for the decode loop, ahead of every update
             mark("rollout")
             for si, st in enumerate(states):
                 self._finish(st, si == n - 1, mark, n)

@@ -387,8 +387,12 @@ class TimeR1_Trainer:
         inputs, st, prompts = ctx["inputs"], ctx["st"], ctx["prompts"]
         G = self.num_generations
         tokens = st.completion_ids
-        self.core.forward_logps(st)                           # enqueued; the host work below overlaps with it on the GPU
-        comp_host = tokens.cpu().numpy()
+        # tokens first, THEN the log-prob forwards: a device-to-host copy waits for everything queued before it on the stream, so in this
+        # order the host decodes / scores / normalises while the GPU is busy with the policy and reference forwards
+        comp_host = getattr(st, "completion_ids_host", None)
+        if comp_host is None:
+            comp_host = tokens.cpu().numpy()
+        self.core.forward_logps(st)
         mask_np = eos_mask(comp_host, self.processing_class.eos_token_id)
         completions = self.processing_class.batch_decode(torch.as_tensor(comp_host), skip_special_tokens=True)
         prompts_rep = [p for p in prompts for _ in range(G)]
@@ -459,6 +463,8 @@ class TimeR1_Trainer:
             self.core.rollout_many(todo)
         elif todo:
             self.core.rollout(todo[0])
+        for st in todo:
+            st.completion_ids_host = st.completion_ids.cpu().numpy()        # one wait for the decode loop, ahead of every update
         return [self._step_finish(c, last_in_window=(i == len(ctxs) - 1)) for i, c in enumerate(ctxs)]
 
     # ------------------------------------------------------------------------------------------------------ training loop
