@@ -26,6 +26,7 @@ class AdamWFlat:
         else:
             self.sync = GradSync(params.train.grad, self.dp, wire_dtype=grad_wire_dtype)
         self._sumsq = ops.zeros(1, dtype=torch.float32)
+        self._send = None
 
     def step(self, lr=None):
         """Averages grads across ranks, clips by global norm, applies AdamW, refreshes the bf16 working weights, zeroes grads.
@@ -62,12 +63,14 @@ class AdamWFlat:
         self.step_count += 1
         a.version = getattr(a, "version", 0) + 1
         works = []
+        if self._send is None:          # the updated bf16 chunks are sent from their own buffer (1/world of the arena), not from inside the gather's
+            self._send = torch.empty(a.numel // W, dtype=a.w16.dtype, device=a.w16.device)       # output: no aliasing between send and receive views
         for (_, sa, sb), (ca, cb, la) in zip(a.segments, a.chunks()):
             n = cb - ca
-            ops.adamw_step(a.master[la:la + n], a.m[la:la + n], a.v[la:la + n], g[la:la + n], a.w16[ca:cb], self.lr if lr is None else lr,
+            ops.adamw_step(a.master[la:la + n], a.m[la:la + n], a.v[la:la + n], g[la:la + n], self._send[la:la + n], self.lr if lr is None else lr,
                            self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm,
                            grad_mult=mult, zero_grad=False)
-            works.append(dist.all_gather_into_tensor(a.w16[sa:sb], a.w16[ca:cb], async_op=True))
+            works.append(dist.all_gather_into_tensor(a.w16[sa:sb], self._send[la:la + n], async_op=True))
         a.grad.zero_()                  # the full fp32 accumulator (the fused kernel only sees the reduced shard)
         for w in works:
             w.wait()
