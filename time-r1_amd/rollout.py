@@ -7,6 +7,8 @@ each decode step is a batch of single-token rows whose GEMMs take the HBM-stream
 bound, so the prompts of one gradient-accumulation window (weights are constant inside it) are decoded TOGETHER: with GA = 2 and
 G = 8 every weight byte read from HBM serves 16 rows instead of 8.  Attention stays per prompt (own prefix, own KV cache).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -119,6 +121,8 @@ class Rollout:
             slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
             pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
             nsplit = max(1, min(28, ((P + 63) // 64 + 3) // 2))
+            if os.environ.get("TR1_DECODE_NSPLIT"):          # tuning hook (A/B runs)
+                nsplit = int(os.environ["TR1_DECODE_NSPLIT"])
             per.append(dict(lay=lay, kv=kv_views, prefill_ctx=pctx, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
         cos_all = torch.cat(cos_rows, 1).contiguous()      # [C, B*G, half]
         sin_all = torch.cat(sin_rows, 1).contiguous()
