@@ -43,7 +43,8 @@ def _worker(rank, world, port, q, wire):
     gathered = tr.dp.gather(torch.tensor([float(rank)]))
     tr.optimizer.step()
     assert not tr.optimizer.sync.active
-    q.put((rank, tr.params.train.master.clone(), gathered.tolist(), dict(tr._metrics)))
+    # numpy (pickled by value): torch tensors travel through shared-memory handles that die with a worker that exits before the parent reads
+    q.put((rank, tr.params.train.master.numpy().copy(), gathered.tolist(), dict(tr._metrics)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,6 +67,7 @@ def test_two_rank_step_equals_single_process_average(wire):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = [(r[0], torch.from_numpy(r[1]), r[2], r[3]) for r in res]
     assert torch.equal(res[0][1], res[1][1]), "ranks must hold identical weights after the averaged step"
     assert res[0][2] == [0.0, 1.0]
     # metrics are means over the gathered (all-rank) values, like accelerator.gather_for_metrics
@@ -118,7 +120,7 @@ def _worker_sharded(rank, world, port, q, wire, shard):
         dist.all_reduce(master_full)          # chunks of different ranks are disjoint
     else:
         master_full.copy_(a.master)
-    q.put((rank, a.w16.clone(), master_full, norms))
+    q.put((rank, a.w16.float().numpy().copy(), master_full.numpy().copy(), norms))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -137,7 +139,7 @@ def _spawn2(target, *extra):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return res
+    return [tuple(torch.from_numpy(x) if hasattr(x, "dtype") and not torch.is_tensor(x) else x for x in r) for r in res]
 
 
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
