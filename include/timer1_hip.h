@@ -174,6 +174,10 @@ int64_t tr1_sample_workspace_words(int64_t rows);
 /* ref: DeepSpeed FusedAdam / DeepSpeedCPUAdam selected by scripts/zero3.json:13-21 and zero3_offload.json:24-31 (AdamW, clip 1.0) */
 int tr1_sumsq_accum(const void* g, int64_t n, void* out_scalar, void* stream);
 int tr1_adamw_step(void* p_f32, void* m_f32, void* v_f32, void* g_f32, void* p_bf16, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const void* sumsq_scalar, float max_norm, float grad_mult, int zero_grad, void* stream);
+/* Data-parallel forms: the all-reduced gradient is consumed from its bf16 wire buffer (no copy back into the fp32 accumulator, which is only
+ * zeroed).  ref: DeepSpeed's bf16 gradient all-reduce + FusedAdam (scripts/zero3.json:13-33). */
+int tr1_adamw_step_g16(void* p_f32, void* m_f32, void* v_f32, void* g_f32, const void* g_bf16, void* p_bf16, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const void* sumsq_scalar, float max_norm, float grad_mult, int zero_grad, void* stream);
+int tr1_sumsq_accum_bf16(const void* g_bf16, int64_t n, void* out_scalar, void* stream);
 
 #ifdef __cplusplus
 }

@@ -454,7 +454,10 @@ class RefOps:
         out_scalar += (g.double() ** 2).sum().float()
 
     def adamw_step(self, p32, m, v, g, p16, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0, grad_mult=1.0,
-                   zero_grad=True):
+                   zero_grad=True, g16=None):
+        g_acc = g
+        if g16 is not None:
+            g = g16.float()
         coef = grad_mult
         if sumsq is not None and max_norm > 0:
             norm = float(sumsq.sqrt()) * grad_mult
@@ -469,4 +472,4 @@ class RefOps:
         p32.addcdiv_(m, denom, value=-lr / bc1)
         p16.copy_(p32.to(p16.dtype))
         if zero_grad:
-            g.zero_()
+            g_acc.zero_()

@@ -360,6 +360,27 @@ def test_adamw_and_clip(hip_ops, ref_ops):
     close(st_h[0], pt.detach(), 1e-6, rtol=1e-5, what="adamw vs torch.optim.AdamW")
 
 
+def test_adamw_reads_bf16_wire_gradient(hip_ops):
+    """Data-parallel form: norm and update consume the all-reduced gradient from its bf16 wire buffer; bit-equal to copying it back into the
+    fp32 accumulator first (bf16 -> fp32 is exact), and the accumulator is zeroed without being read."""
+    n = 100003
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g)
+    wire = (torch.randn(n, generator=g) * 2).to(BF16).cuda()
+    outs = []
+    for use16 in (False, True):
+        st = [p.clone().cuda(), torch.zeros(n, device="cuda:0"), torch.zeros(n, device="cuda:0"), torch.zeros(n, dtype=BF16, device="cuda:0")]
+        acc = (wire.float() if not use16 else torch.full((n,), 7.0, device="cuda:0"))      # use16: garbage in the accumulator must not matter
+        ss = torch.zeros(1, device="cuda:0")
+        hip_ops.sumsq_accum(wire if use16 else acc, ss)
+        hip_ops.adamw_step(st[0], st[1], st[2], acc, st[3], 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, sumsq=ss, max_norm=1.0, grad_mult=0.25, g16=wire if use16 else None)
+        assert float(acc.abs().max()) == 0.0
+        outs.append((ss.cpu(), [t.clone().cpu() for t in st]))
+    assert abs(float(outs[0][0]) - float(outs[1][0])) <= 1e-6 * float(outs[0][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.allclose(a.float(), b.float(), atol=1e-7, rtol=1e-6)
+
+
 def test_decode_qkv_post(hip_ops, ref_ops):
     """Fused decode post-projection == rope(q), rope(k) -> K cache rows, v -> V^T cache columns."""
     R, nh, nkv, hd, S = 16, 14, 2, 128, 512

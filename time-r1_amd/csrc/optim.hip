@@ -29,12 +29,29 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// the same sum over a bf16 array (data-parallel runs: the all-reduced gradient stays in its bf16 wire buffer and is consumed from there)
+__global__ __launch_bounds__(256) void sumsq_bf16_kernel(const bf16_t* __restrict__ g, int64_t n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const int64_t n8 = n >> 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4_t v = OPT_LD(reinterpret_cast<const u32x4_t*>(g) + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = bflo(v[e]), b = bfhi(v[e]); s += a * a + b * b; }
+    }
+    if (blockIdx.x == 0) for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) { const float a = bf2f(g[i]); s += a * a; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
 // sumsq: device scalar with sum of squared grads (already multiplied by nothing); clip coefficient derived in-kernel so the
 // step needs no host round trip:  coef = grad_mult * min(1, max_norm / (grad_mult*sqrt(sumsq) + 1e-6)).
+// G16: the gradient is read from a bf16 array `g16` (the all-reduced wire buffer); `g` (fp32 accumulator) is then only zeroed, never read.
+template <bool G16>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ g,
                                                     bf16_t* __restrict__ p16, int64_t n, float lr, float beta1, float beta2, float eps,
                                                     float wd, float bc1, float bc2_sqrt, const float* __restrict__ sumsq, float max_norm,
-                                                    float grad_mult, int zero_grad) {
+                                                    float grad_mult, int zero_grad, const bf16_t* __restrict__ g16) {
     float coef = grad_mult;
     if (sumsq && max_norm > 0.f) {
         const float norm = sqrtf(*sumsq) * grad_mult;
@@ -43,7 +60,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4_t pv = OPT_LD(reinterpret_cast<f32x4_t*>(p) + i), mv = OPT_LD(reinterpret_cast<f32x4_t*>(m) + i), vv = OPT_LD(reinterpret_cast<f32x4_t*>(v) + i);
-        const f32x4_t gv = OPT_LD(reinterpret_cast<f32x4_t*>(g) + i);
+        f32x4_t gv;
+        if (G16) { const u32x2_t w = OPT_LD(reinterpret_cast<const u32x2_t*>(g16) + i); gv = (f32x4_t){bflo(w[0]), bfhi(w[0]), bflo(w[1]), bfhi(w[1])}; }
+        else gv = OPT_LD(reinterpret_cast<f32x4_t*>(g) + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float gg = gv[j] * coef;
@@ -60,7 +79,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
     if (blockIdx.x == 0) {
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
-            const float gg = g[i] * coef;
+            const float gg = (G16 ? bf2f(g16[i]) : g[i]) * coef;
             float pv = p[i] * (1.f - lr * wd);
             const float mv = beta1 * m[i] + (1.f - beta1) * gg, vv = beta2 * v[i] + (1.f - beta2) * gg * gg;
             pv -= (lr / bc1) * (mv / (sqrtf(vv) / bc2_sqrt + eps));
@@ -83,8 +102,29 @@ extern "C" int tr1_adamw_step(void* p_f32, void* m_f32, void* v_f32, void* g_f32
     if (n == 0) return 0;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(tr1_grid_1d(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (float*)p_f32, (float*)m_f32,
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(tr1_grid_1d(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (float*)p_f32, (float*)m_f32,
                        (float*)v_f32, (float*)g_f32, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
-                       (const float*)sumsq_scalar, max_norm, grad_mult, zero_grad);
+                       (const float*)sumsq_scalar, max_norm, grad_mult, zero_grad, (const bf16_t*)nullptr);
+    TR1_LAUNCH_CHECK();
+}
+
+// Data-parallel form: the gradient SUM over ranks is read from the bf16 wire buffer `g_bf16` (no bf16 -> fp32 copy-back pass); the fp32
+// accumulator `g_f32` is only zeroed (zero_grad) for the next window.
+extern "C" int tr1_adamw_step_g16(void* p_f32, void* m_f32, void* v_f32, void* g_f32, const void* g_bf16, void* p_bf16, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int64_t step, const void* sumsq_scalar, float max_norm, float grad_mult,
+                                  int zero_grad, void* stream) {
+    TR1_CHECK_ARG(step >= 1 && g_bf16, "adamw_g16: step counts from 1, bf16 gradient required");
+    if (n == 0) return 0;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(tr1_grid_1d(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (float*)p_f32, (float*)m_f32,
+                       (float*)v_f32, (float*)g_f32, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
+                       (const float*)sumsq_scalar, max_norm, grad_mult, zero_grad, (const bf16_t*)g_bf16);
+    TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_sumsq_accum_bf16(const void* g_bf16, int64_t n, void* out_scalar, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sumsq_bf16_kernel, dim3(tr1_grid_1d(n / 8 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g_bf16, n, (float*)out_scalar);
     TR1_LAUNCH_CHECK();
 }

@@ -522,13 +522,19 @@ class HipOps:
 
     # ---- optimizer ------------------------------------------------------------------------------------------------
     def sumsq_accum(self, g, out_scalar):
-        assert g.dtype == F32 and out_scalar.dtype == F32
-        self.L.call("tr1_sumsq_accum", _p(g), g.numel(), _p(out_scalar), self._s())
+        assert g.dtype in (F32, BF16) and out_scalar.dtype == F32
+        self.L.call("tr1_sumsq_accum" if g.dtype == F32 else "tr1_sumsq_accum_bf16", _p(g), g.numel(), _p(out_scalar), self._s())
 
     def adamw_step(self, p32, m, v, g, p16, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0, grad_mult=1.0,
-                   zero_grad=True):
+                   zero_grad=True, g16=None):
+        """g16: read the gradient from this bf16 array instead of `g` (the all-reduced wire buffer); `g` is then only zeroed."""
         assert p32.dtype == F32 and m.dtype == F32 and v.dtype == F32 and g.dtype == F32 and p16.dtype == BF16
         n = p32.numel()
         assert m.numel() == n and v.numel() == n and g.numel() == n and p16.numel() == n
+        if g16 is not None:
+            assert g16.dtype == BF16 and g16.numel() == n
+            self.L.call("tr1_adamw_step_g16", _p(p32), _p(m), _p(v), _p(g), _p(g16), _p(p16), n, float(lr), float(beta1), float(beta2), float(eps),
+                        float(weight_decay), int(step), _p(sumsq), float(max_norm), float(grad_mult), int(zero_grad), self._s())
+            return
         self.L.call("tr1_adamw_step", _p(p32), _p(m), _p(v), _p(g), _p(p16), n, float(lr), float(beta1), float(beta2), float(eps),
                     float(weight_decay), int(step), _p(sumsq), float(max_norm), float(grad_mult), int(zero_grad), self._s())

@@ -36,14 +36,18 @@ class AdamWFlat:
             return self._step_sharded(lr)
         if self.dp.enabled and not self.sync.active:
             self.sync.begin()           # nobody overlapped the exchange with backward: reduce everything now
-        self.sync.finish()              # grad arena now holds the SUM over ranks; the mean is folded into grad_mult
+        # bf16 wire: the SUM over ranks stays in the wire buffer and norm + AdamW read it there (no copy back into the fp32 accumulator, which
+        # the fused kernel only zeroes); fp32 wire / single process: the accumulator itself.  The mean is folded into grad_mult.
+        g16 = self.sync.stage if (self.dp.enabled and self.sync.stage is not None) else None
+        self.sync.finish(copy_back=g16 is None)
         mult = 1.0 / self.dp.world
         self._sumsq.zero_()
-        self.ops.sumsq_accum(a.grad, self._sumsq)
+        self.ops.sumsq_accum(a.grad if g16 is None else g16, self._sumsq)
         self.step_count += 1
         a.version = getattr(a, "version", 0) + 1
+        kw = {} if g16 is None else {"g16": g16}
         self.ops.adamw_step(a.master, a.m, a.v, a.grad, a.w16, self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
-                            self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=True)
+                            self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=True, **kw)
         return self._sumsq.sqrt() * mult
 
     def _step_sharded(self, lr=None):
