@@ -138,3 +138,28 @@ def test_rollout_and_update_degenerate_group_sizes(hip_ops, G, C):
         adv = torch.zeros(G)
     out3, row_len = core.loss_backward(st, mask, adv.to(ops.device))
     assert torch.isfinite(out3).all() and torch.isfinite(params.train.grad).all()
+
+
+@pytest.mark.parametrize("T,nh,nkv,empty_row", [(1, 2, 2, None), (70, 4, 2, 3), (129, 14, 2, None), (64, 2, 1, 0)])
+def test_attention_backward_head_dim_128_edges(hip_ops, ref_ops, T, nh, nkv, empty_row):
+    """The LDS-DMA staged dK/dV form (head dim 128): a single query / key, a query-tile count that leaves a ragged last tile (rows past the
+    end are clamped re-reads that must drop out), group size 1 and 7, and a row that sees no key at all (its LSE is -inf: the log2-scaled copy
+    carries +inf so p = 0, never NaN)."""
+    hd, S = 128, T
+    q, k, v, do = rnd(T, nh * hd, seed=1), rnd(S, nkv * hd, seed=2), rnd(S, nkv * hd, seed=3), rnd(T, nh * hd, seed=4, scale=0.3)
+    pre = torch.zeros(T, dtype=I32)
+    lo = torch.zeros(T, dtype=I32)
+    hi = torch.arange(T, dtype=I32)
+    if empty_row is not None:
+        lo[empty_row], hi[empty_row] = 5, 4
+    scale = hd ** -0.5
+    o_r, lse_r = ref_ops.attn_fwd(q.float(), k.float(), ref_ops.pack_transpose(v.float(), nkv, nkv, hd), pre, lo, hi, nh, nkv, S, hd, scale)
+    dq_h, dk_h, dv_h = hip_ops.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o_r.to(BF16).cuda(), do.cuda(), lse_r.cuda(), pre.cuda(), lo.cuda(), hi.cuda(),
+                                        nh, nkv, S, hd, scale)
+    dq_r, dk_r, dv_r = ref_ops.attn_bwd(q.float(), k.float(), v.float(), o_r, do.float(), lse_r, pre, lo, hi, nh, nkv, S, hd, scale)
+    for a, b, name in ((dq_h, dq_r, "dQ"), (dk_h, dk_r, "dK"), (dv_h, dv_r, "dV")):
+        a = a.float().cpu()
+        assert torch.isfinite(a).all(), name
+        assert (a - b.float()).abs().max() <= 0.03 * math.sqrt(nh // nkv) + 0.02 + 0.03 * b.float().abs().max(), name
+    if empty_row is not None:
+        assert float(dq_h[empty_row].float().abs().max()) == 0.0

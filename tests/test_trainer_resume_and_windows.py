@@ -153,6 +153,8 @@ def test_stashed_prefill_window_equals_full_slot_window(monkeypatch):
         monkeypatch.setattr(Engine, "CTX_STASH_GB", gb)
         cfg, tr = make_trainer(fx, ga=2, rollout_batching=True)
         tr.train_dataset = _dataset(fx, 2)
+        # the second prompt is LONGER than the first (more video tokens): its packed sequence outgrows the full set sized for prompt 0
+        tr.train_dataset.rows[1]["video_frames"] = torch.randint(0, 256, (4, 3, 84, 112), generator=torch.Generator().manual_seed(9), dtype=torch.uint8).float()
         tr.accumulation_window([[tr.train_dataset[0]], [tr.train_dataset[1]]])
         pool = tr.engine._ctx_pool
         assert (("stash", 1) in pool) == (gb == 0.0) and ((1 in pool) == (gb != 0.0))
