@@ -16,6 +16,12 @@ __device__ unsigned long long* tr1_probe = nullptr;
 #define TR1_PROBE_AT(slot) do { } while (0)
 #endif
 
+// Split-KV decode: list of the tiles at least one row of the block can see.  The block's tile RANGE is one interval from the first group's
+// suffix start to the last group's newest slot; with the cache laid out group by group (slot = P + g*C + s) that interval also spans the
+// NOT YET GENERATED slots of every group but the last - at C = 1024 a 64-row block walked 144 suffix tiles at every decode step, 8 of them
+// useful on average (config 4: 35 us per layer, constant over the rollout).  The list keeps the prefix tiles and, of the suffix range, the
+// tiles that intersect some token's [lo, hi]; one wave evaluates 64 candidate tiles per pass against the <= 11 tokens of the block.
+#define ATT_LIST_CAP 1024
 template <int D, int CB, int PF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     TR1_PROBE_AT(0);
@@ -30,6 +36,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int KBYTES = ATT_KV * KSTR, VBYTES = D * 144, BUF = KBYTES + VBYTES;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];      // [2][K tile | V^T tile] + meta
     int* lds_meta = reinterpret_cast<int*>(dyn_lds + 2 * BUF);          // [4][3]
+    int* lds_list = lds_meta + 16;                                      // split-KV decode: [ATT_LIST_CAP] relevant tile ids + their count
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int kvh = blockIdx.y % p.n_kv, split = blockIdx.z;
     const int64_t nR = (int64_t)p.T * p.group;
@@ -92,8 +99,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int dt = 0; dt < D / 16; ++dt) o[dt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
-    const int n_my = (split < tr.n_rel) ? (tr.n_rel - split + p.nsplit - 1) / p.nsplit : 0;
-#define TILE_KV0(i) ((int64_t)att_tile_at(tr, split + (i) * p.nsplit) * ATT_KV)
+    const bool use_list = PF > 1 && tr.n_rel <= ATT_LIST_CAP;
+    int n_rel = tr.n_rel;
+    if (use_list) {
+        if (wave == 0) {
+            const int64_t Rb = (int64_t)qtile * (64 * CB);
+            const int64_t Re = (Rb + 64 * CB - 1 < nR - 1) ? Rb + 64 * CB - 1 : nR - 1;
+            int t0, t1, hq_;
+            att_split_row(p, Rb, t0, hq_); att_split_row(p, Re, t1, hq_);
+            const int ntok = t1 - t0 + 1;                                   // <= 64*CB / group + 1 tokens
+            int mylo = 1, myhi = 0;
+            if (lane < ntok && lane < 64) { mylo = p.lo[t0 + lane]; myhi = p.hi[t0 + lane]; }
+            int count = 0;
+            for (int base = 0; base < tr.n_rel; base += 64) {
+                const int i = base + lane;
+                const bool in = i < tr.n_rel;
+                const int tile = att_tile_at(tr, in ? i : 0);
+                const int kv0 = tile * ATT_KV;
+                bool rel = i < tr.pre_tiles;
+                for (int k = 0; k < ntok; ++k) {                            // every lane takes part in the shuffles (no divergence around them)
+                    const int lk = __shfl(mylo, k, 64), hk = __shfl(myhi, k, 64);
+                    rel = rel | ((lk <= kv0 + ATT_KV - 1) & (hk >= kv0));
+                }
+                rel = rel & in;
+                const unsigned long long mask = __ballot(rel);
+                if (rel) lds_list[count + __popcll(mask & ((1ull << lane) - 1ull))] = tile;
+                count += __popcll(mask);
+            }
+            if (lane == 0) lds_list[ATT_LIST_CAP] = count;
+        }
+        __syncthreads();
+        n_rel = lds_list[ATT_LIST_CAP];
+    }
+    const int n_my = (split < n_rel) ? (n_rel - split + p.nsplit - 1) / p.nsplit : 0;
+#define TILE_KV0(i) ((int64_t)(use_list ? lds_list[split + (i) * p.nsplit] : att_tile_at(tr, split + (i) * p.nsplit)) * ATT_KV)
 #pragma unroll
     for (int j = 0; j < PF; ++j)
         if (j < n_my && !(j == 0 && spec && TILE_KV0(0) == spec_kv0))
@@ -110,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int j = 0; j < PF; ++j) {
         const int it = it0 + j;
         if (it >= n_my) break;
-        const int kv0 = att_tile_at(tr, split + it * p.nsplit) * ATT_KV;
+        const int kv0 = (int)TILE_KV0(it);
         const char* lds_k = dyn_lds + (it & 1) * BUF;
         const char* lds_vt = lds_k + KBYTES;
         if (wave_active) {
@@ -370,7 +409,7 @@ __global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_
 
 template <int D, int CB, int PF>
 static void launch_fwd(dim3 grid, hipStream_t s, const AttnParams& p) {
-    const size_t dyn = 2 * (ATT_KV * (2 * D + 16) + D * 144) + 64;
+    const size_t dyn = 2 * (ATT_KV * (2 * D + 16) + D * 144) + 64 + (PF > 1 ? (ATT_LIST_CAP + 1) * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, CB, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
