@@ -161,6 +161,10 @@ int tr1_video_preprocess(const void* frames_u8, void* out_bf16, int64_t ld_out, 
 /* ---- vocabulary side -------------------------------------------------------------------------------------------------- */
 /* ref: src/time_r1/rl/timer1_trainer.py:458-481 (_get_per_token_logps: log_softmax, gather, entropy) */
 int tr1_logp_entropy_fwd(const void* logits, int64_t ld, const void* targets, void* logp, void* entropy, void* lse, int64_t R, int64_t V, void* stream);
+/* lm_head fused with the log-softmax statistics: hn [M,K] x W [N,K]^T is reduced in the GEMM epilogue to per-64-column (max, sum e, sum x e) and merged
+ * per row - the [M, N] logits of _get_per_token_logps (timer1_trainer.py:449-481) never reach HBM.  part_ws: tr1_lmhead_lse_workspace_floats(M, N) floats. */
+int tr1_lmhead_lse_fwd(const void* hn, const void* W, const void* targets, void* part_ws, int64_t ws_floats, void* logp, void* ent, void* lse, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, void* stream);
+int64_t tr1_lmhead_lse_workspace_floats(int64_t M, int64_t N);
 int tr1_logp_bwd(const void* logits, int64_t ld, const void* targets, const void* lse, const void* dlogp, void* dlogits, int64_t ld_out, int64_t R, int64_t V, void* stream);
 /* ref: timer1_trainer.py:635-639 (k3 KL), :713-737 (both loss branches).  out3 = {loss, mean masked kl, sum mask}. */
 int tr1_grpo_loss(const void* logp, const void* ref_logp, const void* mask, const void* adv, void* dlogp, void* out3, void* row_len, void* row_kl, int64_t G, int64_t C, float beta, int use_grpo, float grad_scale, void* stream);

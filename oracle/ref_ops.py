@@ -384,6 +384,10 @@ class RefOps:
         return out, grid
 
     # ---- vocabulary side (ref: timer1_trainer.py:458-481, :635-639, :713-737)
+    def lmhead_lse(self, hn, w, targets):
+        logits = self.gemm_nt(hn, w)              # rounded to the activation dtype like the materialised path
+        return self.logp_entropy_fwd(logits, targets)
+
     def logp_entropy_fwd(self, logits, targets):
         lp = torch.log_softmax(logits.float(), -1)
         logp = lp.gather(1, targets.long()[:, None])[:, 0]

@@ -360,6 +360,28 @@ def test_adamw_and_clip(hip_ops, ref_ops):
     close(st_h[0], pt.detach(), 1e-6, rtol=1e-5, what="adamw vs torch.optim.AdamW")
 
 
+@pytest.mark.parametrize("R,V,K", [(48, 512, 128), (300, 1024, 256), (7, 256, 64), (1600, 152064, 3584)])
+def test_lmhead_lse_fused_epilogue(hip_ops, ref_ops, R, V, K):
+    """lm_head with the log-softmax statistics reduced in the GEMM epilogue (no [R, V] logits in HBM) == the materialised path
+    (GEMM -> bf16 logits -> one-pass logp / entropy kernel), and == the oracle at sizes it runs in seconds."""
+    g = torch.Generator().manual_seed(3)
+    hn = rnd(R, K, seed=1, scale=1.0)
+    w = rnd(V, K, seed=2, scale=2.0 / math.sqrt(K))
+    tg = torch.randint(0, V, (R,), generator=g, dtype=torch.int32)
+    tg[0], tg[R - 1] = 0, V - 1                                   # first / last vocabulary column (first / last 64-column slice)
+    fused = hip_ops.lmhead_lse(hn.cuda(), w.cuda(), tg.cuda())
+    assert fused is not None
+    logits = hip_ops.gemm_nt(hn.cuda(), w.cuda())
+    mat = hip_ops.logp_entropy_fwd(logits, tg.cuda())
+    for a, b, name in zip(fused, mat, ("logp", "entropy", "lse")):
+        assert torch.isfinite(a).all(), name
+        close(a, b, 2e-3, rtol=1e-4, what="fused vs materialised " + name)
+    if V <= 4096:
+        ref = ref_ops.lmhead_lse(hn.float(), w.float(), tg)
+        close(fused[0], ref[0], 0.03, rtol=0, what="fused logp vs oracle")
+        close(fused[1], ref[1], 0.03, rtol=0, what="fused entropy vs oracle")
+
+
 def test_adamw_reads_bf16_wire_gradient(hip_ops):
     """Data-parallel form: norm and update consume the all-reduced gradient from its bf16 wire buffer; bit-equal to copying it back into the
     fp32 accumulator first (bf16 -> fp32 is exact), and the accumulator is zeroed without being read."""

@@ -830,6 +830,11 @@ static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) 
     const int64_t kvblocks = ((n_slots + kb - 1) / kb) * n_kv;
     int64_t qs = (1024 + kvblocks - 1) / kvblocks;
     if (qs > 8) qs = 8;
+    {   // tuning hook (A/B runs): TR1_DKDV_QS=<n> fixes the number of query slices
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("TR1_DKDV_QS"); force = e ? atoi(e) : 0; }
+        if (force > 0) qs = force;
+    }
     if (qs > n_qtiles) qs = n_qtiles;
     if (qs < 1) qs = 1;
     while ((n_qtiles + qs - 1) / qs > DKDV_MAXT) ++qs;

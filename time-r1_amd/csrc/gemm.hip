@@ -222,7 +222,11 @@ TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, co
 #ifndef TR1_EPI_LDS
 #define TR1_EPI_LDS 1
 #endif
-template <bool OUT_F32, bool ACCUM, int RT>
+// EPI = 1 ("lm_head -> log-prob / entropy"): nothing is stored to C.  The wave's 64 columns of a row are rounded to bf16 (the logits the
+// reference materialises are bf16) and reduced to the online-softmax triple (max, sum e^(x-max), sum x e^(x-max)); lane c8 = 0 of a row writes it to
+// part[row][ncol0 / 64] (Cv = float4 partials, ldc = column blocks per row, +1 slot per row for the target's logit), and the lane that holds
+// column targets[row] writes that logit to slot ldc - 1.  `bias` carries the int32 targets.  The [R, V] logits never exist in HBM.
+template <bool OUT_F32, bool ACCUM, int RT, int EPI = 0>
 TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wave_lds, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
                               const bf16_t* __restrict__ residual, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int64_t mrow0, int64_t ncol0,
                               int lane) {
@@ -265,7 +269,7 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
             const int c8 = lane & 7;
             const int64_t n = ncol0 + c8 * 8;
             u32x4_t bv = {0, 0, 0, 0};
-            if (bias && n + 8 <= N) bv = *reinterpret_cast<const u32x4_t*>(bias + n);
+            if (EPI == 0 && bias && n + 8 <= N) bv = *reinterpret_cast<const u32x4_t*>(bias + n);      // (EPI 1: `bias` carries the int32 targets)
 #pragma unroll
             for (int r8 = 0; r8 < CH * 2; ++r8) {
                 if (r8 < cnt * 2) {
@@ -274,6 +278,29 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                     const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8 + 1) ^ (rr & 15)) << 4));
                     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     const int64_t m = mrow0 + i0 * 16 + rr;
+                    if (EPI == 1) {
+                        const bool ok = m < M && n + 8 <= N;
+                        const int tg = m < M ? reinterpret_cast<const int*>(bias)[m] : -1;
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { v[e] = ok ? bf2f(f2bf(v[e])) : -INFINITY; mx = fmaxf(mx, v[e]); }
+                        mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+                        const float ms = (mx == -INFINITY) ? 0.f : mx;
+                        float se = 0.f, te = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float ex = __expf(v[e] - ms);               // exp(-inf) = 0 for masked columns
+                            se += ex; te += (v[e] == -INFINITY) ? 0.f : v[e] * ex;
+                        }
+                        se += __shfl_xor(se, 1, 64); se += __shfl_xor(se, 2, 64); se += __shfl_xor(se, 4, 64);
+                        te += __shfl_xor(te, 1, 64); te += __shfl_xor(te, 2, 64); te += __shfl_xor(te, 4, 64);
+                        if (m < M) {
+                            f32x4_t* prow = reinterpret_cast<f32x4_t*>(Cv) + m * ldc;
+                            if (c8 == 0) prow[ncol0 >> 6] = (f32x4_t){mx, se, te, 0.f};
+                            if (ok && tg >= n && tg < n + 8) reinterpret_cast<float*>(prow + (ldc - 1))[0] = v[tg - n];
+                        }
+                        continue;
+                    }
                     if (m < M && n + 8 <= N) {
                         if (bias) {
 #pragma unroll
@@ -442,7 +469,7 @@ TR1_DEV void stage_round(const bf16_t* __restrict__ g, int64_t ld, int64_t row0,
     __builtin_amdgcn_global_load_lds((gptr_t)(g + grow * ld + k0 + logical * 8), (lptr_t)dst, 16, 0, 0);
 }
 
-template <bool OUT_F32, bool ACCUM, int RT, bool BKM = false>
+template <bool OUT_F32, bool ACCUM, int RT, bool BKM = false, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
                                                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
@@ -581,8 +608,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 #undef STAGE_B
 #if TR1_EPI_LDS
     // every wave is past its last LDS read (the realignment barrier above): the operand buffers become 8 private staging slices
-    store_acc256_lds<OUT_F32, ACCUM, RT>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, residual, M, N, ldc, ldr,
-                                         m0 + wm * (RT * 16), n0 + wn * 64, lane);
+    store_acc256_lds<OUT_F32, ACCUM, RT, EPI>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, residual, M, N, ldc, ldr,
+                                              m0 + wm * (RT * 16), n0 + wn * 64, lane);
 #else
     store_acc256<OUT_F32, ACCUM, RT>(acc, Cv, bias, residual, M, N, ldc, ldr, m0 + wm * (RT * 16), n0 + wn * 64, u, g);
 #endif
@@ -1326,6 +1353,71 @@ extern "C" int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C, int64_
     if (rt == 7) LAUNCHNAR(7); else if (rt == 9) LAUNCHNAR(9); else if (rt == 10) LAUNCHNAR(10); else LAUNCHNAR(8);
 #undef LAUNCHNAR
 #undef LAUNCHNA
+    TR1_LAUNCH_CHECK();
+}
+
+// ---- lm_head -> (log-prob of the target, entropy, LSE) without materialised logits --------------------------------------------------
+// ref: _get_per_token_logps (src/time_r1/rl/timer1_trainer.py:449-481) computes logits [G, L, V], log_softmax, gather and entropy; here the
+// GEMM epilogue reduces every 64-column slice of a row to (max, sum e, sum x e) and this kernel merges the V / 64 slices of a row.
+__global__ __launch_bounds__(256) void lse_combine_kernel(const f32x4_t* __restrict__ part, int64_t ncb, float* __restrict__ logp, float* __restrict__ ent,
+                                                          float* __restrict__ lse_out) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const f32x4_t* pr = part + row * (ncb + 1);
+    float mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < ncb; i += 256) mx = fmaxf(mx, pr[i][0]);
+    mx = block_max(mx, red);
+    __syncthreads();
+    float se = 0.f, te = 0.f;
+    for (int64_t i = threadIdx.x; i < ncb; i += 256) {
+        const f32x4_t v = pr[i];
+        const float w = (v[0] == -INFINITY) ? 0.f : __expf(v[0] - mx);
+        se += v[1] * w; te += v[2] * w;
+    }
+    se = block_sum(se, red);
+    __syncthreads();
+    te = block_sum(te, red);
+    if (threadIdx.x == 0) {
+        const float l = mx + logf(se);
+        const float xt = reinterpret_cast<const float*>(pr + ncb)[0];
+        lse_out[row] = l; logp[row] = xt - l; ent[row] = l - te / se;
+    }
+}
+
+extern "C" int64_t tr1_lmhead_lse_workspace_floats(int64_t M, int64_t N) { return M * ((N + 63) / 64 + 1) * 4; }
+
+// hn [M, K] bf16 (final-norm output of the prediction rows), W [N, K] bf16 (lm_head), targets int32 [M]  ->  logp, entropy, lse fp32 [M].
+extern "C" int tr1_lmhead_lse_fwd(const void* hn, const void* W, const void* targets, void* part_ws, int64_t ws_floats, void* logp, void* ent,
+                                  void* lse, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && N % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0, "lmhead_lse: K % 64, N % 64, lda % 8, ldb % 8 required");
+    TR1_CHECK_ARG(part_ws && ws_floats >= tr1_lmhead_lse_workspace_floats(M, N), "lmhead_lse: workspace too small");
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ncb = N / 64;
+    auto cost = [&](int64_t bm, double eff) {
+        const int64_t t = ((M + bm - 1) / bm) * ((N + BN2 - 1) / BN2);
+        return (double)((t + 255) / 256) * 256.0 * (double)(bm * BN2) / eff;
+    };
+    static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
+    int rt = 8; double best = cost(256, 1.0);
+    for (int r = 7; r <= 10; ++r) { const double c = cost(r * 32, eff[r - 7]); if (c < best) { best = c; rt = r; } }
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES)) + 4096;
+#define SETL(R) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<false, false, R, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+        SETL(7); SETL(8); SETL(9); SETL(10);
+#undef SETL
+        attr_set = true;
+    }
+    dim3 grid2((unsigned)(t2m * t2n));
+#define LAUNCHL(R) hipLaunchKernelGGL((gemm_nt8p_kernel<false, false, R, false, 1>), grid2, dim3(512), dyn, s, (const bf16_t*)hn, (const bf16_t*)W, part_ws, \
+                                      (const bf16_t*)targets, (const bf16_t*)nullptr, M, N, K, lda, ldb, ncb + 1, (int64_t)0, (int)t2m, (int)t2n)
+    if (rt == 7) LAUNCHL(7); else if (rt == 9) LAUNCHL(9); else if (rt == 10) LAUNCHL(10); else LAUNCHL(8);
+#undef LAUNCHL
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)M), dim3(256), 0, s, (const f32x4_t*)part_ws, ncb, (float*)logp, (float*)ent, (float*)lse);
     TR1_LAUNCH_CHECK();
 }
 

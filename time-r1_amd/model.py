@@ -33,6 +33,7 @@ class Engine:
         self.wgrad_on_main = os.environ.get("TR1_WGRAD_MAIN", "d")
         self.wgrad_overwrite_first = True    # see _wgrad: relies on the optimizer zeroing the gradient arena and bumping arena.version (AdamWFlat.step)
         self._gw_ver = {}
+        self.fused_head = os.environ.get("TR1_FUSED_HEAD", "1") != "0"    # lm_head -> logp / entropy in the GEMM epilogue where the logits are not kept
         self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
         self._side = None
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
@@ -390,7 +391,14 @@ class Engine:
         hn, rstd, _ = ops.rmsnorm_fwd(hp, arena.w("norm"), t.rms_eps, need_rstd=save)
         w = self.params.lm_head_w(arena)
         R, ch = hp.shape[0], self.HEAD_CHUNK_ROWS
-        if R <= ch:
+        fused = None
+        if (not save or R > ch) and self.fused_head and hasattr(ops, "lmhead_lse"):
+            # nobody reads these logits again (reference-policy forward; the large-R policy forward recomputes them chunk by chunk in the
+            # backward): lm_head with the log-softmax statistics reduced in the GEMM epilogue - no [R, V] tensor in HBM at all
+            fused = ops.lmhead_lse(hn, w, targets)
+        if fused is not None:
+            logits, (logp, ent, lse) = None, fused
+        elif R <= ch:
             logits = ops.gemm_nt(hn, w)
             logp, ent, lse = ops.logp_entropy_fwd(logits, targets)
         else:

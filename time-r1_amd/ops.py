@@ -491,6 +491,22 @@ class HipOps:
         self.L.call("tr1_logp_entropy_fwd", _p(logits), _ld(logits), _p(targets), _p(logp), _p(ent), _p(lse), R, V, self._s())
         return logp, ent, lse
 
+    def lmhead_lse(self, hn, w, targets):
+        """(logp[target], entropy, lse) of softmax(hn @ w^T) per row WITHOUT the [R, V] logits: the GEMM epilogue reduces each 64-column slice
+        to (max, sum e, sum x e), a second kernel merges the slices of a row.  Returns None when the shape is outside the fused kernel's
+        range (the caller then materialises the logits)."""
+        self._chk(hn, w)
+        R, K = hn.shape
+        V = w.shape[0]
+        if R == 0 or V % 64 or K % 64 or hn.stride(1) != 1 or w.stride(1) != 1 or hn.stride(0) % 8 or w.stride(0) % 8 or V < 256:
+            return None
+        assert targets.dtype == I32 and targets.numel() == R
+        n = int(self.L.raw("tr1_lmhead_lse_workspace_floats")(R, V))
+        ws = self._workspace("lmhead_lse", n, F32)
+        logp, ent, lse = self.empty(R, dtype=F32), self.empty(R, dtype=F32), self.empty(R, dtype=F32)
+        self.L.call("tr1_lmhead_lse_fwd", _p(hn), _p(w), _p(targets), _p(ws), n, _p(logp), _p(ent), _p(lse), R, V, K, hn.stride(0), w.stride(0), self._s())
+        return logp, ent, lse
+
     def logp_bwd(self, logits, targets, lse, dlogp, inplace=True):
         self._chk(logits)
         R, V = logits.shape
