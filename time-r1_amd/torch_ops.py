@@ -313,6 +313,22 @@ def logp_entropy(logits: Tensor, targets: Tensor) -> Tuple[Tensor, Tensor]:
     return lp, ent
 
 
+@_op("lmhead_logp_entropy")
+def lmhead_logp_entropy(hn: Tensor, w: Tensor, targets: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(logp[target], entropy, lse) of softmax(hn @ w^T) per row with the statistics reduced in the GEMM epilogue: no [R, V] logits in HBM
+    (forward only - the no-grad reference-policy log-probs of timer1_trainer.py:613-632)."""
+    r = _ops(hn).lmhead_lse(hn, w, targets)
+    if r is None:
+        raise RuntimeError("lmhead_logp_entropy: needs V % 64 == 0, K % 64 == 0, V >= 256 and row-major operands")
+    return r
+
+
+@lmhead_logp_entropy.register_fake
+def _(hn, w, targets):
+    R = hn.shape[0]
+    return hn.new_empty(R, dtype=F32), hn.new_empty(R, dtype=F32), hn.new_empty(R, dtype=F32)
+
+
 @_op("grpo_loss")
 def grpo_loss_op(logp: Tensor, ref_logp: Optional[Tensor], mask: Tensor, adv: Tensor, beta: float, use_grpo: bool, grad_scale: float) -> Tuple[Tensor, Tensor, Tensor]:
     dlogp, out3, row_len, _ = _ops(logp).grpo_loss(logp, ref_logp, mask, adv, beta, use_grpo, grad_scale)
@@ -372,7 +388,7 @@ def _(frames_u8, out_h, out_w, k_pad):
 
 
 OP_NAMES = ["rmsnorm_fwd", "rmsnorm_bwd", "swiglu_fwd", "swiglu_bwd", "linear_fwd", "linear_bwd", "rope_fwd", "mrope_table", "attn_fwd", "attn_bwd",
-            "logp_entropy_fwd", "logp_bwd", "grpo_loss", "sample_tokens", "adamw_step", "video_preprocess"]
+            "logp_entropy_fwd", "logp_bwd", "lmhead_logp_entropy", "grpo_loss", "sample_tokens", "adamw_step", "video_preprocess"]
 
 
 # ================================================================================================ dropping the ops into an HF model
