@@ -52,8 +52,8 @@ class AdamWFlat:
 
     def _step_sharded(self, lr=None):
         """reduce-scatter (overlapped with the backward through ShardSync.ready, finished here) -> global norm from the local shards (one
-        scalar all-reduce) -> fused AdamW on the local chunk of every segment, writing the new bf16 weights straight into their place in
-        the full working arena -> per-segment in-place all-gather of those bf16 chunks, issued right behind the segment's AdamW launch so
+        scalar all-reduce) -> fused AdamW on the local chunk of every segment, writing the new bf16 weights into a send buffer (1/world of the
+        arena) -> per-segment all-gather of those chunks into the full working arena, issued right behind the segment's AdamW launch so
         the exchange of segment s overlaps the update of segment s+1."""
         a, ops, W = self.params.train, self.ops, self.dp.world
         if not self.sync.active:
