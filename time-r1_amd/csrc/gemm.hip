@@ -807,7 +807,7 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
                                                                       const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                       const bf16_t* __restrict__ bias, int M, int64_t N, int64_t K, int64_t ldx,
                                                                       int64_t ldw, int64_t ldc, float eps, int64_t up_off, QkvEpi qe = QkvEpi{}) {
-    static_assert(!GLU || NCOL == 2, "GLU pairs one gate and one up column group");
+    static_assert(!GLU || NCOL % 2 == 0, "GLU pairs NCOL/2 gate column groups with NCOL/2 up column groups");
     static_assert(!QKV || (NCOL == 2 && !GLU), "QKV pairs the two rotate-half column groups of a head");
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ float ssred[WAVES][MG][16];
@@ -815,13 +815,14 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
     const int u = lane & 15, g = lane >> 4;
     const int qkv_gph = QKV ? qe.hd >> 5 : 1;                                   // 16-column group pairs per head
     const int qkv_h = QKV ? (int)blockIdx.x / qkv_gph : 0, qkv_j = QKV ? (int)blockIdx.x % qkv_gph : 0;
-    const int64_t n0 = QKV ? (int64_t)qkv_h * qe.hd + qkv_j * 16 : (int64_t)blockIdx.x * (GLU ? 16 : 16 * NCOL);
+    constexpr int OG = GLU ? NCOL / 2 : (QKV ? 1 : NCOL);                       // output column groups per block
+    const int64_t n0 = QKV ? (int64_t)qkv_h * qe.hd + qkv_j * 16 : (int64_t)blockIdx.x * (16 * OG);
     const bf16_t* wp[NCOL];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
-        int64_t wrow = QKV ? n0 + c * (qe.hd >> 1) + u : (GLU ? n0 + u : n0 + c * 16 + u);
+        int64_t wrow = QKV ? n0 + c * (qe.hd >> 1) + u : (GLU ? n0 + (c % OG) * 16 + u : n0 + c * 16 + u);
         if (wrow >= N) wrow = N - 1;
-        if (GLU && c == 1) wrow += up_off;
+        if (GLU && c >= OG) wrow += up_off;
         wp[c] = W + wrow * ldw + g * 8;
     }
     const bf16_t* xp[MG];      // rows >= M re-read row M-1 (see gemm_skinny_kernel); their outputs are never stored
@@ -832,13 +833,14 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
     const int64_t s_per = (nsteps + WAVES - 1) / WAVES;
     const int64_t s0 = wave * s_per;
     int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
-    f32x4_t acc[NCOL][MG][2];
+    constexpr int NA = (GLU && NCOL >= 4) ? 1 : 2;      // accumulators per tile: the wide GLU forms have enough independent tiles to hide the MFMA latency
+    f32x4_t acc[NCOL][MG][NA];
     float ss[MG];
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg) {
         ss[mg] = 0.f;
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c < NCOL; ++c) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][NA - 1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     }
     // rotating software pipeline over UNROLL k-step buffers (see gemm_skinny_kernel)
     bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2], la[UNROLL][2];
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
             const bf16x8_t x1__ = scale_frag_sumsq(xa[q][mg][1], la[q][1], ss[mg]);                                           \
             _Pragma("unroll") for (int c = 0; c < NCOL; ++c) {                                                                \
                 acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], x0__, acc[c][mg][0], 0, 0, 0);           \
-                acc[c][mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], x1__, acc[c][mg][1], 0, 0, 0);           \
+                acc[c][mg][NA - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], x1__, acc[c][mg][NA - 1], 0, 0, 0); \
             }                                                                                                                 \
         }                                                                                                                     \
     } while (0)
@@ -893,18 +895,18 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 #pragma unroll
         for (int c = 0; c < NCOL; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = acc[c][mg][0][r] + acc[c][mg][1][r];
+            for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = NA == 2 ? acc[c][mg][0][r] + acc[c][mg][1][r] : acc[c][mg][0][r];
     }
     __syncthreads();
     const float inv_k = 1.f / (float)K;
-    for (int i = threadIdx.x; i < ((GLU || QKV) ? 1 : NCOL) * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
+    for (int i = threadIdx.x; i < OG * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
         const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
         const int m = mg * 16 + mm;
         const int64_t n = n0 + c * 16 + nn;
         if (m < M && n < N) {
             float sq = 0.f, v = 0.f, v2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) { sq += ssred[w][mg][mm]; v += red[w][c][mg][mm][nn]; if (GLU || QKV) v2 += red[w][1][mg][mm][nn]; }
+            for (int w = 0; w < WAVES; ++w) { sq += ssred[w][mg][mm]; v += red[w][c][mg][mm][nn]; if (GLU || QKV) v2 += red[w][GLU ? c + OG : 1][mg][mm][nn]; }
             const float rstd = rsqrtf(sq * inv_k + eps);
             v = __fmul_rn(v, rstd);          // explicitly rounded (no fma contraction): the fused-QKV and two-kernel paths agree bit for bit
             if (QKV) {      // same rounding points as projection -> bf16 qkv buffer -> decode_qkv_post
@@ -940,19 +942,19 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 // LDS image of a stage: [gate 16 rows | up 16 rows] x 128 bytes (64 k); row r keeps its logical 16-byte chunk c at position c ^ keyA(r)
 // (applied on the SOURCE address of the DMA): the 16-row fragment reads are conflict-free.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NST, int R, int NRED = 2>
+template <int NST, int R, int NRED = 2, int MG = 1>
 __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                                                            int64_t ldc, float eps, int64_t up_off) {
     constexpr int STAGE = 4096;                                            // bytes per stage: gate 2 KiB + up 2 KiB
-    constexpr int REDW = 2 * 16 * 17;                                      // floats of one wave's partial (gate | up)
+    constexpr int REDW = MG * 2 * 16 * 17;                                 // floats of one wave's partial: MG row groups x (gate | up)
     // red[2][8][REDW] f32 | ssq[8][16] | [8 waves][R stages][4 KiB].  The rings come LAST: a DMA destination is passed as (slot - stage offset)
     // because the instruction's immediate offset is added to the LDS address too, and that pointer must not fall below the LDS base.
     extern __shared__ __attribute__((aligned(16))) char glu_lds[];
     float* red = reinterpret_cast<float*>(glu_lds);
-    float* ssq = red + NRED * 8 * REDW;
-    char* rings = glu_lds + (NRED * 8 * REDW + 8 * 16) * sizeof(float);
-    static_assert((NRED * 8 * REDW + 8 * 16) * sizeof(float) >= 6 * 128 && ((NRED * 8 * REDW + 8 * 16) * sizeof(float)) % 16 == 0, "ring base");
+    float* ssq = red + NRED * 8 * REDW;                                   // [8 waves][MG][16]
+    char* rings = glu_lds + (NRED * 8 * REDW + 8 * MG * 16) * sizeof(float);
+    static_assert((NRED * 8 * REDW + 8 * MG * 16) * sizeof(float) >= 6 * 128 && ((NRED * 8 * REDW + 8 * MG * 16) * sizeof(float)) % 16 == 0, "ring base");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     const int64_t NP = (N + 15) / 16;
     const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
@@ -993,34 +995,51 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
     }
     // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares - built AFTER the first weight stages were
     // issued, so the HBM stream starts at kernel entry instead of waiting for this L2 round trip
-    bf16x8_t xr[NST * 2];
+    bf16x8_t xr[MG][NST * 2];
     {
-        float ss = 0.f;
-        const bf16_t* xp = X + (int64_t)(u < M ? u : M - 1) * ldx + kb + g * 8;
+        float ss[MG];
+        const bf16_t* xp[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) { ss[mg] = 0.f; xp[mg] = X + (int64_t)(mg * 16 + u < M ? mg * 16 + u : M - 1) * ldx + kb + g * 8; }
         const bf16_t* lp = lnw + kb + g * 8;
 #pragma unroll
-        for (int i = 0; i < NST * 2; ++i) {
-            const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xp + i * 32), lv = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
-            xr[i] = scale_frag_sumsq(xv, lv, ss);
+        for (int i0 = 0; i0 < NST * 2; i0 += 4) {        // four k-halves at a time: the loads of ALL fragments in flight at once would not fit the
+#pragma unroll                                           // register file next to xr at MG = 2 (scheduling fence below)
+            for (int i = i0; i < i0 + 4 && i < NST * 2; ++i) {
+                const bf16x8_t lv = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xp[mg] + i * 32);
+                    u32x4_t f = __builtin_bit_cast(u32x4_t, scale_frag_sumsq(xv, lv, ss[mg]));
+                    asm volatile("" : "+v"(f));          // pin the PACKED fragment here: left alone, the compiler keeps the unpacked f32 products
+                    xr[mg][i] = __builtin_bit_cast(bf16x8_t, f);     // live into the main loop (2x the registers) and spills at MG = 2
+                }
+            }
+            if (MG > 1) __builtin_amdgcn_sched_barrier(0);
         }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        if (g == 0) ssq[wave * 16 + u] = ss;
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            float v = ss[mg];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) ssq[(wave * MG + mg) * 16 + u] = v;
+        }
     }
     TR1_BARRIER();                                       // the eight waves' sum-of-squares partials are in LDS (the prologue DMA is in flight)
     float rstd;
     {
         float sq = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) sq += ssq[w * 16 + ((threadIdx.x >> 4) & 15)];
+        for (int w = 0; w < 8; ++w) sq += ssq[(w * MG + (MG > 1 ? (threadIdx.x >> 8) : 0)) * 16 + ((threadIdx.x >> 4) & 15)];
         rstd = rsqrtf(sq * (1.f / (float)K) + eps);
     }
     const int rd_off = u * 128;
     const int kA = keyA(u);
     int cslot = 0;                                       // ring slot of the item being consumed
     for (int pi = 0; pi < npair; ++pi) {
-        f32x4_t ag[2], au[2];
-        ag[0] = ag[1] = au[0] = au[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        f32x4_t ag[MG][2], au[MG][2];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) ag[mg][0] = ag[mg][1] = au[mg][0] = au[mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             const int item = pi * NST + st;
@@ -1043,30 +1062,34 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                 wu[ks] = *reinterpret_cast<const bf16x8_t*>(sb + 2048 + off);
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                ag[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[ks], xr[st * 2 + ks], ag[ks], 0, 0, 0);
-                au[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[ks], xr[st * 2 + ks], au[ks], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    ag[mg][ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[ks], xr[mg][st * 2 + ks], ag[mg][ks], 0, 0, 0);
+                    au[mg][ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[ks], xr[mg][st * 2 + ks], au[mg][ks], 0, 0, 0);
+                }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this stage's reads have returned before its slot can be refilled
         }
         float* rw = red + ((NRED == 2 ? (pi & 1) : 0) * 8 + wave) * REDW;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rw[u * 17 + g * 4 + r] = ag[0][r] + ag[1][r];
-            rw[16 * 17 + u * 17 + g * 4 + r] = au[0][r] + au[1][r];
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                rw[mg * 544 + u * 17 + g * 4 + r] = ag[mg][0][r] + ag[mg][1][r];
+                rw[mg * 544 + 16 * 17 + u * 17 + g * 4 + r] = au[mg][0][r] + au[mg][1][r];
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TR1_BARRIER();                                                  // partial tiles are visible; the DMA of the next pair stays in flight
-        if (threadIdx.x < 256) {
-            const int mm = threadIdx.x >> 4, nn = threadIdx.x & 15;
-            const float* rb = red + (NRED == 2 ? (pi & 1) : 0) * 8 * REDW;
+        if (threadIdx.x < 256 * MG) {
+            const int mgi = MG > 1 ? (threadIdx.x >> 8) : 0, mm = (threadIdx.x >> 4) & 15, nn = threadIdx.x & 15;
+            const float* rb = red + (NRED == 2 ? (pi & 1) : 0) * 8 * REDW + mgi * 544;
             float v = 0.f, v2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) { v += rb[w * REDW + mm * 17 + nn]; v2 += rb[w * REDW + 16 * 17 + mm * 17 + nn]; }
             v = __fmul_rn(v, rstd);
             const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
             const int64_t n = (p0 + pi) * 16 + nn;
-            if (mm < M && n < N) C[(int64_t)mm * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
+            if (mgi * 16 + mm < M && n < N) C[(int64_t)(mgi * 16 + mm) * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
         }
         if (NRED == 1) TR1_BARRIER();                                   // single reduction buffer: everybody has read it before the next pair writes
     }
@@ -1091,29 +1114,35 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     static int glu_lds = -1;                         // TR1_GLU_LDS=0 selects the register-fragment form (A/B measurements)
     if (glu_lds < 0) { const char* e = getenv("TR1_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
     const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
-    if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3) && N % 16 == 0) {   // hidden 3584 / 2048 / 1536
-        constexpr int RING = 3;          // a ring of 4 (with a single reduction buffer and a second barrier per pair) measured the same: 50.0 us
-        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+    if (glu && M <= 32 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3) && N % 16 == 0) {   // hidden 3584 / 2048 / 1536
+        // <= 16 rows: ring of 3 + double reduction buffer (a ring of 4 with a single buffer and a second barrier per pair measured the same).
+        // 17..32 rows (config 4 decodes 2 x 16 rollouts): two row groups per wave against the SAME LDS stage, ring of 3, single reduction
+        // buffer (132 KB of LDS): 77.4 -> 52.8 us at 32 x 18944 x 3584 (5.1 TB/s of weights) over the register-fragment form.
+        constexpr int RING = 3;
+        const size_t dyn1 = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        const size_t dyn2 = 8 * RING * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float);
         static int n_cu = 0;
         if (!n_cu) {
             hipDeviceProp_t prop; int dev = 0;
             hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<7, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<3, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<4, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+#define GLU_ATTR(NSTV)                                                                                                                          \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn1); \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn2)
+            GLU_ATTR(7); GLU_ATTR(4); GLU_ATTR(3);
+#undef GLU_ATTR
         }
         const int64_t NP = N / 16;
         const unsigned grid = (unsigned)(NP < n_cu ? NP : n_cu);
-        if (nst == 7)
-            hipLaunchKernelGGL((norm_glu_lds_kernel<7, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
-                               (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
-        else if (nst == 4)
-            hipLaunchKernelGGL((norm_glu_lds_kernel<4, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
-                               (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
-        else
-            hipLaunchKernelGGL((norm_glu_lds_kernel<3, RING>), dim3(grid), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W,
-                               (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);
+#define GLU_LAUNCH(NSTV)                                                                                                                        \
+    do {                                                                                                                                        \
+        if (M <= 16) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 2, 1>), dim3(grid), dim3(512), dyn1, s, (const bf16_t*)x, (const bf16_t*)lnw, \
+                                        (const bf16_t*)W, (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);                                   \
+        else hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 1, 2>), dim3(grid), dim3(512), dyn2, s, (const bf16_t*)x, (const bf16_t*)lnw,         \
+                                (const bf16_t*)W, (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);                                           \
+    } while (0)
+        if (nst == 7) GLU_LAUNCH(7); else if (nst == 4) GLU_LAUNCH(4); else GLU_LAUNCH(3);
+#undef GLU_LAUNCH
     }
     else if (glu) { if (M <= 16) NG(4, 2, 1, true); else if (M <= 32) NG(4, 2, 2, true); else NG(4, 2, 4, true); }
     else if (N >= 100000 && M <= 32) {      // lm_head: 4 column groups per block halve the re-reads of x (228 -> ~195 us at M = 16)
