@@ -107,6 +107,13 @@ class Workload:
         late = toks_host is None and os.environ.get("TR1_BENCH_TOKENS_LATE") == "1"
         if toks_host is None and not late:
             toks_host = st.completion_ids.cpu().numpy()
+        if a.ragged_eos and not late:
+            # SURVEY 8d "ragged case": an EOS at a uniform position in [C/2, C) of every row (seed 1); the decode ran all C steps (the
+            # reference's generation config has no EOS either), what changes is the mask: loss weights, lengths, counted tokens
+            rng = np.random.default_rng(1 + 7919 * self.rank + self.micro)
+            toks_host = np.array(toks_host, copy=True)
+            toks_host[np.arange(a.G), rng.integers(a.C // 2, max(a.C // 2 + 1, a.C), size=a.G)] = self.cfg.eos_token_id
+            st.completion_ids = self.ops.tensor(toks_host.astype(np.int32), torch.int32)
         core.forward_logps(st)
         if late:
             toks_host = st.completion_ids.cpu().numpy()
@@ -397,6 +404,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-config1-prompts", type=int, default=1)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-peak-probe", action="store_true")
+    ap.add_argument("--ragged-eos", action="store_true", help="inject an EOS at a uniform position in [C/2, C) of every completion (seed 1): the ragged-length case of SURVEY 8d")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only), fp8 MFMA (W8A8)")
     ap.add_argument("--rollout-fp8-w8a16", action="store_true", help="fp8 weight copies converted to bf16 in registers (bf16 MFMA) instead of the fp8 MFMA")
@@ -497,6 +505,7 @@ def main(argv=None):
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step"
                                    % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
                                       wl.prompts[0][1].shape[2], wl.prompts[0][1].shape[3]),
+                       "completion_lengths": "ragged: EOS injected at uniform[C/2, C) per row, seed 1" if args.ragged_eos else "all C tokens (EOS suppressed)",
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
                        "rollout_weight_dtype": ("fp8-e4m3 weights x e4m3 block-scaled activations, fp8 MFMA (sampling policy only)" if args.rollout_fp8 else
                                                 "fp8-e4m3 weights -> bf16 in registers, bf16 MFMA (sampling policy only)" if args.rollout_fp8_w8a16 else "bf16"),

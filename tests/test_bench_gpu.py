@@ -37,6 +37,15 @@ def test_driver_argument_shape_runs_and_reports_contract_fields():
     assert out["peak_probe"]["hbm_copy_GBs"] > 500
 
 
+def test_ragged_eos_run_counts_only_tokens_up_to_the_injected_eos():
+    full = _run(["--steps", "2", "--warmup", "0", "--no-roofline", "--no-peak-probe"])
+    rag = _run(["--steps", "2", "--warmup", "0", "--no-roofline", "--no-peak-probe", "--ragged-eos"])
+    assert "ragged" in rag["config"]["completion_lengths"] and "all C" in full["config"]["completion_lengths"]
+    tok = lambda o: o["generated_tokens_per_sec_end_to_end"] * o["ms_per_step"] * o["steps"] / 1000.0      # tokens counted in the timed region
+    assert tok(full) <= 2 * 4 * 8 + 1e-3                       # 2 micro-steps x G = 4 x C = 8 (a sampled EOS may shorten a row)
+    assert 0 < tok(rag) < tok(full)                            # same seeds, same samples: the injected EOS (kept, lengths in [C/2 + 1, C]) only shortens rows
+
+
 @pytest.mark.parametrize("shard", [False, True])
 def test_self_spawned_two_rank_run(shard):
     out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-peak-probe"] + (["--shard-optimizer"] if shard else []),
