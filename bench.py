@@ -93,6 +93,7 @@ class Workload:
             gen = torch.Generator().manual_seed(7 + 100 * rank + i)
             frames = torch.randint(0, 256, (n_frames, 3) + tuple(src_hw), generator=gen, dtype=torch.uint8).to(device)   # staged in HBM before the timed region
             self.prompts.append((ids, frames, g))
+        self.host_frames = [f.cpu().pin_memory() for _, f, _ in self.prompts] if args.host_frames else None
         self.P = len(self.prompts[0][0])
         self.reward_funcs = [R.iou_timestamp_reward_v2, R.format_reward]
         self.micro = 0
@@ -150,6 +151,8 @@ class Workload:
 
         def prepare(j):
             ids, frames, grid = self.prompts[(self.micro + j) % len(self.prompts)]
+            if a.host_frames:           # PCIe-inclusive variant (reported in DESIGN.md, never the headline value): pinned host frames -> HBM inside the step
+                frames = self.host_frames[(self.micro + j) % len(self.prompts)].to(frames.device, non_blocking=True)
             # reference: resize + rescale / normalise + patchify inside compute_loss (timer1_trainer.py:531-556) -> here one fused kernel
             pix, g = self.ops.video_preprocess(frames, self.target, v.patch_dim_padded, v.patch_size, v.temporal_patch_size, v.spatial_merge_size)
             assert tuple(g) == tuple(grid[0]), (g, grid)
@@ -404,6 +407,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-config1-prompts", type=int, default=1)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-peak-probe", action="store_true")
+    ap.add_argument("--host-frames", action="store_true", help="copy the uint8 frames from pinned host memory inside the timed step (PCIe-inclusive rate; default: frames resident in HBM)")
     ap.add_argument("--ragged-eos", action="store_true", help="inject an EOS at a uniform position in [C/2, C) of every completion (seed 1): the ragged-length case of SURVEY 8d")
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only), fp8 MFMA (W8A8)")
@@ -505,6 +509,7 @@ def main(argv=None):
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step"
                                    % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
                                       wl.prompts[0][1].shape[2], wl.prompts[0][1].shape[3]),
+                       "frames": "pinned host memory, copied to HBM inside the timed step" if args.host_frames else "resident in HBM before the timed region",
                        "completion_lengths": "ragged: EOS injected at uniform[C/2, C) per row, seed 1" if args.ragged_eos else "all C tokens (EOS suppressed)",
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
                        "rollout_weight_dtype": ("fp8-e4m3 weights x e4m3 block-scaled activations, fp8 MFMA (sampling policy only)" if args.rollout_fp8 else
