@@ -104,6 +104,11 @@ int tr1_embed_bwd(const void* dout, const void* ids, void* dtable_f32, int64_t T
  * problem b uses Q/O/mask rows [b*T, (b+1)*T) and cache slots starting at b*kv_batch_slots (decode over several prompts' caches). */
 int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* stream);
 int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit);
+/* Split-KV decode over the layers of ONE decode step (same pre/lo/hi in every layer of model.generate's step, timer1_trainer.py:568-573): the
+ * launch with plan_mode 1 publishes each query tile's relevant-tile list in `plan` (int32[tr1_attn_plan_ints()]), launches with plan_mode 2 start
+ * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */
+int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
+int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch);
 /* Backward of the above (recompute based): needs K, V row-major.  KT / kt_ld are kept for ABI stability and ignored (may be NULL / 0): the dQ
  * kernel reads its K^T fragments from the K rows with ds_read_b64_tr_b16.  QT / dOT (tr1_pack_transpose copies) only for head dims padded to
  * 32 or 96 (may be NULL for 64 / 128: the 8-wave dK/dV kernel transposes in its LDS reads the same way).

@@ -442,6 +442,21 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
         o_h, _ = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
                                   need_lse=False, n_batch=B, kv_batch_slots=s_cap)
         close(o_h, o_r, 0.02, what="batched decode attention nsplit=%d" % nsplit)
+        if nsplit > 1:
+            # the per-step tile plan (layer 0 publishes, the other layers reuse): all three modes give the same bits, also with garbage in the plan
+            plan = hip_ops.attn_plan(G, nh, nkv, B)
+            plan.fill_(0x7fffffff)
+            o_w, _ = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
+                                      need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=1)
+            q2 = rnd(B * G, nh * hd, seed=4)       # "another layer": different q / cache contents, same masks
+            o_0, _ = hip_ops.attn_fwd(q2.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
+                                      need_lse=False, n_batch=B, kv_batch_slots=s_cap)
+            o_0 = o_0.clone()
+            o_2, _ = hip_ops.attn_fwd(q2.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
+                                      need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=2)
+            assert torch.equal(o_w, o_h) and torch.equal(o_2, o_0), "planned split-KV attention must be bit-identical (nsplit=%d)" % nsplit
+            cnt = plan.view(B, -1, 1025)[:, :, 1024]
+            assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
 
 @pytest.mark.parametrize("T,H,W,Ho,Wo", [(8, 360, 640, 364, 644), (6, 360, 640, 308, 532), (3, 240, 320, 112, 140), (4, 100, 90, 196, 168)])

@@ -42,6 +42,9 @@ struct AttnParams {
     unsigned group_magic;              // ceil(2^32 / group): R / group == umulhi(R, group_magic) for R < 2^32 / group (att_set_group)
     int n_batch; int64_t kv_batch_slots;   // forward only: batch b uses Q/O/mask rows [b*T,(b+1)*T) and cache slots [b*kv_batch_slots, ...)
     float scale_log2;                  // softmax scale * log2(e)
+    // split-KV decode: the relevant-tile lists of a decode step are the same in every layer (same pre / lo / hi), so the first layer's launch
+    // (plan_mode 1) stores them - [n_batch][q tiles][ATT_LIST_CAP ids + count] - and the other layers' launches (plan_mode 2) read them
+    int* plan; int plan_mode;
 };
 
 #define ATT_KV 64          // keys per tile

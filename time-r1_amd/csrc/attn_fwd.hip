@@ -26,8 +26,9 @@ template <int D, int CB, int PF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     TR1_PROBE_AT(0);
     constexpr int KSTR = 2 * D + 16;
+    const int bidx = blockIdx.y / p.n_kv;
     {   // batched launch (decode over several prompts' caches): blockIdx.y = b * n_kv + kvh
-        const int b = blockIdx.y / p.n_kv;
+        const int b = bidx;
         p.Q += (int64_t)b * p.T * p.q_ld; p.O += (int64_t)b * p.T * p.o_ld;
         p.pre += (int64_t)b * p.T; p.lo += (int64_t)b * p.T; p.hi += (int64_t)b * p.T;
         p.K += (int64_t)b * p.kv_batch_slots * p.k_ld; p.VT += (int64_t)b * p.kv_batch_slots;
@@ -44,6 +45,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     // rows with the whole prefix), so the heaviest blocks are dispatched first and the light ones fill the tail (longest-processing-time order)
     const int qtile = (int)(gridDim.x - 1 - blockIdx.x);
     const int64_t R0 = (int64_t)qtile * (64 * CB) + wave * (16 * CB);
+    // plan_mode 2: this block's tile list was stored by the first layer's launch of the same decode step.  The count is a scalar load; the
+    // block's own entries (list[split + t * nsplit], t = thread) are requested at once, clamped into the plan - entries beyond the count are never used.
+    int* plan_blk = (PF > 1 && p.plan) ? p.plan + ((int64_t)bidx * gridDim.x + qtile) * (ATT_LIST_CAP + 1) : nullptr;
+    int plan_n = -1, plan_mine = 0;
+    if (PF > 1 && p.plan_mode == 2) {
+        plan_n = plan_blk[ATT_LIST_CAP];
+        const int idx = (int)blockIdx.z + (int)threadIdx.x * p.nsplit;
+        plan_mine = plan_blk[idx < ATT_LIST_CAP ? idx : ATT_LIST_CAP - 1];
+    }
+    const bool planned = plan_n >= 0;
 
     // Split-KV decode (PF > 1): the block's first tile is almost always tile `split` of the shared prefix.  Its K / V^T loads are issued
     // BEFORE the row masks are fetched and reduced (a dependent global round trip + a barrier, 1.5 us of a 10 us block); once the tile
@@ -66,16 +77,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
         if (valid[cb]) { wmaxpre = max(wmaxpre, pre[cb]); if (hi[cb] >= lo[cb]) { wminlo = min(wminlo, lo[cb]); wmaxhi = max(wmaxhi, hi[cb]); } }
     }
+    TileRange tr{0, 0, 0};
+    if (!planned) {                                                         // block-uniform
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
+        for (int o = 1; o < 16; o <<= 1) {
+            wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
+        }
+        if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
+        __syncthreads();
+        int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
+        tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
     }
-    if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
-    __syncthreads();
-    int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
-    const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
     TR1_PROBE_AT(1);
     // a wave whose 32 rows are all out of range (decode: 56 live rows in a 128-row tile) only helps staging
     const bool wave_active = __builtin_amdgcn_readfirstlane((int)(R0 < nR)) != 0;
@@ -99,8 +113,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int dt = 0; dt < D / 16; ++dt) o[dt][cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
-    const bool use_list = PF > 1 && tr.n_rel <= ATT_LIST_CAP;
-    int n_rel = tr.n_rel;
+    const bool use_list = !planned && PF > 1 && tr.n_rel <= ATT_LIST_CAP;
+    int n_rel = planned ? plan_n : tr.n_rel;
+    if (planned) {      // own entries, compacted: lds_list[t] = list[split + t * nsplit]
+        const int n_mine = (split < n_rel) ? (n_rel - split + p.nsplit - 1) / p.nsplit : 0;
+        if ((int)threadIdx.x < n_mine) lds_list[threadIdx.x] = plan_mine;
+        __syncthreads();
+    }
     if (use_list) {
         if (wave == 0) {
             const int64_t Rb = (int64_t)qtile * (64 * CB);
@@ -130,9 +149,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
         __syncthreads();
         n_rel = lds_list[ATT_LIST_CAP];
+        if (p.plan_mode == 1 && kvh == 0 && split == 0) {                   // one block per (batch entry, query tile) publishes the list
+            for (int i = threadIdx.x; i < n_rel; i += 256) plan_blk[i] = lds_list[i];
+            if (threadIdx.x == 0) plan_blk[ATT_LIST_CAP] = (n_rel <= 256 * p.nsplit) ? n_rel : -1;   // a reader block holds one entry per thread
+        }
+    } else if (PF > 1 && !planned && p.plan_mode == 1 && kvh == 0 && split == 0 && threadIdx.x == 0) {
+        plan_blk[ATT_LIST_CAP] = -1;                                        // no list (range too long): the other layers take the full path as well
     }
     const int n_my = (split < n_rel) ? (n_rel - split + p.nsplit - 1) / p.nsplit : 0;
-#define TILE_KV0(i) ((int64_t)(use_list ? lds_list[split + (i) * p.nsplit] : att_tile_at(tr, split + (i) * p.nsplit)) * ATT_KV)
+#define TILE_KV0(i) ((int64_t)(planned ? lds_list[i] : use_list ? lds_list[split + (i) * p.nsplit] : att_tile_at(tr, split + (i) * p.nsplit)) * ATT_KV)
 #pragma unroll
     for (int j = 0; j < PF; ++j)
         if (j < n_my && !(j == 0 && spec && TILE_KV0(0) == spec_kv0))
@@ -426,11 +451,18 @@ static int attn_check(const AttnParams& p, int d_pad) {
     return 0;
 }
 
-extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
-                            void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
-                            int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
-                            int64_t kv_batch_slots, void* stream) {
+extern "C" int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch) {
+    const int64_t nR = T * (n_kv > 0 ? n_heads / n_kv : 1);
+    return n_batch * ((nR + 63) / 64) * (ATT_LIST_CAP + 1);
+}
+
+static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
+                         void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
+                         int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
+                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
     AttnParams p; memset(&p, 0, sizeof(p));
+    TR1_CHECK_ARG(plan_mode == 0 || (plan && nsplit > 1 && (plan_mode == 1 || plan_mode == 2)), "attention: plan_mode 1 / 2 needs a plan buffer and nsplit > 1");
+    p.plan = (int*)plan; p.plan_mode = plan_mode;
     TR1_CHECK_ARG(n_batch >= 1, "attention: n_batch must be >= 1");
     p.n_batch = (int)n_batch; p.kv_batch_slots = kv_batch_slots;
     p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.VT = (const bf16_t*)VT; p.vt_ld = vt_ld;
@@ -480,6 +512,25 @@ extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t 
         }
     }
     TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
+                            void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
+                            int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
+                            int64_t kv_batch_slots, void* stream) {
+    return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32, ws_floats,
+                         n_batch, kv_batch_slots, nullptr, 0, stream);
+}
+
+// Split-KV decode over the layers of ONE decode step: the masks are the same in every layer, so the launch of the first layer (plan_mode 1)
+// publishes each query tile's relevant-tile list in `plan` (tr1_attn_plan_ints ints) and the launches of the other layers (plan_mode 2) start
+// from it - no mask reduction, no list construction, two block barriers fewer in front of the first tile.  plan_mode 0 = tr1_attn_fwd.
+extern "C" int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
+                                    void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
+                                    int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
+                                    int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
+    return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32, ws_floats,
+                         n_batch, kv_batch_slots, plan, plan_mode, stream);
 }
 
 extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit) {

@@ -28,7 +28,8 @@ static int64_t decode_ws_bytes(const int64_t* d) {
     const int64_t att = d[D_BATCH] * tr1_attn_fwd_workspace_floats(T, d[D_HEADS], d[D_KV], d[D_HEAD_DIM], d[D_NSPLIT]);
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     const int64_t fix = tr1_gemm_skinny_fixup_workspace_floats(R, hid, d[D_INTER]);
-    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + 4096;
+    const int64_t plan = tr1_attn_plan_ints(T, d[D_HEADS], d[D_KV], d[D_BATCH]);
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
 }
 
 extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
@@ -53,6 +54,11 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     // 37.9 -> 34.9 us at M = 16, 54 -> 45 us at M = 32); its ticket counters live in `work`, which the caller zero-fills ONCE
     const int64_t fix_floats = tr1_gemm_skinny_fixup_workspace_floats(R, hid, inter);
     void* fix = c.take(fix_floats * 4);
+    // relevant-tile lists of this step's split-KV attention: written by layer 0's launch, read by the others (TR1_ATTN_PLAN=0: every layer builds its own)
+    static int use_plan = -1;
+    if (use_plan < 0) { const char* e = getenv("TR1_ATTN_PLAN"); use_plan = e ? atoi(e) : 1; }
+    void* plan = c.take(tr1_attn_plan_ints(T, nh, nkv, B) * 4);
+    const bool planned = use_plan && nsplit > 1 && L > 1;
     const bool down_fixup = !w8 && R >= 16 && inter >= 8192;
     const bool down_fixup8 = w8 == 2 && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
     TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");
@@ -75,8 +81,8 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
             CK(tr1_norm_gemm_skinny(h, w[0], w[1], w[2], qkv, R, qkvd, hid, hid, hid, qkvd, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
         }
-        CK(tr1_attn_fwd(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
-                        scap, stream));
+        CK(tr1_attn_fwd_planned(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
+                                scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
         if (w8) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
         else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
         if (w8) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));

@@ -418,9 +418,14 @@ class HipOps:
                     _p(slots), R, n_heads, n_kv, head_dim, self._s())
         return q
 
+    def attn_plan(self, T, n_heads, n_kv, n_batch=1):
+        """int32 buffer for attn_fwd(plan=..., plan_mode=1|2): the relevant-tile lists of one decode step, shared by its layers."""
+        return self.zeros(self.L.raw("tr1_attn_plan_ints")(T, n_heads, n_kv, n_batch), dtype=I32)
+
     def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
-                 kv_batch_slots=0):
-        """n_batch > 1: q/out/masks hold n_batch problems of T = rows/n_batch tokens each; problem b reads cache slots from b*kv_batch_slots."""
+                 kv_batch_slots=0, plan=None, plan_mode=0):
+        """n_batch > 1: q/out/masks hold n_batch problems of T = rows/n_batch tokens each; problem b reads cache slots from b*kv_batch_slots.
+        plan / plan_mode: split-KV decode only - mode 1 publishes the tile lists of these masks in `plan`, mode 2 reuses them (same masks)."""
         self._chk(q, k, vt)
         assert pre.dtype == I32 and lo.dtype == I32 and hi.dtype == I32
         rows = q.shape[0]
@@ -432,6 +437,11 @@ class HipOps:
         if nsplit > 1:
             nws = n_batch * self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
             ws = self._workspace("attn_split", nws, F32)
+        if plan_mode:
+            assert plan is not None and plan.dtype == I32 and plan.numel() >= self.L.raw("tr1_attn_plan_ints")(T, n_heads, n_kv, n_batch)
+            self.L.call("tr1_attn_fwd_planned", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
+                        n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, _p(plan), int(plan_mode), self._s())
+            return o, lse
         self.L.call("tr1_attn_fwd", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
                     n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, self._s())
         return o, lse

@@ -20,7 +20,11 @@ int main(int argc, char** argv) {
     hipMemcpy(dpre, pre.data(), R * 4, hipMemcpyHostToDevice); hipMemcpy(dlo, lo.data(), R * 4, hipMemcpyHostToDevice); hipMemcpy(dhi, hi.data(), R * 4, hipMemcpyHostToDevice);
     const int64_t wsf = B * tr1_attn_fwd_workspace_floats(G, H, NKV, HD, nsplit);
     hipMalloc(&ws, wsf * 4);
-    auto run = [&]() { return tr1_attn_fwd(q, H * HD, k, NKV * HD, vt, B * S, o, H * HD, nullptr, dpre, dlo, dhi, G, H, NKV, S, HD, 0.088f, nsplit, ws, wsf, B, S, nullptr); };
+    // argv[3] = 1: timelines of a plan_mode 2 launch (tile lists published by one plan_mode 1 launch first)
+    const int planned = argc > 3 ? atoi(argv[3]) : 0;
+    void* plan; hipMalloc(&plan, tr1_attn_plan_ints(G, H, NKV, B) * 4); hipMemset(plan, 0, tr1_attn_plan_ints(G, H, NKV, B) * 4);
+    if (planned) tr1_attn_fwd_planned(q, H * HD, k, NKV * HD, vt, B * S, o, H * HD, nullptr, dpre, dlo, dhi, G, H, NKV, S, HD, 0.088f, nsplit, ws, wsf, B, S, plan, 1, nullptr);
+    auto run = [&]() { return tr1_attn_fwd_planned(q, H * HD, k, NKV * HD, vt, B * S, o, H * HD, nullptr, dpre, dlo, dhi, G, H, NKV, S, HD, 0.088f, nsplit, ws, wsf, B, S, plan, planned ? 2 : 0, nullptr); };
     for (int i = 0; i < 10; ++i) if (run()) { printf("error %s\n", g_err); return 1; }
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
