@@ -77,6 +77,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
         if (valid[cb]) { wmaxpre = max(wmaxpre, pre[cb]); if (hi[cb] >= lo[cb]) { wminlo = min(wminlo, lo[cb]); wmaxhi = max(wmaxhi, hi[cb]); } }
     }
+    // Q fragments (B operand): Q[q = u][d = ks*32 + g*8 .. +8].  q was written by the previous kernel (an L2 miss, ~2 us): requested here, in front
+    // of the mask reduction / plan hand-off, so that it has landed when the first tile is staged (the compiler waits for ALL outstanding loads
+    // there).  (Round 1, without the speculated first tile: issuing them early measured slower, 3.95 vs 3.86 ms per decode step.)
+    bf16x8_t qf[CB][D / 32];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const bf16_t* qrow = p.Q + (int64_t)tq[cb] * p.q_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) qf[cb][ks] = load_row_frag(qrow, ks * 32 + g * 8, p.d_real, valid[cb]);
+    }
     TileRange tr{0, 0, 0};
     if (!planned) {                                                         // block-uniform
 #pragma unroll
@@ -95,14 +105,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const bool wave_active = __builtin_amdgcn_readfirstlane((int)(R0 < nR)) != 0;
 
 
-    // Q fragments (B operand): Q[q = u][d = ks*32 + g*8 .. +8]  (issuing these before the mask reduction measured slower: 3.95 vs 3.86 ms per decode step)
-    bf16x8_t qf[CB][D / 32];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        const bf16_t* qrow = p.Q + (int64_t)tq[cb] * p.q_ld + (int64_t)(kvh * p.group + hq[cb]) * p.d_real;
-#pragma unroll
-        for (int ks = 0; ks < D / 32; ++ks) qf[cb][ks] = load_row_frag(qrow, ks * 32 + g * 8, p.d_real, valid[cb]);
-    }
 
     f32x4_t o[D / 16][CB];
     float m[CB], l[CB];
@@ -158,12 +160,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
     const int n_my = (split < n_rel) ? (n_rel - split + p.nsplit - 1) / p.nsplit : 0;
 #define TILE_KV0(i) ((int64_t)(planned ? lds_list[i] : use_list ? lds_list[split + (i) * p.nsplit] : att_tile_at(tr, split + (i) * p.nsplit)) * ATT_KV)
+    // Split-KV decode with the speculated first tile already in flight: stage it into LDS BEFORE the other tiles are requested.  The tiles
+    // travel through registers, so the compiler places the s_waitcnt, and with loads on conditional paths it waits for EVERYTHING outstanding
+    // (vmcnt(0)) in front of a tile_store_lds: requested first, tiles 1 and 2 would hold back tile 0 by a full memory latency.
+    const bool spec_hit = PF > 1 && spec && n_my > 0 && TILE_KV0(0) == spec_kv0;        // block-uniform
+    if (spec_hit) tile_store_lds<D>(rg[0], dyn_lds, dyn_lds + KBYTES, TILE_KV0(0), p.n_slots, p.d_real);
 #pragma unroll
     for (int j = 0; j < PF; ++j)
-        if (j < n_my && !(j == 0 && spec && TILE_KV0(0) == spec_kv0))
+        if (j < n_my && !(j == 0 && spec_hit))
             tile_load_regs<D>(rg[j], p.K, p.k_ld, p.VT, p.vt_ld, kvh, TILE_KV0(j), p.n_slots, p.d_real);
     if (n_my > 0) {
-        tile_store_lds<D>(rg[0], dyn_lds, dyn_lds + KBYTES, TILE_KV0(0), p.n_slots, p.d_real);
+        if (!spec_hit) tile_store_lds<D>(rg[0], dyn_lds, dyn_lds + KBYTES, TILE_KV0(0), p.n_slots, p.d_real);
         if (PF < n_my) tile_load_regs<D>(rg[0], p.K, p.k_ld, p.VT, p.vt_ld, kvh, TILE_KV0(PF), p.n_slots, p.d_real);
     }
     __syncthreads();
