@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         pre[cb] = valid[cb] ? p.pre[tq[cb]] : 0;
         lo[cb] = valid[cb] ? p.lo[tq[cb]] : 1;
         hi[cb] = valid[cb] ? p.hi[tq[cb]] : 0;
-        if (valid[cb]) { wmaxpre = max(wmaxpre, pre[cb]); if (hi[cb] >= lo[cb]) { wminlo = min(wminlo, lo[cb]); wmaxhi = max(wmaxhi, hi[cb]); } }
     }
     // Q fragments (B operand): Q[q = u][d = ks*32 + g*8 .. +8].  q was written by the previous kernel (an L2 miss, ~2 us): requested here, in front
     // of the mask reduction / plan hand-off, so that it has landed when the first tile is staged (the compiler waits for ALL outstanding loads
@@ -89,6 +88,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     }
     TileRange tr{0, 0, 0};
     if (!planned) {                                                         // block-uniform
+        // (the first USE of the mask values: with a plan they are not touched before the tile loop, so the row masks, the speculated tile, the
+        //  plan entries and the Q fragments are ONE memory round trip instead of two)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            if (valid[cb]) { wmaxpre = max(wmaxpre, pre[cb]); if (hi[cb] >= lo[cb]) { wminlo = min(wminlo, lo[cb]); wmaxhi = max(wmaxhi, hi[cb]); } }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
             wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
