@@ -459,6 +459,29 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
 
+def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):
+    """A reader block holds one plan entry per thread: with few splits and many relevant tiles (n_rel > 256 * nsplit) the publishing launch stores
+    count -1 and the reading launches take the full path - still the same bits."""
+    G, C, step, nh, nkv, hd, P, nsplit = 4, 64, 63, 4, 1, 128, 40000, 2       # 625 prefix tiles + 4 suffix tiles > 256 * 2
+    S = P + G * C
+    k = (torch.randn(S, nkv * hd, generator=torch.Generator().manual_seed(1)) * 0.3).to(BF16).cuda()
+    vt = (torch.randn(nkv * hd, S, generator=torch.Generator().manual_seed(2)) * 0.3).to(BF16).cuda()
+    q = rnd(G, nh * hd, seed=3).cuda()
+    pre = torch.full((G,), P, dtype=torch.int32).cuda()
+    lo = (P + torch.arange(G) * C).int().cuda()
+    hi = (lo + step).int()
+    plan = hip_ops.attn_plan(G, nh, nkv, 1)
+    o0, _ = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=nsplit, need_lse=False)
+    o0 = o0.clone()
+    o1, _ = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, plan=plan, plan_mode=1)
+    o1 = o1.clone()
+    assert int(plan[1024]) == -1, int(plan[1024])
+    o2, _ = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, plan=plan, plan_mode=2)
+    assert torch.equal(o0, o1) and torch.equal(o0, o2)
+    with pytest.raises(RuntimeError):       # a plan needs split-KV
+        hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=1, need_lse=False, plan=plan, plan_mode=1)
+
+
 @pytest.mark.parametrize("T,H,W,Ho,Wo", [(8, 360, 640, 364, 644), (6, 360, 640, 308, 532), (3, 240, 320, 112, 140), (4, 100, 90, 196, 168)])
 def test_video_preprocess_fused(hip_ops, ref_ops, T, H, W, Ho, Wo):
     """Fused resize (bicubic AA) + normalise + patchify vs the CPU chain (F.interpolate antialias -> round/clamp -> patchify)."""
