@@ -63,6 +63,13 @@ def main():
     ap.add_argument("--finetune", action="store_true", help="fine-tune wiring: pre-decoded clips + TimeR1_Trainer_ft (reference finetune.py)")
     ap.add_argument("--video_folder", default=None)
     ap.add_argument("--preprocessed_data_path", default=None)
+    # sample filtering stage of the curriculum loop (reference scripts/posttrain/train_rl_SF.sh:86-110): after training, answer every query of
+    # --filter_split greedily with the trained engine, score difficulty = 100 x tIoU and write the next epoch's training set
+    ap.add_argument("--filter_split", default=None, help="annotation json to score and filter after training (usually --train_data_path)")
+    ap.add_argument("--filter_output_dir", default=None)
+    ap.add_argument("--filter_task", default="0070_all", choices=["0070_all", "gaussian_03", "random_sample"])
+    ap.add_argument("--filter_k", type=int, default=2500)
+    ap.add_argument("--filter_max_new_tokens", type=int, default=1024)
     ns, _unknown = ap.parse_known_args()      # unknown reference flags (--fp16 ...) are ignored on purpose
     init_from_env("cuda")
     set_global_seed(42)
@@ -87,6 +94,17 @@ def main():
     else:
         trainer.train()
     trainer.save_model(args.output_dir)
+    if ns.filter_split and trainer.state.is_world_process_zero:
+        from time_r1_amd import filtering
+        from time_r1_amd.evaluate import evaluate_grounding
+        from time_r1_amd.data import _clean_sentence
+        items = filtering.load_filter_split(ns.filter_split)
+        rows = [{"task_type": "tg", "problem": _clean_sentence(it["sentence"]), "choices": "", "solution": (float(it["timestamp"][0]), float(it["timestamp"][1])),
+                 "video_path": it["video"], "durations": it["duration"], "video_start": it["video_start"], "video_end": it["video_end"],
+                 "preprocessed_path": ""} for it in items]
+        _, records = evaluate_grounding(trainer, rows, max_new_tokens=ns.filter_max_new_tokens)
+        shares, path = filtering.filter_epoch(items, records, ns.filter_output_dir or os.path.join(args.output_dir, "filtering"), ns.filter_task, ns.filter_k)
+        print("filtering: share of samples with tIoU > 0.3 / 0.5 / 0.7 = %s; next training set: %s" % (shares, path))
 
 
 if __name__ == "__main__":
