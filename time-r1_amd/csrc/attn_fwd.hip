@@ -26,7 +26,17 @@ template <int D, int CB, int PF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     TR1_PROBE_AT(0);
     constexpr int KSTR = 2 * D + 16;
-    const int bidx = blockIdx.y / p.n_kv;
+    // logical block coordinates: the 3-D grid itself for split-KV decode, the XCD-contiguous re-mapping of a 1-D grid otherwise
+    int bx = blockIdx.x, by_ = blockIdx.y, gx = gridDim.x, gy = gridDim.y;
+    if (PF == 1 && p.xcd_pad > 0) {
+        // chunks of 8 consecutive logical blocks (8 query tiles of one head: about one ViT segment, or neighbouring causal tiles of similar
+        // weight) are dealt round-robin to the XCDs: sharing inside a chunk, balance across XCDs
+        const int L = (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int logical = (((slot >> 3) << 3) + xcd) * 8 + (slot & 7);
+        if (logical >= p.grid_x * p.grid_y) return;                         // padding block (the grid is rounded up to a multiple of 8)
+        gx = p.grid_x; gy = p.grid_y; by_ = logical / gx; bx = logical - by_ * gx;
+    }
+    const int bidx = by_ / p.n_kv;
     {   // batched launch (decode over several prompts' caches): blockIdx.y = b * n_kv + kvh
         const int b = bidx;
         p.Q += (int64_t)b * p.T * p.q_ld; p.O += (int64_t)b * p.T * p.o_ld;
@@ -39,15 +49,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     int* lds_meta = reinterpret_cast<int*>(dyn_lds + 2 * BUF);          // [4][3]
     int* lds_list = lds_meta + 16;                                      // split-KV decode: [ATT_LIST_CAP] relevant tile ids + their count
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int kvh = blockIdx.y % p.n_kv, split = blockIdx.z;
+    const int kvh = by_ % p.n_kv, split = blockIdx.z;
     const int64_t nR = (int64_t)p.T * p.group;
     // query tiles are walked from the LAST one down: later rows of the packed sequence see more keys (causal prompt rows, then the completion
     // rows with the whole prefix), so the heaviest blocks are dispatched first and the light ones fill the tail (longest-processing-time order)
-    const int qtile = (int)(gridDim.x - 1 - blockIdx.x);
+    const int qtile = (int)(gx - 1 - bx);
     const int64_t R0 = (int64_t)qtile * (64 * CB) + wave * (16 * CB);
     // plan_mode 2: this block's tile list was stored by the first layer's launch of the same decode step.  The count is a scalar load; the
     // block's own entries (list[split + t * nsplit], t = thread) are requested at once, clamped into the plan - entries beyond the count are never used.
-    int* plan_blk = (PF > 1 && p.plan) ? p.plan + ((int64_t)bidx * gridDim.x + qtile) * (ATT_LIST_CAP + 1) : nullptr;
+    int* plan_blk = (PF > 1 && p.plan) ? p.plan + ((int64_t)bidx * gx + qtile) * (ATT_LIST_CAP + 1) : nullptr;
     int plan_n = -1, plan_mine = 0;
     if (PF > 1 && p.plan_mode == 2) {
         plan_n = plan_blk[ATT_LIST_CAP];
@@ -297,12 +307,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                 p.lse[(int64_t)(kvh * p.group + hq[cb]) * p.T + tq[cb]] = l[cb] > 0.f ? (m[cb] + log2f(l[cb])) * 0.6931471805599453f : NEG_INF;
         }
     } else {
-        const int64_t nRpad = (int64_t)gridDim.x * (64 * CB);
+        const int64_t nRpad = (int64_t)gx * (64 * CB);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             if (!valid[cb]) continue;
             const int64_t R = R0 + cb * 16 + u;
-            const int64_t slot = ((int64_t)split * gridDim.y + blockIdx.y) * nRpad + R;
+            const int64_t slot = ((int64_t)split * gy + by_) * nRpad + R;
             float* op = p.Opart + slot * D;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4_t*>(op + dt * 16 + g * 4) = o[dt][cb];
@@ -497,6 +507,13 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
         p.Opart = (float*)ws_f32; p.mpart = p.Opart + nsplit * n_batch * n_kv * nRpad * d_pad; p.lpart = p.mpart + nsplit * n_batch * n_kv * nRpad;
     }
     dim3 grid(qtiles, (unsigned)(n_kv * n_batch), (unsigned)nsplit);
+    static int xcd_map = -1;                         // TR1_ATTN_XCD=0: plain 2-D grid for the nsplit == 1 launches (A/B measurements)
+    if (xcd_map < 0) { const char* e = getenv("TR1_ATTN_XCD"); xcd_map = e ? atoi(e) : 1; }
+    if (!decode && xcd_map) {
+        p.grid_x = qtiles; p.grid_y = (int)(n_kv * n_batch);
+        p.xcd_pad = (p.grid_x * p.grid_y + 63) / 64 * 64;
+        grid = dim3((unsigned)p.xcd_pad, 1, 1);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (decode) {
         switch (d_pad) {
