@@ -31,7 +31,7 @@ from time_r1_amd.config import PRESETS  # noqa: E402
 from time_r1_amd.params import ModelParams  # noqa: E402
 from time_r1_amd.model import Engine  # noqa: E402
 from time_r1_amd.grpo import GRPOCore, eos_mask, group_advantages  # noqa: E402
-from time_r1_amd.synthetic import synthetic_prompt  # noqa: E402
+from time_r1_amd.synthetic import synthetic_prompt, piece_decode  # noqa: E402
 from time_r1_amd import rewards as R  # noqa: E402
 from time_r1_amd import vision_process as VP  # noqa: E402
 from time_r1_amd.dist import init_from_env, DataParallel  # noqa: E402
@@ -43,15 +43,6 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec
 SRC_HW = (360, 640)         # synthetic source resolution
 VIDEO_ELE = {"total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}      # reference timer1_trainer.py:503-509
 
-_PIECES = ["<think>", "</think>", "<answer>", "</answer>", " to ", " and ", "1", "2", "3", "4", "5", "6", "7", "8", "9", "0", ".", " ", "the", "person",
-           "because", "\n", "step", "observe", "<timestep>", "</timestep>"]
-
-
-def fake_decode(ids_row):
-    """No tokenizer files exist offline: a fixed id -> text piece map so that the real reward callbacks run on real strings."""
-    return "".join(_PIECES[int(i) % len(_PIECES)] for i in ids_row)
-
-
 def window_plan(n_steps, ga):
     """K micro-steps -> window sizes: full windows of `ga`, then the remainder (every window ends in an optimizer step)."""
     n_steps, ga = int(n_steps), max(1, int(ga))
@@ -62,22 +53,21 @@ def window_plan(n_steps, ga):
 
 
 class Workload:
+    """The benchmark's job: a `TimeR1_Trainer` (the drop-in class the reference's users call, main.py:573-625) on synthetic dataset rows.
+    `window()` = `trainer.optimizer_window(batches)`: the body of `trainer.train()`'s loop, fed by the trainer's own sampler + prefetch
+    thread.  `engine_window()` drives the same engine objects (GRPOCore / AdamWFlat) from a bare loop without the trainer class - the
+    round-1/2 measurement path, kept as a cross-check that the class costs nothing (`engine_path` in the JSON)."""
+
     def __init__(self, args, ops, device, rank):
+        from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig
+        from time_r1_amd.synthetic import SyntheticProcessor, SyntheticClips
         self.cfg = PRESETS[args.model]()
         self.args, self.ops, self.rank = args, ops, rank
         dp = DataParallel()
-        shard = bool(args.shard_optimizer) and dp.enabled      # sharded: master / m / v are allocated as 1/world shards only (AdamWFlat -> Arena.set_shard)
-        self.params = ModelParams(self.cfg, ops, init="none", optimizer_state=not shard)
+        self.shard = bool(args.shard_optimizer) and dp.enabled      # sharded: master / m / v are allocated as 1/world shards only (AdamWFlat -> Arena.set_shard)
+        self.params = ModelParams(self.cfg, ops, init="none", optimizer_state=not self.shard)
         if hasattr(self.params, "init_random_device"):
             self.params.init_random_device(seed=0)
-        self.eng = Engine(self.cfg, ops, self.params)
-        self.ref = self.params.train.clone_weights_only() if args.beta != 0.0 else None
-        self.core = GRPOCore(self.eng, self.ref, args.G, args.C, beta=args.beta, use_grpo=not args.clip_loss, temperature=1.0, top_k=50,
-                             seed=1234 + rank, rope_index_mode="hf4")
-        if args.rollout_fp8 or args.rollout_fp8_w8a16:
-            self.core.roll.weight_dtype = "fp8" if args.rollout_fp8_w8a16 else "fp8-mfma"
-        from time_r1_amd.optim import AdamWFlat
-        self.opt = AdamWFlat(self.params, ops, lr=1e-6, dp=dp, shard_optimizer=shard)
         tiny = args.model.startswith("tiny")
         grid = GRIDS[args.frames] if not tiny else (2, 4, 6)
         self.grid = grid
@@ -85,99 +75,118 @@ class Workload:
         # decoded source frames (uint8, what the reference's video reader returns) and the size plan of the reference's fetch_video_v3
         n_frames = grid[0] * v.temporal_patch_size
         src_hw = SRC_HW if not tiny else (72, 96)
+        self.src_hw = src_hw
         self.target = VP.video_target_size(VIDEO_ELE, n_frames, *src_hw) if not tiny else (56, 84)
         assert (self.target[0] // v.patch_size, self.target[1] // v.patch_size) == tuple(grid[1:]), (self.target, grid)
-        self.prompts = []
-        for i in range(args.n_prompts):
-            ids, _, g = synthetic_prompt(self.cfg, grid, 64, 64, seed=100 * rank + i)
-            gen = torch.Generator().manual_seed(7 + 100 * rank + i)
-            frames = torch.randint(0, 256, (n_frames, 3) + tuple(src_hw), generator=gen, dtype=torch.uint8).to(device)   # staged in HBM before the timed region
-            self.prompts.append((ids, frames, g))
-        self.host_frames = [f.cpu().pin_memory() for _, f, _ in self.prompts] if args.host_frames else None
-        self.P = len(self.prompts[0][0])
+        # every rank holds the whole (tiny) synthetic dataset; the trainer's sampler deals rows perm[rank::world] (staged before the timed region)
+        self.dataset = SyntheticClips(args.n_prompts * dp.world, n_frames, src_hw, device=device, pin=args.host_frames)
         self.reward_funcs = [R.iou_timestamp_reward_v2, R.format_reward]
+        targs = GRPOConfig(output_dir="/tmp/tr1_bench", num_generations=args.G, max_completion_length=args.C, beta=args.beta, use_grpo=not args.clip_loss,
+                           temperature=1.0, top_k=50, seed=1234, rope_index_mode="hf4", gradient_accumulation_steps=args.ga, learning_rate=1e-6,
+                           lr_scheduler_type="constant", logging_steps=1, save_strategy="no", disable_log_print=True, shard_optimizer=self.shard,
+                           rollout_batching=not args.no_rollout_batching,
+                           rollout_weight_dtype="fp8" if args.rollout_fp8_w8a16 else ("fp8-mfma" if args.rollout_fp8 else "bf16"))
+        self.trainer = TimeR1_Trainer(self.params, self.reward_funcs, [], args=targs, train_dataset=self.dataset,
+                                      processing_class=SyntheticProcessor(self.cfg), ops=ops)
+        tr = self.trainer
+        self.eng, self.core, self.opt = tr.engine, tr.core, tr.optimizer
+        self._feed = self._batches()
+        self.P = None
         self.micro = 0
-        self.ev = []
 
-    def _finish(self, st, last, mark, n_in_window):
-        """Policy / reference log-probs, host rewards, loss gradient and backward of one prompt."""
+    def _batches(self):
+        """Endless stream of batches through the trainer's own data path: rank-sharded sampler -> prefetch thread (host half of the
+        preparation: chat template, size plan, tokenisation) -> identity collation."""
+        tr = self.trainer
+        while True:
+            for b in tr._prefetching(tr.get_train_dataloader()):
+                yield b
+
+    # ------------------------------------------------------------------------------------------------------------ trainer path
+    def window(self, n=None):
+        """`n` (default `ga`) micro-steps + one optimizer step through `TimeR1_Trainer.optimizer_window`."""
+        n = self.args.ga if n is None else n
+        tr = self.trainer
+        batches = [next(self._feed) for _ in range(n)]
+        if self.args.ragged_eos:
+            self._ragged_hook()
+        tr.optimizer_window(batches)
+        if self.P is None:
+            self.P = int(tr.core.last_P)
+        self.micro += n
+
+    def _ragged_hook(self):
+        """SURVEY 8d "ragged case": an EOS at a uniform position in [C/2, C) of every row (seed 1); the decode ran all C steps (the
+        reference's generation config has no EOS either), what changes is the mask: loss weights, lengths, counted tokens.  Installed
+        once as a wrapper of the processor's batch_decode input: the trainer's EOS mask is computed from the same host token array."""
+        tr, a = self.trainer, self.args
+        if getattr(tr, "_ragged_installed", False):
+            return
+        tr._ragged_installed = True
+        rng = np.random.default_rng(1 + 7919 * self.rank)
+        core = tr.core
+        orig_many, orig_one = core.rollout_many, core.rollout
+
+        def inject(states):
+            for st in states:
+                toks = st.completion_ids.cpu().numpy().copy()
+                toks[np.arange(a.G), rng.integers(a.C // 2, max(a.C // 2 + 1, a.C), size=a.G)] = self.cfg.eos_token_id
+                st.completion_ids = self.ops.tensor(toks.astype(np.int32), torch.int32)
+
+        def rollout_many(states):
+            out = orig_many(states)
+            inject(states)
+            return out
+
+        def rollout(st):
+            out = orig_one(st)
+            inject([st])
+            return out
+        core.rollout_many, core.rollout = rollout_many, rollout
+
+    # ------------------------------------------------------------------------------------------------------------ bare engine loop
+    def _finish(self, st, last, n_in_window):
+        """Policy / reference log-probs, host rewards, loss gradient and backward of one prompt (no trainer class)."""
         a, core = self.args, self.core
-        # the sampled tokens come to the host BEFORE the log-prob forwards are enqueued (a copy on the same stream waits for everything
-        # queued in front of it): the decode / reward / advantage work below then runs on the host WHILE the GPU computes the log-probs
-        toks_host = getattr(st, "completion_ids_host", None)
-        late = toks_host is None and os.environ.get("TR1_BENCH_TOKENS_LATE") == "1"
-        if toks_host is None and not late:
-            toks_host = st.completion_ids.cpu().numpy()
-        if a.ragged_eos and not late:
-            # SURVEY 8d "ragged case": an EOS at a uniform position in [C/2, C) of every row (seed 1); the decode ran all C steps (the
-            # reference's generation config has no EOS either), what changes is the mask: loss weights, lengths, counted tokens
-            rng = np.random.default_rng(1 + 7919 * self.rank + self.micro)
-            toks_host = np.array(toks_host, copy=True)
-            toks_host[np.arange(a.G), rng.integers(a.C // 2, max(a.C // 2 + 1, a.C), size=a.G)] = self.cfg.eos_token_id
-            st.completion_ids = self.ops.tensor(toks_host.astype(np.int32), torch.int32)
+        toks_host = st.completion_ids_host
         core.forward_logps(st)
-        if late:
-            toks_host = st.completion_ids.cpu().numpy()
-        completions = [fake_decode(r) for r in toks_host]
+        completions = [piece_decode(r) for r in toks_host]
         mask = eos_mask(toks_host, self.cfg.eos_token_id)
         rew = torch.zeros(a.G, len(self.reward_funcs))
         kw = dict(solution=[(2.0, 12.0)] * a.G, durations=[30.0] * a.G)
         for j, fn in enumerate(self.reward_funcs):
             rew[:, j] = torch.tensor(fn(prompts=None, completions=completions, **kw), dtype=torch.float32)
         _, adv, _ = group_advantages(rew, a.G)
-        mark("logps")
         sync = None
         if last and self.opt.dp.enabled and not a.no_grad_overlap:
             sync = self.opt.sync
             sync.begin()                # last micro-step of the window: overlap the RCCL gradient exchange with its backward
-        core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / n_in_window, grad_sync=sync)
-        mark("backward")
-        self.micro += 1
-        self.last_tokens += int(mask.sum())
+        core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga, grad_sync=sync)
 
-    def window(self, timing=None, n=None):
-        """`n` (default `ga`) micro-steps = one optimizer step. The rollouts of the window are decoded together (weights are constant inside
-        an accumulation window, so this is the reference's sequence of micro-steps with the decode GEMMs amortised over n*G rows)."""
-        a, core, v = self.args, self.core, self.cfg.vision
+    def engine_window(self, n=None):
+        a, core, v, tr = self.args, self.core, self.cfg.vision, self.trainer
         n = a.ga if n is None else n
-
-        def mark(name):
-            if timing is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                timing.append((name, e))
-        mark("start")
-        self.last_tokens = 0
-
-        def prepare(j):
-            ids, frames, grid = self.prompts[(self.micro + j) % len(self.prompts)]
-            if a.host_frames:           # PCIe-inclusive variant (reported in DESIGN.md, never the headline value): pinned host frames -> HBM inside the step
-                frames = self.host_frames[(self.micro + j) % len(self.prompts)].to(frames.device, non_blocking=True)
-            # reference: resize + rescale / normalise + patchify inside compute_loss (timer1_trainer.py:531-556) -> here one fused kernel
+        states = []
+        for j in range(n):
+            row = self.dataset[(self.rank + (self.micro + j) * self.opt.dp.world) % len(self.dataset)]
+            frames = row["video_frames"].to(self.ops.device, non_blocking=True)
             pix, g = self.ops.video_preprocess(frames, self.target, v.patch_dim_padded, v.patch_size, v.temporal_patch_size, v.spatial_merge_size)
-            assert tuple(g) == tuple(grid[0]), (g, grid)
-            mark("preprocess")
-            st = core.prepare(ids, pix, grid)
-            mark("vision")
-            return st
+            n_tok = g[0] * g[1] * g[2] // v.merge_unit
+            ids = tr.processing_class.prompt_ids(tr.processing_class.apply_chat_template(tr.make_conversation_video(row)), n_tok)
+            states.append(core.prepare(ids, pix, np.asarray([g])))
         if a.no_rollout_batching:
-            # one prompt at a time: rollout and update of a prompt are interleaved (its saved prefill lives in the single slot-0 buffers)
-            for j in range(n):
-                st = prepare(j)
+            for j, st in enumerate(states):
                 core.rollout(st)
-                mark("rollout")
-                self._finish(st, j == n - 1, mark, n)
+                st.completion_ids_host = st.completion_ids.cpu().numpy()
+                self._finish(st, j == n - 1, n)
         else:
-            states = [prepare(j) for j in range(n)]
             core.rollout_many(states)
-            if os.environ.get("TR1_BENCH_TOKENS_LATE") != "1":                 # (A/B switch: the round-1 order fetched them after enqueuing the forwards)
-                for st in states:
-                    st.completion_ids_host = st.completion_ids.cpu().numpy()     # one wait for the decode loop, ahead of every update
-            mark("rollout")
+            for st in states:
+                st.completion_ids_host = st.completion_ids.cpu().numpy()     # one wait for the decode loop, ahead of every update
             for si, st in enumerate(states):
-                self._finish(st, si == n - 1, mark, n)
+                self._finish(st, si == n - 1, n)
         self.opt.step()
-        mark("optimizer")
+        self.micro += n
 
 
 def measure_peaks(ops, device):
@@ -412,6 +421,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only), fp8 MFMA (W8A8)")
     ap.add_argument("--rollout-fp8-w8a16", action="store_true", help="fp8 weight copies converted to bf16 in registers (bf16 MFMA) instead of the fp8 MFMA")
+    ap.add_argument("--engine-path", action="store_true", help="time the bare engine loop (GRPOCore + AdamWFlat, no TimeR1_Trainer) instead of the trainer class")
+    ap.add_argument("--no-engine-leg", action="store_true", help="skip the short bare-engine-loop cross-check that follows the timed region")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
     ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
                     "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json)")
@@ -464,57 +475,75 @@ def main(argv=None):
     peaks = measure_peaks(ops, device) if (rank == 0 and not args.no_peak_probe) else None
     wl = Workload(args, ops, device, rank)
     dp = DataParallel()
+    tr = wl.trainer
+    run_window = wl.engine_window if args.engine_path else wl.window
 
     for n in window_plan(args.warmup, args.ga):
-        wl.window(n=n)
+        run_window(n=n)
+    tr._flush_metrics()
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
-    timing = []
-    gen_tokens = 0
+    tok0, ph0 = tr.generated_tokens, dict(tr.phase_ms_total)
     timed_plan = window_plan(args.steps, args.ga)
     t0 = time.perf_counter()
     for n in timed_plan:
-        wl.window(timing, n=n)
-        gen_tokens += wl.last_tokens
+        run_window(n=n)
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dp.enabled:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-        gt = torch.tensor([gen_tokens], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(gt)
-        gen_tokens = int(gt.item())
+    tr._flush_metrics()
+    if args.engine_path:
+        gen_tokens = args.steps * world * args.G * args.C        # the bare loop keeps no token counter; all C tokens are generated (EOS suppressed)
+        phases = {}
+    else:
+        gen_tokens = int(tr.generated_tokens - tok0)              # gathered completion lengths of the timed micro-steps, all ranks
+        phases = {k: (v - ph0.get(k, 0.0)) / args.steps for k, v in tr.phase_ms_total.items()}   # per micro-step (rollout / vision are per window / ga)
 
-    phases = {}
-    for (n0, e0), (n1, e1) in zip(timing[:-1], timing[1:]):
-        if n1 != "start":
-            phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1)
-    phases = {k: v / args.steps for k, v in phases.items()}     # per micro-step (the rollout / vision phases are per window / ga)
+    # cross-check: the same engine objects driven by a bare loop without the trainer class (a few windows, after the timed region)
+    engine_leg = None
+    if not args.engine_path and not args.no_engine_leg:
+        n_leg = max(args.ga, min(args.steps, 4 * args.ga) // args.ga * args.ga)
+        wl.engine_window()
+        torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for n in window_plan(n_leg, args.ga):
+            wl.engine_window(n=n)
+        torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
+        engine_leg = {"ms_per_step": 1000.0 * (time.perf_counter() - t1) / n_leg, "steps": n_leg,
+                      "what": "GRPOCore + AdamWFlat driven by a bare loop (no TimeR1_Trainer, no metrics, no log): the round-1/2 measurement path"}
 
     out = None
     if rank == 0:
         cfg = wl.cfg
         value = args.steps * world / dt
+        logs = [h for h in tr.state.log_history if "samples_per_sec" in h]
         out = {
             "metric": "grpo_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "rollout_tokens_per_sec": (gen_tokens / world / args.steps) / (phases.get("rollout", 1e-9) / 1000.0) * world,
+            "path": "bare engine loop (--engine-path)" if args.engine_path else "TimeR1_Trainer.optimizer_window (the loop body of trainer.train(): sampler + prefetch thread, "
+                    "compute path, reward callbacks, metrics, AdamW step, on_step_end, log() every optimizer step)",
+            "rollout_tokens_per_sec": (gen_tokens / world / args.steps) / (max(phases.get("rollout", 0.0), 1e-9) / 1000.0) * world if phases else None,
             "generated_tokens_per_sec_end_to_end": gen_tokens / dt,
             "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
+            "engine_path": engine_leg,
+            "trainer_log_last": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (logs[-1] if logs else {}).items()},
             "optimizer_steps": len(timed_plan), "windows": "%d x %d" % (args.steps // args.ga, args.ga) + (" + 1 x %d" % (args.steps % args.ga) if args.steps % args.ga else ""),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 1e9, 1), "reserved_peak": round(torch.cuda.max_memory_reserved() / 1e9, 1),
                        "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0)), "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))},
             "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
-                                   "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step"
-                                   % (cfg.name, args.frames, str(wl.grid), wl.P, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
-                                      wl.prompts[0][1].shape[2], wl.prompts[0][1].shape[3]),
+                                   "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step%s"
+                                   % (cfg.name, args.frames, str(wl.grid), wl.P or 0, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
+                                      wl.src_hw[0], wl.src_hw[1],
+                                      "; fp8 (e4m3) weights for the SAMPLING policy only - prefill, log-probs, KL and the update read bf16" if (args.rollout_fp8 or args.rollout_fp8_w8a16) else ""),
                        "frames": "pinned host memory, copied to HBM inside the timed step" if args.host_frames else "resident in HBM before the timed region",
                        "completion_lengths": "ragged: EOS injected at uniform[C/2, C) per row, seed 1" if args.ragged_eos else "all C tokens (EOS suppressed)",
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
                        "rollout_weight_dtype": ("fp8-e4m3 weights x e4m3 block-scaled activations, fp8 MFMA (sampling policy only)" if args.rollout_fp8 else
                                                 "fp8-e4m3 weights -> bf16 in registers, bf16 MFMA (sampling policy only)" if args.rollout_fp8_w8a16 else "bf16"),
-                       "optimizer": "zero-sharded (reduce-scatter / local AdamW / all-gather)" if (args.shard_optimizer and world > 1) else "replicated AdamW + gradient all-reduce"},
+                       "optimizer": "zero-sharded (reduce-scatter / local AdamW / all-gather)" if wl.shard else "replicated AdamW + gradient all-reduce"},
         }
     # ---- roofline of the dominant kernel, measured live with HIP events in one extra (untimed) step
     if not args.no_roofline:
@@ -524,7 +553,7 @@ def main(argv=None):
         # op by op from the host so that every GEMM launch can be bracketed by its own pair of HIP events
         wl.core.roll.native_decode = False
         wl.eng.overlap_wgrad = False        # ... and the weight-gradient GEMMs stay on the main stream: a launch timed while another GEMM
-        wl.window()                         # shares the GPU would be charged the other kernel's time
+        run_window()                        # shares the GPU would be charged the other kernel's time
         torch.cuda.synchronize()
         wl.core.roll.native_decode = True
         wl.eng.overlap_wgrad = True

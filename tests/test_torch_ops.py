@@ -160,3 +160,44 @@ def test_ops_inside_a_transformers_qwen2_decoder():
     for k, gr in out["eager"][1].items():
         rel = float((out["timer1"][1][k] - gr).norm() / gr.norm().clamp(min=1e-12))
         assert rel < 0.08, (k, rel)
+
+
+@pytest.mark.gpu
+def test_hf_attention_seam_honours_is_causal_cu_seqlens_and_kv_cache():
+    """transformers routes the Qwen2-VL vision blocks through the same registered function with is_causal=False and
+    flash-style cu_seq_lens; `generate` calls it with S > T.  Each form against an fp32 softmax reference; a padding mask is refused."""
+    import types
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, H, KV, D = 1, 4, 2, 64
+
+    def ref(q, k, v, vis):
+        kh, vh = k[0].float().repeat_interleave(H // KV, 0), v[0].float().repeat_interleave(H // KV, 0)
+        sc = (q[0].float() @ kh.transpose(1, 2)) * D ** -0.5
+        return (torch.softmax(sc.masked_fill(~vis[None], float("-inf")), -1) @ vh).transpose(0, 1)     # [T, H, D]
+
+    def mk(T_, S_):
+        return [(torch.randn(B, h, n, D, device="cuda", generator=g) * 0.5).to(BF16) for h, n in ((H, T_), (KV, S_), (KV, S_))]
+    mod = types.SimpleNamespace(is_causal=True)
+    # (1) vision form: bidirectional inside cu_seqlens segments
+    Tn = 96
+    q, k, v = mk(Tn, Tn)
+    cu = torch.tensor([0, 40, 64, 96], device="cuda", dtype=torch.int32)
+    o, _ = T.hf_attention_forward(mod, q, k, v, None, scaling=D ** -0.5, is_causal=False, cu_seq_lens_q=cu, cu_seq_lens_k=cu)
+    seg = torch.searchsorted(cu[1:].long(), torch.arange(Tn, device="cuda"), right=True)
+    _close(o[0], ref(q, k, v, seg[:, None] == seg[None, :]), 0.02, "vision varlen")
+    # (2) is_causal=False without segments: full attention; module default is_causal is NOT used when the kwarg says False
+    o, _ = T.hf_attention_forward(mod, q, k, v, None, scaling=D ** -0.5, is_causal=False)
+    _close(o[0], ref(q, k, v, torch.ones(Tn, Tn, dtype=torch.bool, device="cuda")), 0.02, "full")
+    # (3) generate with a KV cache: T new queries are the last T of S keys
+    Tq, S = 16, 80
+    q, k, v = mk(Tq, S)
+    o, _ = T.hf_attention_forward(mod, q, k, v, None, scaling=D ** -0.5)
+    vis = torch.arange(S, device="cuda")[None, :] <= (S - Tq + torch.arange(Tq, device="cuda"))[:, None]
+    _close(o[0], ref(q, k, v, vis), 0.02, "suffix queries")
+    # (4) the plain causal float mask transformers builds is accepted, a left-padding mask is refused loudly
+    q, k, v = mk(32, 32)
+    tri = torch.zeros(1, 1, 32, 32, device="cuda").masked_fill(~torch.ones(32, 32, dtype=torch.bool, device="cuda").tril(), float("-inf"))
+    T.hf_attention_forward(mod, q, k, v, tri, scaling=D ** -0.5)
+    pad = tri.clone(); pad[..., :4] = float("-inf")
+    with pytest.raises(NotImplementedError):
+        T.hf_attention_forward(mod, q, k, v, pad, scaling=D ** -0.5)

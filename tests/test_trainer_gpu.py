@@ -64,3 +64,55 @@ def test_hip_full_step_with_rollout_and_optimizer(hip_ops):
         outs.append((tr.last_completions, tr.params.train.w16.clone()))
     assert outs[0][0] == outs[1][0], "same seed -> same sampled completions (Philox keyed by seed,row,step)"
     assert torch.equal(outs[0][1], outs[1][1]) or torch.allclose(outs[0][1].float(), outs[1][1].float(), atol=1e-2)
+
+
+def test_trainer_path_gradients_equal_engine_path_gradients(hip_ops):
+    """the drop-in class adds nothing to the arithmetic.  The same sampled tokens pushed through
+    (a) TimeR1_Trainer.accumulation_window (loader rows, fused preprocessing, deferred metrics) and (b) a bare GRPOCore loop give
+    bit-identical gradient arenas and identical losses."""
+    from time_r1_amd.grpo import eos_mask, group_advantages
+    from time_r1_amd import rewards as R
+    from time_r1_amd import vision_process as VP
+    fx = load_case("grpo_beta")
+    G, C = fx["G"], fx["C"]
+    rows = []
+    for i in range(2):
+        r = dict(fx["row"])
+        r["problem"] = "event %d" % i
+        r["video_frames"] = torch.randint(0, 256, (4, 3, 72, 96), generator=torch.Generator().manual_seed(40 + i), dtype=torch.uint8)
+        rows.append(r)
+    # (a) trainer path: sampled rollout, window of 2
+    cfg, tr = _make(fx, hip_ops)
+    tr.args.gradient_accumulation_steps = 2
+    losses_a = [float(x) for x in tr.accumulation_window([[dict(r)] for r in rows])]
+    toks = None
+    grad_a = tr.params.train.grad.clone()
+    m = tr._metrics
+    assert len(m["reward"]) == 2
+    # the tokens the trainer sampled: replay them through the bare engine loop on a fresh, identically initialised model
+    cfg_b, tr_b = _make(fx, hip_ops)
+    core, ops, v = tr_b.core, hip_ops, cfg_b.vision
+    core.roll.calls = 0
+    states = []
+    for r in rows:
+        T, _, H, W = r["video_frames"].shape
+        th, tw = VP.video_target_size({"total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}, T, H, W)
+        pix, g = ops.video_preprocess(r["video_frames"].to(ops.device), (th, tw), v.patch_dim_padded, v.patch_size, v.temporal_patch_size, v.spatial_merge_size)
+        ids = tr_b.processing_class.prompt_ids("PROMPT", g[0] * g[1] * g[2] // v.merge_unit)
+        states.append(core.prepare(ids, pix, np.asarray([g])))
+    core.rollout_many(states)
+    losses_b = []
+    for st in states:
+        th_ = st.completion_ids.cpu().numpy()
+        core.forward_logps(st)
+        comps = tr_b.processing_class.batch_decode(torch.as_tensor(th_), skip_special_tokens=True)
+        mask = eos_mask(th_, tr_b.processing_class.eos_token_id)
+        rew = torch.zeros(G, 2)
+        kw = dict(solution=[fx["row"]["solution"]] * G, durations=[fx["row"]["durations"]] * G)
+        for j, fn in enumerate([R.iou_timestamp_reward_v2, R.format_reward]):
+            rew[:, j] = torch.tensor(fn(prompts=None, completions=comps, **kw), dtype=torch.float32)
+        _, adv, _ = group_advantages(rew, G)
+        out3, _ = core.loss_backward(st, ops.tensor(mask, torch.int32), ops.tensor(adv.numpy(), torch.float32), 0.5)
+        losses_b.append(float(out3.float()[0]))
+    assert losses_a == losses_b
+    assert torch.equal(grad_a, tr_b.params.train.grad)

@@ -122,6 +122,11 @@ def test_deepspeed_zero_json_selects_the_sharded_optimizer():
     assert TimeR1_Trainer._wants_shard(GRPOConfig(deepspeed="scripts/zero3_offload.json"))
     assert not TimeR1_Trainer._wants_shard(GRPOConfig())
     assert not TimeR1_Trainer._wants_shard(GRPOConfig(deepspeed="scripts/zero3.json", shard_optimizer=False))
+    # world sizes whose chunks are not 128-byte aligned (3, 5, 6, 7) fall back to the replicated optimizer instead of asserting
+    import types
+    for world, want in ((2, True), (3, False), (4, True), (6, False), (8, True)):
+        dp = types.SimpleNamespace(enabled=True, world=world, rank=1)
+        assert TimeR1_Trainer._wants_shard(GRPOConfig(deepspeed="scripts/zero3.json"), dp) == want
 
 
 def test_row_chunked_lm_head_equals_whole_head(monkeypatch):

@@ -38,6 +38,42 @@ class GRPOCore:
         self.roll = Rollout(engine, self.G, self.C, temperature, top_k, seed, stop_at_eos)
         if self.beta != 0.0 and ref_arena is None:
             raise ValueError("beta != 0 needs a reference-policy arena (reference timer1_trainer.py:295-307)")
+        # algorithmic work of what was run since the trainer last read it (TimeR1_Trainer.log -> perf/* keys): bytes the decode steps must
+        # stream (HBM-bound family) and FLOPs of the log-prob forwards + backward (MFMA-bound family); formulas in DESIGN.md section 4
+        self.work = dict(decode_bytes=0.0, train_flops=0.0, decode_ms_events=0.0)
+
+    # ------------------------------------------------------------------------------------------------------- work accounting
+    def _llm_flops(self, rows, pairs):
+        t = self.cfg.text
+        lin = 2.0 * rows * (t.hidden * t.qkv_dim + t.q_dim * t.hidden + 3 * t.hidden * t.intermediate)
+        att = 4.0 * pairs * t.head_dim * t.n_heads
+        return t.n_layers * (lin + att)
+
+    def _count_decode(self, states):      # states: the prompt lengths P of one batched rollout
+        t = self.cfg.text
+        wb = 1.0 if self.roll.weight_dtype in ("fp8", "fp8-mfma") else 2.0
+        w_bytes = wb * (t.n_layers * (t.hidden * t.qkv_dim + t.q_dim * t.hidden + 3 * t.hidden * t.intermediate) + t.vocab_size * t.hidden)
+        G, C = self.G, self.C
+        kv = sum(sum(P + G * s for s in range(1, C)) for P in states) * t.kv_dim * 2 * 2.0 * t.n_layers   # prefix once per prompt + every group's suffix
+        self.work["decode_bytes"] += (C - 1) * w_bytes + kv
+        for e0, e1 in getattr(self.roll, "decode_events", []):
+            e1.synchronize()
+            self.work["decode_ms_events"] += e0.elapsed_time(e1)
+        self.roll.decode_events = []
+
+    def _count_update(self, st, reused_prefill):
+        t = self.cfg.text
+        P, G, C = st.P, self.G, self.C
+        M = P + G * C
+        pairs_c = G * (C * P + C * (C + 1) / 2.0)
+        pairs_all = P * (P + 1) / 2.0 + pairs_c
+        head = 2.0 * G * C * t.vocab_size * t.hidden
+        fl = (self._llm_flops(G * C, pairs_c) if reused_prefill else self._llm_flops(M, pairs_all)) + head        # policy forward
+        if self.beta != 0.0:
+            fl += self._llm_flops(M, pairs_all) + head                                                           # reference-policy forward
+        lin_all = self._llm_flops(M, 0.0)
+        fl += 2.0 * lin_all + 2.5 * (self._llm_flops(M, pairs_all) - lin_all) + 2.0 * head                       # backward (dgrad + wgrad; flash backward = 5 products)
+        self.work["train_flops"] += fl
 
     # ------------------------------------------------------------------------------------------------------- phase 1
     def prepare(self, input_ids, pixel_values_videos, video_grid_thw):
@@ -47,7 +83,7 @@ class GRPOCore:
         st = StepState()
         ids = np.asarray(input_ids, dtype=np.int64).reshape(-1)
         grid = [tuple(int(x) for x in g) for g in np.asarray(video_grid_thw).reshape(-1, 3)]
-        st.P = int(ids.shape[0])
+        st.P = self.last_P = int(ids.shape[0])
         st.grid = grid
         st.prompt_ids_host = ids
         st.prompt_ids = ops.tensor(ids.astype(np.int32), I32)
@@ -80,6 +116,7 @@ class GRPOCore:
         st.layout = lay
         st.completion_ids = tokens        # int32 [G, C] on device
         st.prefill = self.roll.last_prefill[0] if self.reuse_prefill else None
+        self._pending_decode = (getattr(self, "_pending_decode", []) + [[st.P]])[-64:]
         return tokens
 
     def rollout_many(self, states):
@@ -90,7 +127,16 @@ class GRPOCore:
         for b, (st, (tokens, lay)) in enumerate(zip(states, outs)):
             st.layout, st.completion_ids = lay, tokens
             st.prefill = self.roll.last_prefill[b] if self.reuse_prefill else None
+        self._pending_decode = (getattr(self, "_pending_decode", []) + [[st.P for st in states]])[-64:]
         return [st.completion_ids for st in states]
+
+    def drain_work(self):
+        """-> the work counters since the last call (decode events are resolved here, i.e. when the trainer logs - never inside a step)."""
+        for states in getattr(self, "_pending_decode", []):
+            self._count_decode(states)
+        self._pending_decode = []
+        w, self.work = self.work, dict.fromkeys(self.work, 0.0)
+        return w
 
     # ------------------------------------------------------------------------------------------------------- phase 3
     def _packed_inputs(self, st):
@@ -119,6 +165,7 @@ class GRPOCore:
         self._packed_inputs(st)
         tr = eng.params.train
         pf = getattr(st, "prefill", None)
+        self._count_update(st, pf is not None and pf[0] is not None)
         if pf is not None and pf[0] is not None:
             # continuation: only the G*C completion rows; the prompt rows' activations and K/V come from the rollout's prefill
             P, M = st.P, st.layout.M

@@ -156,6 +156,10 @@ class Rollout:
             ids_buf = ops.zeros(R, dtype=I32)
             ids_p = ids_buf.data_ptr()
 
+        timed = torch.device(ops.device).type == "cuda" if getattr(ops, "device", None) is not None else False
+        if timed:          # HIP events around the decode loop (read by the trainer's log(), never waited for here)
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for s in range(C - 1):
             if native:
                 ids_buf.copy_(tokens_all[:, s])
@@ -212,5 +216,9 @@ class Rollout:
             for b, st in enumerate(per):
                 ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
                                   st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+        if timed:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.decode_events = (getattr(self, "decode_events", []) + [(ev0, ev1)])[-64:]
         self.last_prefill = [(st["prefill_ctx"], st["kv"]) for st in per]    # (saved prompt activations, cache views) per prompt
         return [(st["tokens"], st["lay"]) for st in per]

@@ -404,14 +404,38 @@ class TimeR1RMSNorm(torch.nn.Module):
         return rmsnorm(hidden_states, self.weight, self.variance_epsilon)
 
 
-def hf_attention_forward(module, query, key, value, attention_mask=None, dropout=0.0, scaling=None, **kwargs):
-    """transformers AttentionInterface signature: q [B, H, T, D], k / v [B, Hkv, S, D] -> ([B, T, H, D], None).  Causal self-attention per
-    batch element (the decoder path of the reference's logprob forward, timer1_trainer.py:452-457)."""
+def hf_attention_forward(module, query, key, value, attention_mask=None, dropout=0.0, scaling=None, is_causal=None, **kwargs):
+    """transformers AttentionInterface signature: q [B, H, T, D], k / v [B, Hkv, S, D] -> ([B, T, H, D], None).
+    Honours what transformers passes: `is_causal` (decoder: True; the Qwen2-VL / Qwen2.5-VL VISION blocks route through the same function
+    with is_causal=False and flash-style `cu_seq_lens_q` -> bidirectional attention inside each frame / window), S > T (`generate` with a
+    KV cache: the T new queries are the last T of the S keys, causal among themselves) and refuses what it cannot express (a padding /
+    arbitrary additive mask) instead of silently ignoring it.  Reference call site: timer1_trainer.py:452-457 (logprob forward)."""
     B, Hq, T, D = query.shape
     Hkv, S = key.shape[1], key.shape[2]
-    if S != T:
-        raise NotImplementedError("timer1_hip attention: prefill / training forward only (q and k must cover the same tokens)")
-    pre, lo, hi = causal_masks(T, query.device)
+    if S < T:
+        raise NotImplementedError("timer1_hip attention: fewer keys (%d) than queries (%d)" % (S, T))
+    causal = is_causal if is_causal is not None else bool(getattr(module, "is_causal", True))
+    if attention_mask is not None and attention_mask.dtype == torch.bool:
+        full = bool(attention_mask.all())
+    elif attention_mask is not None:
+        # an additive float mask: transformers builds the plain causal triangle for sdpa-like backends; anything else (left padding,
+        # sliding windows, packed documents) cannot be expressed by one (pre, lo, hi) interval per query here
+        tri = torch.ones(T, S, dtype=torch.bool, device=query.device).tril(S - T) if causal else torch.ones(T, S, dtype=torch.bool, device=query.device)
+        full = bool(((attention_mask.reshape(-1, T, S) == 0) == tri).all())
+    else:
+        full = True
+    if not full:
+        raise NotImplementedError("timer1_hip attention: a non-trivial attention_mask (padding / sliding window) was passed; use "
+                                  "attn_implementation='sdpa' for padded batches")
+    cu = kwargs.get("cu_seq_lens_q", kwargs.get("cu_seqlens"))
+    if cu is not None and S == T:
+        pre, lo, hi = varlen_masks(cu.to(query.device), causal=causal)
+    elif causal:
+        z = torch.zeros(T, dtype=I32, device=query.device)
+        pre, lo, hi = z, z, torch.arange(S - T, S, dtype=I32, device=query.device)       # query t sees keys 0 .. (S - T) + t
+    else:
+        z = torch.zeros(T, dtype=I32, device=query.device)
+        pre, lo, hi = z, z, torch.full((T,), S - 1, dtype=I32, device=query.device)
     outs = []
     for b in range(B):
         q2 = query[b].transpose(0, 1).reshape(T, Hq * D)

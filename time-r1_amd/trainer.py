@@ -80,9 +80,11 @@ class GRPOConfig:
     grad_wire_dtype: str = "bf16"           # data-parallel gradient exchange wire format ("bf16" | "fp32")
     shard_optimizer: Optional[bool] = None  # ZeRO-style: master/m/v on 1/world of every arena segment, reduce-scatter grads, all-gather bf16 weights.
                                             # None = follow `deepspeed` (a zero2 / zero3 json, as in every reference script) ; no effect on one GPU
-    gpu_video_preprocess: bool = False      # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path
+    gpu_video_preprocess: Optional[bool] = None   # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path.
+                                            # None = automatic: on whenever the row carries pre-decoded uint8 frames; False forces the host processor
     rollout_weight_dtype: str = "bf16"      # "fp8": the SAMPLING policy reads e4m3 copies of the decoder matrices (row scales, re-quantised every window);
                                             # log-probs, KL and the update keep bf16 weights (BASELINE config "fp8 weights")
+    disable_log_print: bool = False         # keep log() from printing on rank 0 (bench.py prints exactly one JSON line)
     dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
@@ -147,6 +149,40 @@ def _call(cb, name, *a, **k):
         return r
 
 
+class _PhaseClock:
+    """Phase boundaries of the micro-steps (preprocess | vision | rollout | logps | backward | optimizer) as HIP events on the stream the
+    kernels run on - recording costs ~2 us and never waits; the durations are read when `log()` builds the throughput keys.
+    On a CPU op backend (tests) it falls back to the host clock."""
+
+    def __init__(self, ops):
+        dev = getattr(ops, "device", None)
+        self.cuda = dev is not None and torch.device(dev).type == "cuda"
+        self.marks = []
+
+    def mark(self, name):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        else:
+            e = time.perf_counter()
+        self.marks.append((name, e))
+        if len(self.marks) > 4096:           # nobody is reading (a caller driving micro-steps without log()): keep the tail only
+            del self.marks[:2048]
+
+    def drain(self):
+        """-> {phase: milliseconds} summed over the marks recorded so far ("start" marks open an interval and carry no time)."""
+        marks, self.marks = self.marks, []
+        out = {}
+        if self.cuda and marks:
+            marks[-1][1].synchronize()
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            if n1 == "start":
+                continue
+            dt = e0.elapsed_time(e1) if self.cuda else (e1 - e0) * 1e3
+            out[n1] = out.get(n1, 0.0) + dt
+        return out
+
+
 def clip_ratio_metrics(logp, old_logp, advantages, mask, eps_low=0.2, eps_high=0.2):
     """Fractions of completion tokens whose probability ratio exp(logp - old_logp) left the PPO clip range on the side that matters for
     the sign of the advantage: (low, high, either), each sum(flag * mask) / sum(mask) (reference timer1_trainer_ft.py:820-829)."""
@@ -159,11 +195,9 @@ def clip_ratio_metrics(logp, old_logp, advantages, mask, eps_low=0.2, eps_high=0
     return (is_low * m).sum() / tot, (is_high * m).sum() / tot, ((is_low | is_high) * m).sum() / tot
 
 
-def load_model_dir(path, ops):
-    """HF checkpoint directory (config.json + *.safetensors) -> (ModelConfig, ModelParams)."""
-    from safetensors.torch import load_file
-    hc = json.load(open(os.path.join(path, "config.json")))
-    tc = hc.get("text_config", hc)
+def config_from_hf(hc, name="model"):
+    """transformers config dict (config.json / PretrainedConfig.to_dict()) of a Qwen2-VL or Qwen2.5-VL checkpoint -> ModelConfig."""
+    tc = hc.get("text_config") or hc
     vc = hc["vision_config"]
     from .config import TextConfig, VisionConfig
     rope = tc.get("rope_parameters") or tc.get("rope_scaling") or {}
@@ -172,7 +206,7 @@ def load_model_dir(path, ops):
                       rms_eps=tc.get("rms_norm_eps", 1e-6), rope_theta=float(rope.get("rope_theta", tc.get("rope_theta", 1e6))),
                       mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))), tie_word_embeddings=bool(hc.get("tie_word_embeddings", tc.get("tie_word_embeddings", False))))
     tps = 2.0
-    if "Qwen2_5" in "".join(hc.get("architectures", [])) or hc.get("model_type") == "qwen2_5_vl":
+    if "Qwen2_5" in "".join(hc.get("architectures") or []) or hc.get("model_type") == "qwen2_5_vl":
         # Qwen2.5-VL vision config (configuration_qwen2_5_vl.py): hidden_size = ViT width, out_hidden_size = LLM width
         vision = VisionConfig(depth=vc["depth"], embed_dim=vc["hidden_size"], num_heads=vc["num_heads"], mlp_dim=vc["intermediate_size"],
                               out_hidden=vc["out_hidden_size"], patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
@@ -181,22 +215,38 @@ def load_model_dir(path, ops):
                               fullatt_block_indexes=tuple(vc.get("fullatt_block_indexes", (7, 15, 23, 31))))
         tps = float(vc.get("tokens_per_second", 2))
     else:
-        vision = None
-    vision = vision or VisionConfig(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_dim=int(vc["embed_dim"] * vc.get("mlp_ratio", 4)),
-                          out_hidden=vc["hidden_size"], patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
-                          spatial_merge_size=vc.get("spatial_merge_size", 2), in_channels=vc.get("in_channels", vc.get("in_chans", 3)))
+        vision = VisionConfig(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_dim=int(vc["embed_dim"] * vc.get("mlp_ratio", 4)),
+                              out_hidden=vc["hidden_size"], patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
+                              spatial_merge_size=vc.get("spatial_merge_size", 2), in_channels=vc.get("in_channels", vc.get("in_chans", 3)))
     cfg = ModelConfig(text=text, vision=vision, image_token_id=hc["image_token_id"], video_token_id=hc["video_token_id"],
                       vision_start_token_id=hc["vision_start_token_id"], vision_end_token_id=hc["vision_end_token_id"],
-                      eos_token_id=tc.get("eos_token_id", hc.get("eos_token_id", 151645)), pad_token_id=tc.get("pad_token_id", hc.get("pad_token_id", 151643)) or 151643,
-                      tokens_per_second=tps, name=os.path.basename(os.path.normpath(path)))
+                      eos_token_id=tc.get("eos_token_id", hc.get("eos_token_id", 151645)) or 151645, pad_token_id=tc.get("pad_token_id", hc.get("pad_token_id", 151643)) or 151643,
+                      tokens_per_second=tps, name=name)
     if isinstance(cfg.eos_token_id, list):
         cfg.eos_token_id = cfg.eos_token_id[0]
+    return cfg
+
+
+def load_model_dir(path, ops):
+    """HF checkpoint directory (config.json + *.safetensors) -> (ModelConfig, ModelParams)."""
+    from safetensors.torch import load_file
+    cfg = config_from_hf(json.load(open(os.path.join(path, "config.json"))), name=os.path.basename(os.path.normpath(path)))
     sd = {}
     for f in sorted(os.listdir(path)):
         if f.endswith(".safetensors"):
             sd.update(load_file(os.path.join(path, f)))
     params = ModelParams(cfg, ops, init="none")
     params.load_hf_state_dict(sd)
+    return cfg, params
+
+
+def load_hf_module(model, ops):
+    """A loaded transformers model (reference timer1_trainer.py:184-206, :244-262 accepts a `PreTrainedModel` instance as well as a path) ->
+    (ModelConfig, ModelParams): its config and state dict are copied into the engine's arenas; the module itself is not kept."""
+    hc = model.config.to_dict()
+    cfg = config_from_hf(hc, name=str(getattr(model.config, "_name_or_path", "") or type(model).__name__).rstrip("/").split("/")[-1])
+    params = ModelParams(cfg, ops, init="none")
+    params.load_hf_state_dict({k: v.detach() for k, v in model.state_dict().items()})
     return cfg, params
 
 
@@ -209,7 +259,7 @@ class TimeR1_Trainer:
                  max_pixels: Optional[int] = 12845056, min_pixels: Optional[int] = 3136, attn_implementation: str = "flash_attention_2",
                  ops=None):
         if args is None:
-            name = model if isinstance(model, str) else getattr(getattr(model, "cfg", None), "name", "model")
+            name = model if isinstance(model, str) else getattr(getattr(model, "cfg", None), "name", None) or getattr(getattr(model, "config", None), "_name_or_path", None) or "model"
             args = GRPOConfig(output_dir="%s-GRPO" % str(name).split("/")[-1])
         self.args = args
         if peft_config is not None:
@@ -236,8 +286,10 @@ class TimeR1_Trainer:
             self.cfg, self.params = model.cfg, model
         elif isinstance(model, ModelConfig):
             self.cfg, self.params = model, ModelParams(model, ops, seed=args.seed)
+        elif hasattr(model, "state_dict") and hasattr(model, "config"):
+            self.cfg, self.params = load_hf_module(model, ops)      # a loaded transformers model, like the reference accepts
         else:
-            raise TypeError("model must be a checkpoint path, a preset name, a ModelConfig or a ModelParams")
+            raise TypeError("model must be a checkpoint path, a preset name, a ModelConfig, a ModelParams or a loaded transformers model")
         self.model = self.params
         self.engine = Engine(self.cfg, ops, self.params)
         self.beta = args.beta
@@ -286,21 +338,31 @@ class TimeR1_Trainer:
         self.optimizer = AdamWFlat(self.params, ops, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
                                    weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, dp=self.dp,
                                    grad_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_dtype", "bf16") == "bf16" else torch.float32,
-                                   shard_optimizer=self._wants_shard(args))
-        self._metrics = defaultdict(list)
+                                   shard_optimizer=self._wants_shard(args, self.dp))
+        self._metrics_store = defaultdict(list)
+        self._pending = []                   # micro-steps whose device-side metric values have not been fetched yet (_flush_metrics)
+        self._clock = _PhaseClock(ops)
+        self._tok_since_log, self._micro_at_log, self._t_last_log = 0.0, 0, None
+        self.generated_tokens, self.phase_ms_total = 0.0, defaultdict(float)
         self.state = TrainerState()
         self.state.is_world_process_zero = self.dp.rank == 0
         self.control = TrainerControl()
         self.is_deepspeed_enabled = False
         self._micro = 0
+        self._loss_acc, self._tr_loss_last, self._steps_per_epoch = [], 0.0, 0
 
     @staticmethod
-    def _wants_shard(args):
+    def _wants_shard(args, dp=None):
         so = getattr(args, "shard_optimizer", None)
-        if so is not None:
-            return bool(so)
         ds = getattr(args, "deepspeed", None)       # reference scripts: --deepspeed scripts/zero3.json | zero3_offload.json | zero2.json
-        return isinstance(ds, str) and "zero" in os.path.basename(ds).lower()
+        want = bool(so) if so is not None else (isinstance(ds, str) and "zero" in os.path.basename(ds).lower())
+        if want and dp is not None and dp.enabled and dp.world not in (2, 4, 8):
+            # arena segments split into 1/2/4/8 equal 128-byte-aligned chunks (params.SEG_ALIGN); other world sizes train with the replicated
+            # optimizer (same results, more optimizer-state memory) instead of failing at construction where the reference script ran
+            if dp.rank == 0:
+                print("[time-r1_amd] optimizer sharding supports 2 / 4 / 8 ranks; world size %d falls back to the replicated optimizer" % dp.world, flush=True)
+            return False
+        return want
 
     # ------------------------------------------------------------------------------------------------------ prompt building
     def make_conversation_video(self, example):
@@ -349,12 +411,16 @@ class TimeR1_Trainer:
         prompts = [self.make_conversation_video(ex) for ex in inputs]
         prompts_text = [self.processing_class.apply_chat_template(p, tokenize=False, add_generation_prompt=True) for p in prompts]
         frames = example.get("video_frames")
-        if getattr(self.args, "gpu_video_preprocess", False) and torch.is_tensor(frames) and frames.dtype == torch.uint8:
+        gpu_pre = getattr(self.args, "gpu_video_preprocess", None)
+        if (gpu_pre is None or gpu_pre) and torch.is_tensor(frames) and frames.dtype == torch.uint8:
             # pre-decoded uint8 frames: size plan on the host (integers), pixels on the GPU (fused resize + normalise + patchify kernel)
             ele = {"total_pixels": 3584 * 28 * 28, "min_pixels": 16 * 28 * 28}
             T, _, H, W = frames.shape
             th, tw = VP.video_target_size(ele, T, H, W)
-            return dict(prompts=prompts, text=prompts_text, gpu_frames=frames.contiguous(), target=(th, tw))
+            v = self.cfg.vision          # the grid follows from the size plan, so the prompt is tokenised here (prefetch thread) too
+            n_tok = ((T + v.temporal_patch_size - 1) // v.temporal_patch_size) * (th // v.patch_size) * (tw // v.patch_size) // v.merge_unit
+            ids = np.asarray(self._prompt_ids(prompts_text[0], n_tok)).reshape(-1)
+            return dict(prompts=prompts, text=prompts_text, gpu_frames=frames.contiguous(), target=(th, tw), ids_gpu=ids, n_tok=n_tok)
         video_inputs, fps_inputs = self._video_inputs(example)
         prompt_inputs = self.processing_class(text=[prompts_text[0]], images=None, videos=[video_inputs[0]], fps=[fps_inputs[0]], padding=True,
                                               return_tensors="pt", padding_side="left", add_special_tokens=False)
@@ -369,13 +435,15 @@ class TimeR1_Trainer:
         prompts, prompts_text = hp["prompts"], hp["text"]
         if "gpu_frames" in hp:
             v = self.cfg.vision
-            pixels, grid = self.ops.video_preprocess(hp["gpu_frames"].to(self.ops.device), hp["target"], v.patch_dim_padded, v.patch_size,
+            pixels, grid = self.ops.video_preprocess(hp["gpu_frames"].to(self.ops.device, non_blocking=True), hp["target"], v.patch_dim_padded, v.patch_size,
                                                      v.temporal_patch_size, v.spatial_merge_size)
+            self._clock.mark("preprocess")
             n_tok = grid[0] * grid[1] * grid[2] // v.merge_unit
-            ids = np.asarray(self._prompt_ids(prompts_text[0], n_tok)).reshape(-1)
+            ids = hp["ids_gpu"] if hp.get("n_tok") == n_tok else np.asarray(self._prompt_ids(prompts_text[0], n_tok)).reshape(-1)
             st = self.core.prepare(ids, pixels, np.asarray([grid]))
         else:
             st = self.core.prepare(hp["ids"], hp["pixels"], hp["grid"])
+        self._clock.mark("vision")
         forced = example.get("_forced_completion_ids")       # test hook: teacher-forced completions instead of sampling
         if forced is not None:
             from .positions import PackedLayout
@@ -384,6 +452,10 @@ class TimeR1_Trainer:
         return dict(inputs=inputs, st=st, prompts=prompts, forced=forced)
 
     def _step_finish(self, ctx, last_in_window=False):
+        """Log-probs, rewards, loss gradient and backward of one prompt.  Returns the micro-step loss as a DEVICE scalar (HF's compute_loss
+        returns a device tensor too): nothing in here waits for the GPU after the backward is enqueued - the metric values that live on the
+        device (loss, KL, entropy, clip ratios) are packed into one small vector per micro-step and fetched with ONE copy when `log()` (or
+        anybody reading `self._metrics`) asks for them, so the host prepares the next micro-step while this one's backward runs."""
         inputs, st, prompts = ctx["inputs"], ctx["st"], ctx["prompts"]
         G = self.num_generations
         tokens = st.completion_ids
@@ -404,49 +476,94 @@ class TimeR1_Trainer:
         for i, fn in enumerate(self.reward_funcs):
             rewards_per_func[:, i] = torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
         rewards, advantages, std = group_advantages(rewards_per_func, G)
+        metric_vals = None
+        if self._is_ft and self.metric_funcs:
+            metric_vals = torch.stack([torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
+                                       for fn in self.metric_funcs], 1)
+        self._clock.mark("logps")
         scale = 1.0 / max(1, self.args.gradient_accumulation_steps)     # HF divides the loss by GA (model_accepts_loss_kwargs=False, :421-424)
         sync = None
         if last_in_window and self.dp.enabled:
             sync = self.optimizer.sync
             sync.begin()                      # overlap the gradient exchange with this (last) micro-step's backward
-        out3, row_len = self.core.loss_backward(st, self.ops.tensor(mask_np, torch.int32), self.ops.tensor(advantages.numpy(), torch.float32), scale,
-                                                grad_sync=sync)
-        # ---- metrics (reference :739-777; ft adds metrics/<fn> and clip ratios :789-842)
-        dev = self.ops.device
-        gather = self.dp.gather
-        mask_t = torch.as_tensor(mask_np)
-        self._metrics["completion_length"].append(gather(mask_t.sum(1).float().to(dev)).mean().item())
-        rpf = gather(rewards_per_func.to(dev)).mean(0)
-        for i, fn in enumerate(self.reward_funcs):
-            self._metrics["rewards/%s" % fn.__name__].append(rpf[i].item())
-        self._metrics["reward"].append(gather(rewards.to(dev)).mean().item())
-        self._metrics["reward_std"].append(gather(std.to(dev)).mean().item())
-        out3_h = out3.float().cpu()
-        if self.beta != 0.0:
-            self._metrics["kl"].append(gather(out3[1:2]).mean().item())
-        ent = st.entropy.float().cpu()
-        ent_mean = ((ent * mask_t).sum(1) / mask_t.sum(1).clamp(min=1)).mean()
-        self._metrics["generation_entropy"].append(gather(ent_mean.reshape(1).to(dev)).mean().item())
-        if self._is_ft:
-            for fn in self.metric_funcs:
-                vals = torch.tensor(fn(prompts=prompts_rep, completions=completions, **reward_kwargs), dtype=torch.float32)
-                self._metrics["metrics/%s" % fn.__name__].append(gather(vals.to(dev)).mean().item())
-            if not self.use_grpo:   # reference timer1_trainer_ft.py:820-842 (undefined there for use_grpo: coef_1 does not exist)
-                lp = st.logp.float().cpu()
-                low, high, region = clip_ratio_metrics(lp, lp, advantages, mask_t, self.epsilon_low, self.epsilon_high)   # old policy == policy (one update per rollout)
-                g_low, g_high, g_reg = gather(low.reshape(1).to(dev)), gather(high.reshape(1).to(dev)), gather(region.reshape(1).to(dev))
-                self._metrics["clip_ratio/low_mean"].append(g_low.nanmean().item())
-                self._metrics["clip_ratio/low_min"].append(g_low[~g_low.isnan()].min().item() if (~g_low.isnan()).any() else float("nan"))
-                self._metrics["clip_ratio/high_mean"].append(g_high.nanmean().item())
-                self._metrics["clip_ratio/high_max"].append(g_high[~g_high.isnan()].max().item() if (~g_high.isnan()).any() else float("nan"))
-                self._metrics["clip_ratio/region_mean"].append(g_reg.nanmean().item())
+        mask_dev = self.ops.tensor(mask_np, torch.int32)
+        adv_dev = self.ops.tensor(advantages.numpy(), torch.float32)
+        # device-side metric pieces are computed BEFORE the backward releases the step's tensors; tiny [G, C] work on the same stream
+        maskf = mask_dev.to(torch.float32)
+        ent_mean = ((st.entropy.float() * maskf).sum(1) / maskf.sum(1).clamp(min=1)).mean()
+        clip3 = None
+        if self._is_ft and not self.use_grpo:   # reference timer1_trainer_ft.py:820-842 (undefined there for use_grpo: coef_1 does not exist)
+            lp = st.logp.float()
+            clip3 = torch.stack(clip_ratio_metrics(lp, lp, adv_dev, maskf, self.epsilon_low, self.epsilon_high))   # old policy == policy (one update per rollout)
+        out3, row_len = self.core.loss_backward(st, mask_dev, adv_dev, scale, grad_sync=sync)
+        self._clock.mark("backward")
+        out3f = out3.float()
+        dev = torch.cat([out3f[:2], ent_mean.reshape(1)] + ([clip3.float()] if clip3 is not None else []))
+        # ---- metrics (reference :739-777; ft adds metrics/<fn> and clip ratios :789-842): per-sample host values + the device vector,
+        # turned into the reference's gathered means by _flush_metrics
+        self._pending.append(dict(length=mask_np.sum(1).astype(np.float32), rpf=rewards_per_func.numpy().copy(), reward=rewards.numpy().copy(),
+                                  std=std.numpy().copy(), mvals=None if metric_vals is None else metric_vals.numpy(), dev=dev,
+                                  has_clip=clip3 is not None))
         self.last_completions = completions
         self.last_rewards = rewards
-        return out3_h[0]
+        return out3f[0]
+
+    # ------------------------------------------------------------------------------------------------------ deferred metrics
+    @property
+    def _metrics(self):
+        """The reference's `self._metrics` (defaultdict of per-micro-step lists, timer1_trainer.py:739-777).  Reading it resolves the micro-steps
+        whose device-side values are still pending (one packed device-to-host copy, one all-gather under data parallelism)."""
+        self._flush_metrics()
+        return self._metrics_store
+
+    def _flush_metrics(self):
+        pend, self._pending = self._pending, []
+        if not pend:
+            return
+        G, nf = self.num_generations, len(self.reward_funcs)
+        nm = pend[0]["mvals"].shape[1] if pend[0]["mvals"] is not None else 0
+        dev = torch.stack([r["dev"] for r in pend])                     # [n, nd] on the device
+        host = np.stack([np.concatenate([r["length"], r["rpf"].reshape(-1), r["reward"], r["std"]] +
+                                        ([r["mvals"].reshape(-1)] if nm else [])).astype(np.float32) for r in pend])
+        if self.dp.enabled:
+            both = torch.cat([self.ops.tensor(host, torch.float32), dev], 1)
+            allv = self.dp.gather(both[None]).cpu()                      # [world, n, L]
+        else:
+            allv = torch.cat([torch.as_tensor(host), dev.cpu()], 1)[None]
+        M = self._metrics_store
+        o_rpf, o_rew, o_std, o_mv = G, G + G * nf, 2 * G + G * nf, 3 * G + G * nf
+        o_dev = o_mv + G * nm
+        for i, r in enumerate(pend):
+            v = allv[:, i]                                               # [world, L]: rank-major, like accelerator.gather's concatenation
+            M["completion_length"].append(v[:, :G].reshape(-1).mean().item())
+            rpf = v[:, o_rpf:o_rew].reshape(-1, nf).mean(0)
+            for j, fn in enumerate(self.reward_funcs):
+                M["rewards/%s" % fn.__name__].append(rpf[j].item())
+            M["reward"].append(v[:, o_rew:o_std].reshape(-1).mean().item())
+            M["reward_std"].append(v[:, o_std:o_mv].reshape(-1).mean().item())
+            if self.beta != 0.0:
+                M["kl"].append(v[:, o_dev + 1].mean().item())
+            M["generation_entropy"].append(v[:, o_dev + 2].mean().item())
+            if nm:
+                mv = v[:, o_mv:o_dev].reshape(-1, nm)
+                for j, fn in enumerate(self.metric_funcs):
+                    M["metrics/%s" % fn.__name__].append(mv[:, j].mean().item())
+            if r["has_clip"]:
+                g_low, g_high, g_reg = v[:, o_dev + 3], v[:, o_dev + 4], v[:, o_dev + 5]
+                M["clip_ratio/low_mean"].append(g_low.nanmean().item())
+                M["clip_ratio/low_min"].append(g_low[~g_low.isnan()].min().item() if (~g_low.isnan()).any() else float("nan"))
+                M["clip_ratio/high_mean"].append(g_high.nanmean().item())
+                M["clip_ratio/high_max"].append(g_high[~g_high.isnan()].max().item() if (~g_high.isnan()).any() else float("nan"))
+                M["clip_ratio/region_mean"].append(g_reg.nanmean().item())
+            self._tok_since_log += float(v[:, :G].sum())
+            self.generated_tokens += float(v[:, :G].sum())        # cumulative, all ranks
 
     def accumulation_window(self, batches):
         """All micro-steps of one optimizer step. With rollout_batching the G x len(batches) completions are decoded together
-        (weights do not change inside the window, so this equals the reference's sequential micro-steps). Returns the losses."""
+        (weights do not change inside the window, so this equals the reference's sequential micro-steps). Returns the losses
+        (device scalars; nothing here waits for the backward)."""
+        clock = self._clock
+        clock.mark("start")
         if not getattr(self.args, "rollout_batching", True):
             # one prompt at a time, rollout and update interleaved: a sequential rollout keeps its saved prefill (prompt activations, K/V)
             # in the single slot-0 buffers, which the NEXT prompt's prefill overwrites - so each prompt is finished before the next starts
@@ -455,6 +572,7 @@ class TimeR1_Trainer:
                 c = self._step_prepare(b)
                 if c["forced"] is None:
                     self.core.rollout(c["st"])
+                clock.mark("rollout")
                 losses.append(self._step_finish(c, last_in_window=(i == len(batches) - 1)))
             return losses
         ctxs = [self._step_prepare(b) for b in batches]
@@ -465,7 +583,35 @@ class TimeR1_Trainer:
             self.core.rollout(todo[0])
         for st in todo:
             st.completion_ids_host = st.completion_ids.cpu().numpy()        # one wait for the decode loop, ahead of every update
+        clock.mark("rollout")
         return [self._step_finish(c, last_in_window=(i == len(ctxs) - 1)) for i, c in enumerate(ctxs)]
+
+    def optimizer_window(self, window, t_start=None):
+        """One optimizer step = the unit `train()` repeats: the window's micro-steps, the (clipped, fused) AdamW step with the data-parallel
+        gradient exchange, LR schedule, `on_step_end`, logging and step-based checkpoints (TF trainer.py:1892-1961 inner loop body).
+        `bench.py` times exactly this method."""
+        a = self.args
+        if self._t_last_log is None:         # driven without train() (bench.py): the throughput keys count from the first window
+            self._t_last_log, self._micro_at_log = time.perf_counter(), self._micro
+        self._loss_acc.extend(self.accumulation_window(window))
+        self._micro += len(window)
+        gnorm = self.optimizer.step(lr=self._lr(self.state.global_step))
+        self._clock.mark("optimizer")
+        self.state.global_step += 1
+        if self._steps_per_epoch:
+            self.state.epoch = self.state.global_step / self._steps_per_epoch
+        for cb in self.callbacks:
+            _call(cb, "on_step_end", a, self.state, self.control)
+        if a.logging_steps and self.state.global_step % a.logging_steps == 0:
+            # HF logs the mean of the micro-step losses since the last log (training_step returns loss / GA, summed over GA micro-steps);
+            # the losses and the gradient norm are device scalars until here - this is the one place per optimizer step the host waits
+            losses, self._loss_acc = self._loss_acc, []
+            mean_loss = float(torch.stack([torch.as_tensor(x).float().reshape(()) for x in losses]).mean()) if losses else 0.0
+            self._tr_loss_last = mean_loss
+            self.log({"loss": round(mean_loss, 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
+        if a.save_strategy == "steps" and a.save_steps and self.state.global_step % a.save_steps == 0:
+            self._save_checkpoint()
+        return gnorm
 
     # ------------------------------------------------------------------------------------------------------ training loop
     def get_train_dataloader(self):
@@ -548,8 +694,10 @@ class TimeR1_Trainer:
                 b = q.popleft()
                 fill()
                 yield b
-        finally:
+            pool.shutdown(wait=False)        # exhausted: batches already handed out may still be waiting for their worker result
+        except BaseException:                # closed early (max_steps / callback stop) or failed: drop the work nobody will read
             pool.shutdown(wait=False, cancel_futures=True)
+            raise
 
     def training_step(self, inputs):
         return self.compute_loss(self.params, inputs)
@@ -563,6 +711,7 @@ class TimeR1_Trainer:
         loader = self.get_train_dataloader()
         ga = max(1, a.gradient_accumulation_steps)
         steps_per_epoch = max(len(loader) // ga, 1)
+        self._steps_per_epoch = steps_per_epoch
         if self.state.max_steps <= 0:
             self.state.max_steps = a.max_steps if a.max_steps > 0 else math.ceil(a.num_train_epochs * steps_per_epoch)
         n_epochs = math.ceil(self.state.max_steps / steps_per_epoch)
@@ -578,7 +727,8 @@ class TimeR1_Trainer:
         for cb in self.callbacks:
             _call(cb, "on_train_begin", a, self.state, self.control)
         t_start = time.time()
-        tr_loss, n_loss = 0.0, 0
+        self._t_last_log, self._micro_at_log = time.perf_counter(), self._micro
+        self._loss_acc, self._tr_loss_last = [], 0.0
         self.control.should_training_stop = False
         while not self.control.should_training_stop and self.state.global_step < self.state.max_steps and epoch < n_epochs:
             window = []
@@ -586,24 +736,17 @@ class TimeR1_Trainer:
                 window.append(batch)
                 if len(window) < ga:
                     continue
-                for loss in self.accumulation_window(window):
-                    tr_loss += float(loss)
-                    n_loss += 1
-                    self._micro += 1
+                self.optimizer_window(window, t_start)
                 window = []
-                gnorm = self.optimizer.step(lr=self._lr(self.state.global_step))
-                self.state.global_step += 1
-                self.state.epoch = self.state.global_step / steps_per_epoch
-                for cb in self.callbacks:
-                    _call(cb, "on_step_end", a, self.state, self.control)
-                if a.logging_steps and self.state.global_step % a.logging_steps == 0:
-                    # HF logs the mean of the micro-step losses since the last log (training_step returns loss / GA, summed over GA micro-steps)
-                    self.log({"loss": round(tr_loss / max(n_loss, 1), 6), "grad_norm": float(gnorm), "learning_rate": self._lr(self.state.global_step - 1)}, t_start)
-                    tr_loss, n_loss = 0.0, 0
-                if a.save_strategy == "steps" and a.save_steps and self.state.global_step % a.save_steps == 0:
-                    self._save_checkpoint()
                 if self.state.global_step >= self.state.max_steps or self.control.should_training_stop:
                     break
+            if window and len(loader) < ga and self.state.global_step < self.state.max_steps and not self.control.should_training_stop:
+                # an epoch shorter than one accumulation window (small dataset / many ranks): HF steps on the last batch of a short epoch
+                # (TF trainer.py do_sync_step at steps_in_epoch) - without this the run would end after zero optimizer steps
+                self.optimizer_window(window, t_start)
+            elif window and self.dp.rank == 0:
+                print("[time-r1_amd] epoch %d: %d trailing batch(es) do not fill an accumulation window of %d and are dropped (steps_per_epoch = "
+                      "len(loader) // GA, the arithmetic main.py's resume logic uses)" % (epoch, len(window), ga), flush=True)
             skip_batches = 0
             if self.state.global_step < (epoch + 1) * steps_per_epoch:
                 break                      # stopped inside the epoch (max_steps / callback): no epoch-end event
@@ -615,20 +758,55 @@ class TimeR1_Trainer:
                 self._save_checkpoint()
         for cb in self.callbacks:
             _call(cb, "on_train_end", a, self.state, self.control)
-        return types.SimpleNamespace(global_step=self.state.global_step, training_loss=tr_loss / max(n_loss, 1), metrics={"train_runtime": time.time() - t_start})
+        if self._loss_acc:                 # micro-steps since the last log (logging_steps > 1)
+            self._tr_loss_last = float(torch.stack([torch.as_tensor(x).float().reshape(()) for x in self._loss_acc]).mean())
+            self._loss_acc = []
+        return types.SimpleNamespace(global_step=self.state.global_step, training_loss=self._tr_loss_last, metrics={"train_runtime": time.time() - t_start})
 
     # ------------------------------------------------------------------------------------------------------ logging / saving
     def log(self, logs, start_time=None):
+        """The reference's keys (timer1_trainer.py:784-793: means of the per-micro-step metric lists, then cleared) plus the throughput keys
+        SURVEY 5.5 asks this build to emit beside them: `samples_per_sec` / `rollout_tokens_per_sec` (whole job) and the two roofline
+        fractions of the step's dominant kernel families (`perf/*`, from HIP-event phase times and the algorithmic work of the shapes run)."""
         metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}     # reference :784-793
-        logs = {**logs, **metrics}
+        logs = {**logs, **metrics, **self._throughput_keys()}
         if self.state.epoch is not None:
             logs["epoch"] = round(self.state.epoch, 4)
         self.state.log_history.append({**logs, "step": self.state.global_step})
         for cb in self.callbacks:
             _call(cb, "on_log", self.args, self.state, self.control, logs=logs)
-        if self.dp.rank == 0:
+        if self.dp.rank == 0 and not getattr(self.args, "disable_log_print", False):
             print(logs, flush=True)
-        self._metrics.clear()
+        self._metrics_store.clear()
+
+    def _throughput_keys(self):
+        """Whole-job rates since the previous log.  Wall time is this rank's (ranks step in lock-step through the gradient exchange); generated
+        tokens are the gathered completion lengths; phase times are HIP events on the compute stream (read here, after the step was enqueued)."""
+        now = time.perf_counter()
+        ph = self._clock.drain()
+        n_micro = self._micro - self._micro_at_log
+        out = {}
+        if self._t_last_log is not None and n_micro > 0 and now > self._t_last_log:
+            out["samples_per_sec"] = n_micro * self.dp.world / (now - self._t_last_log)
+        toks, self._tok_since_log = self._tok_since_log, 0.0
+        roll_ms = ph.get("rollout", 0.0)
+        if roll_ms > 0 and toks > 0:
+            out["rollout_tokens_per_sec"] = toks / (roll_ms * 1e-3)
+        if n_micro > 0:
+            w = self.core.drain_work()
+            dec_ms = w.get("decode_ms_events") or 0.0
+            if w.get("decode_bytes") and roll_ms > 0:
+                # decode steps stream every decoder + lm_head weight once per step (+ the KV cache): HBM-bound family, peak 8 TB/s
+                out["perf/decode_hbm_frac"] = w["decode_bytes"] / ((dec_ms or roll_ms) * 1e-3) / 8.0e12
+            mm_ms = ph.get("logps", 0.0) + ph.get("backward", 0.0)
+            if w.get("train_flops") and mm_ms > 0:
+                # log-prob forwards + backward: MFMA-bound family, peak 2.5 PFLOP/s dense bf16
+                out["perf/train_mfma_frac"] = w["train_flops"] / (mm_ms * 1e-3) / 2.5e15
+        for k, v in ph.items():
+            out["perf/ms_%s" % k] = v / max(n_micro, 1)
+            self.phase_ms_total[k] += v
+        self._t_last_log, self._micro_at_log = now, self._micro
+        return out
 
     def save_model(self, output_dir=None, _internal_call=False):
         """16-bit weights under transformers key names in one safetensors file (what the reference's ZeRO-3 save gathers, zero3.json:32)."""
@@ -660,9 +838,10 @@ class TimeR1_Trainer:
             sd = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()}
             sd["rollout_calls"] = self.core.roll.calls
             sd["micro"] = self._micro
-            if self.ref_model is not None:
-                sd["ref_w16"] = self.ref_model.w16.cpu()
             torch.save(sd, os.path.join(d, "optimizer_rank%d.pt" % self.dp.rank))
+            if self.ref_model is not None and self.dp.rank == 0:
+                # the frozen reference policy is identical on every rank: one copy per checkpoint (15 GB at 7B), not one per rank
+                torch.save({"ref_w16": self.ref_model.w16.cpu()}, os.path.join(d, "reference_policy.pt"))
         for cb in self.callbacks:
             _call(cb, "on_save", self.args, self.state, self.control)
         self.dp.barrier()
@@ -681,7 +860,10 @@ class TimeR1_Trainer:
             self.optimizer.load_state_dict({k: (v.to(self.ops.device) if torch.is_tensor(v) else v) for k, v in sd.items() if k in ("step", "master", "m", "v", "shard")})
             self.core.roll.calls = sd.get("rollout_calls", 0)
             self._micro = sd.get("micro", 0)
-            if self.ref_model is not None and "ref_w16" in sd:
+            refp = os.path.join(d, "reference_policy.pt")
+            if self.ref_model is not None and os.path.exists(refp):
+                self.ref_model.w16.copy_(torch.load(refp, weights_only=False)["ref_w16"].to(self.ops.device))
+            elif self.ref_model is not None and "ref_w16" in sd:      # checkpoints written before round 3 embedded it per rank
                 self.ref_model.w16.copy_(sd["ref_w16"].to(self.ops.device))
         return self.state.global_step
 
