@@ -69,7 +69,7 @@ def test_hip_full_step_with_rollout_and_optimizer(hip_ops):
 def test_trainer_path_gradients_equal_engine_path_gradients(hip_ops):
     """the drop-in class adds nothing to the arithmetic.  The same sampled tokens pushed through
     (a) TimeR1_Trainer.accumulation_window (loader rows, fused preprocessing, deferred metrics) and (b) a bare GRPOCore loop give
-    bit-identical gradient arenas and identical losses."""
+    identical losses and the same gradient arena (up to fp32 atomic-add order)."""
     from time_r1_amd.grpo import eos_mask, group_advantages
     from time_r1_amd import rewards as R
     from time_r1_amd import vision_process as VP
@@ -114,5 +114,8 @@ def test_trainer_path_gradients_equal_engine_path_gradients(hip_ops):
         _, adv, _ = group_advantages(rew, G)
         out3, _ = core.loss_backward(st, ops.tensor(mask, torch.int32), ops.tensor(adv.numpy(), torch.float32), 0.5)
         losses_b.append(float(out3.float()[0]))
-    assert losses_a == losses_b
-    assert torch.equal(grad_a, tr_b.params.train.grad)
+    assert losses_a == losses_b                                    # forward + loss: bit-identical
+    grad_b = tr_b.params.train.grad
+    # same kernels on the same inputs; the only freedom is the order of the fp32 atomic adds in the embedding / norm-weight gradient kernels
+    rel = float((grad_a - grad_b).norm() / grad_b.norm())
+    assert rel < 1e-5, rel
