@@ -112,7 +112,7 @@ int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_b
 /* Backward of the above (recompute based): needs K, V row-major.  KT / kt_ld are kept for ABI stability and ignored (may be NULL / 0): the dQ
  * kernel reads its K^T fragments from the K rows with ds_read_b64_tr_b16.  QT / dOT (tr1_pack_transpose copies) only for head dims padded to
  * 32 or 96 (may be NULL for 64 / 128: the 8-wave dK/dV kernel transposes in its LDS reads the same way).
- * delta: fp32 [2*n_heads, T] scratch (delta, then the log2-scaled LSE); qmeta_ws: int32 [4*ceil(T*group/64)] scratch; ws_f32: tr1_attn_bwd_workspace_floats() floats (fp32 dK/dV
+ * delta: fp32 [2*n_heads, T] scratch (delta, then the log2-scaled LSE); qmeta_ws: int32 [8*ceil(T*group/64)] scratch; ws_f32: tr1_attn_bwd_workspace_floats() floats (fp32 dK/dV
  * partials of the query-split dK/dV kernel).  Writes dQ [T, n_heads*hd], dK, dV [slots, n_kv*hd]. */
 int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT, int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld, const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld, void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32, int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
 int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim);

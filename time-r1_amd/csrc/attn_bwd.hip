@@ -13,24 +13,50 @@
 #include "attn_common.h"
 #include <stdlib.h>
 
+#define DKDV32_MAXT 512     // query tiles per block of the 32x32x16 kernel (its LDS budget is spent on the tile ring + P exchange)
+#define ATT_QMETA 8         // ints per 64-row query tile in the mask summary written by attn_delta_kernel
+
+// optional wave-timeline probe (tools/bench_attn.py --probe against a -DTR1_PROBE build of the library; not compiled into the product):
+// lane 0 of every wave of ONE block (blockIdx.x == 0, blockIdx.z == 2) stamps s_memtime at up to 8 points of its first 64 tiles
+#ifdef TR1_PROBE
+__device__ unsigned long long* tr1_bwd_probe = nullptr;
+extern "C" int tr1_bwd_probe_set(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_bwd_probe), &ptr, sizeof(ptr)); }
+// the stamps of a tile stay in scalar registers and are written in one burst by BWD_FLUSH: reading an s_memtime result costs an
+// s_waitcnt lgkmcnt(0), which would drain the LDS reads in flight at the stamped point
+#define BWD_STAMPS unsigned long long bwd_st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BWD_STAMP(it, slot) do { bwd_st_[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BWD_FLUSH(it) do { if (tr1_bwd_probe && blockIdx.x == 0 && blockIdx.z == 2 && (threadIdx.x & 63) == 0 && (it) < 64) { \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) tr1_bwd_probe[(((threadIdx.x >> 6) * 64 + (it)) * 8 + s_)] = bwd_st_[s_]; } } while (0)
+#else
+#define BWD_STAMPS do { } while (0)
+#define BWD_STAMP(it, slot) do { } while (0)
+#define BWD_FLUSH(it) do { } while (0)
+#endif
+
 // per 64 packed rows: (max pre, min lo, max hi) over rows with a non-empty [lo,hi].  One wave per tile; runs inside attn_delta_kernel (its
 // first n_qtiles blocks): under a weight-gradient GEMM on the side stream every extra small launch of the main stream waits ~150 us for
 // wave slots, so the 6 us of work used to cost 170 us per layer as a launch of its own.
 TR1_DEV void attn_qmeta_tile(const int* __restrict__ pre, const int* __restrict__ lo, const int* __restrict__ hi, int* __restrict__ qmeta,
                              int T, int group, int tile, int lane) {
     const int64_t R = (int64_t)tile * 64 + lane;
-    int mp = 0, ml = 0x7fffffff, mh = -1, mnp = 0x7fffffff;
+    int mp = 0, ml = 0x7fffffff, mh = -1, mnp = 0x7fffffff, mxl = -1, mnh = 0x7fffffff;
     if (R < (int64_t)T * group) {
         const int t = (int)((unsigned)R / (unsigned)group);
         mp = pre[t]; mnp = pre[t];
-        if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; }
+        if (hi[t] >= lo[t]) { ml = lo[t]; mh = hi[t]; mxl = lo[t]; mnh = hi[t]; }
+        else { mxl = 0x7fffffff; mnh = -1; }                  // a row with an empty [lo, hi] sees no key through its interval
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         mp = max(mp, __shfl_xor(mp, o, 64)); ml = min(ml, __shfl_xor(ml, o, 64)); mh = max(mh, __shfl_xor(mh, o, 64)); mnp = min(mnp, __shfl_xor(mnp, o, 64));
+        mxl = max(mxl, __shfl_xor(mxl, o, 64)); mnh = min(mnh, __shfl_xor(mnh, o, 64));
     }
-    // [3]: the smallest prefix length among the tile's rows - keys below it are visible to EVERY row of the tile (mask-free fast path)
-    if (lane == 0) { qmeta[tile * 4 + 0] = mp; qmeta[tile * 4 + 1] = ml; qmeta[tile * 4 + 2] = mh; qmeta[tile * 4 + 3] = mnp; }
+    // [3]: the smallest prefix length among the tile's rows - keys below it are visible to EVERY row of the tile (mask-free fast path);
+    // [4], [5]: largest lo / smallest hi - keys in [max lo, min hi] are visible to every row as well (causal prompt rows below the diagonal)
+    if (lane == 0) {
+        int* q = qmeta + tile * ATT_QMETA;
+        q[0] = mp; q[1] = ml; q[2] = mh; q[3] = mnp; q[4] = mxl; q[5] = mnh;
+    }
 }
 
 // delta[h][t] = sum_d dO[t,h,d] * O[t,h,d].  16 lanes per (t, h) row, 16 bytes per lane: consecutive rows are consecutive in memory, so a
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
             const int c = base + lane, qi = qz + c * QS;
             bool rel = false;
             if (c < n_cand) {
-                const int mp = p.qmeta[qi * 4], ml = p.qmeta[qi * 4 + 1], mh = p.qmeta[qi * 4 + 2];
+                const int mp = p.qmeta[qi * ATT_QMETA], ml = p.qmeta[qi * ATT_QMETA + 1], mh = p.qmeta[qi * ATT_QMETA + 2];
                 rel = (kvb0 < mp) || (kvb0 + KB - 1 >= ml && kvb0 <= mh);
             }
             const unsigned long long mask = __ballot(rel);
@@ -587,8 +613,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_dma_kernel(AttnParams p
             bool rel = false;
             int mnp = 0;
             if (c < n_cand) {
-                const int mp = p.qmeta[qi * 4], ml = p.qmeta[qi * 4 + 1], mh = p.qmeta[qi * 4 + 2];
-                mnp = p.qmeta[qi * 4 + 3];
+                const int mp = p.qmeta[qi * ATT_QMETA], ml = p.qmeta[qi * ATT_QMETA + 1], mh = p.qmeta[qi * ATT_QMETA + 2];
+                mnp = p.qmeta[qi * ATT_QMETA + 3];
                 rel = (kvb0 < mp) || (kvb0 + KB - 1 >= ml && kvb0 <= mh);
             }
             const unsigned long long mask = __ballot(rel);
@@ -804,6 +830,365 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_dma_kernel(AttnParams p
     }
 }
 
+// ------------------------------------------------------------------------------ dK/dV on 32x32x16 MFMA tiles, role-split wave pairs (head dim 128)
+// Round 3.  The 16x16x32 forms above read one LDS fragment per MFMA and were LDS- / issue-bound (MFMA busy 17-20 %).  Here a wave owns 32 keys
+// and works on v_mfma_f32_32x32x16_bf16 tiles: an operand fragment read from LDS feeds twice the MACs (half the LDS bytes per FLOP), and the
+// register cost of 32 keys (K + V fragments 64, dK + dV accumulators 128, S + dP 64) is split over a PAIR of waves:
+//   role 0:  S = Q K^T  ->  P = exp2(S * scale_log2 - lse2) (masked)  ->  P to its pair partner through LDS  ->  dV^T += dO^T P
+//   role 1:  dP = dO V^T                         (barrier)  ->  dS = P o (dP - delta)                          ->  dK^T += Q^T dS
+// Both roles run the SAME instruction skeleton on swapped tiles (16 MFMAs against the stationary K / V fragments, 16 MFMAs against the
+// transposed tile), ~170 registers each, two waves per SIMD - one of each role (waves w and w + 4 share a SIMD), so one wave's exp2 / pack
+// work runs beside the other's MFMAs.  S and dP come out in the SAME accumulator layout (lane = key, registers = query rows), so the P hand-off
+// is lane-private: each lane writes its 32 values and its partner's same lane reads them back (b128, conflict-free, no shuffles).
+// The C layout of a 32x32 tile (lane (n, h): rows (r&3) + 8(r>>2) + 4h) IS a legal B operand for the next product after a k-permutation:
+// registers 8c..8c+7 = the 16 query rows q = 16c + (j&3) + 8(j>>2) + 4h (j = k-slot of lane half h), and the transposed A operand
+// (dO^T / Q^T: 32 features x those 16 rows) is two ds_read_b64_tr_b16 per lane from the ROW-major tile (rows 4h..4h+3 and 8+4h..8+4h+3).
+// Tile images as in the DMA kernel above (64 rows x 256 B, unpadded, global_load_lds with the swizzle applied on the SOURCE address), but
+// keyed with skey(row) = (row&3)<<2 | (row>>2)&3: the 16 rows of a b128 service group get 16 distinct chunk positions, and the 4 rows x 4
+// chunks of a 32-lane transposing read land in 4 disjoint aligned chunk groups - both read shapes are bank-conflict free.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+TR1_DEV int skey(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+TR1_DEV bf16x8_t pack8(const f32x16_t& c, int b) {
+    u32x4_t w = {pack2bf(c[b], c[b + 1]), pack2bf(c[b + 2], c[b + 3]), pack2bf(c[b + 4], c[b + 5]), pack2bf(c[b + 6], c[b + 7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int n_qtiles, const float* __restrict__ lse2, float* __restrict__ part_k,
+                                                              float* __restrict__ part_v) {
+    constexpr int D = 128, NP = 4, KB = NP * 32;                      // 4 wave pairs x 32 keys
+    constexpr int TILE = 64 * 256, META = 64 * 5 * 4, BUF = 2 * TILE + META, PEX = 64 * 32 * 2;      // P exchange: bf16, one buffer per tile parity
+    static_assert(NB == 3, "ring depth (the top-of-tile wait is vmcnt(0): tile it+1 was requested one iteration ago)");
+    extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][Q rows | dO rows | lse2, delta, pre, lo, hi] | [2][NP] P exchange | tile list
+    char* lds_pex = dyn_lds + NB * BUF;
+    int* lds_tiles = reinterpret_cast<int*>(lds_pex + 2 * NP * PEX);
+    int* lds_full = lds_tiles + DKDV32_MAXT + 1;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c32 = lane & 31, h = lane >> 5;
+    const int role = wave >> 2, pair = wave & 3;
+    const int QS = gridDim.x / p.n_kv;
+    const int kvh = blockIdx.x % p.n_kv, qz = blockIdx.x / p.n_kv;
+    const int kvb0 = blockIdx.z * KB;
+    const int kv = kvb0 + pair * 32 + c32;
+    const bool kv_ok = kv < p.n_slots;
+    const unsigned nR = (unsigned)p.T * (unsigned)p.group;
+
+    if (wave == 0) {      // this block's list of relevant query tiles (qi = qz, qz+QS, ...) and whether every (row, key) pair of the visit is visible
+        int count = 0;
+        const int n_cand = (n_qtiles - qz + QS - 1) / QS;
+        const bool keys_in = kvb0 + KB <= p.n_slots;
+        for (int base = 0; base < n_cand; base += 64) {
+            const int c = base + lane, qi = qz + c * QS;
+            bool rel = false, full = false;
+            if (c < n_cand) {
+                const int* qm = p.qmeta + qi * ATT_QMETA;
+                const int mp = qm[0], ml = qm[1], mh = qm[2], mnp = qm[3], mxl = qm[4], mnh = qm[5];
+                rel = (kvb0 < mp) || (kvb0 + KB - 1 >= ml && kvb0 <= mh);
+                full = keys_in && ((unsigned)qi * 64u + 64u <= nR) && ((kvb0 + KB <= mnp) || (mxl <= kvb0 && kvb0 + KB - 1 <= mnh));
+            }
+            const unsigned long long mask = __ballot(rel);
+            if (rel) { const int at = count + __popcll(mask & ((1ull << lane) - 1ull)); lds_tiles[at] = qi; lds_full[at] = full ? 1 : 0; }
+            count += __popcll(mask);
+        }
+        if (lane == 0) lds_tiles[DKDV32_MAXT] = count;
+    }
+    // stationary B fragments of this wave's 32 keys: K rows (role 0) or V rows (role 1); lane (key c32, half h) holds features ks*16 + h*8 .. +7
+    bf16x8_t sf[D / 16];
+    {
+        const bf16_t* base = role == 0 ? p.K : p.V;
+        const int64_t ld = role == 0 ? p.k_ld : p.v_ld;
+        const bf16_t* srow = base + (int64_t)(kv_ok ? kv : 0) * ld + (int64_t)kvh * D;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) sf[ks] = load_row_frag(srow, ks * 16 + h * 8, D, kv_ok);
+    }
+    f32x16_t acc[4];                                                  // dV^T (role 0) / dK^T (role 1): [32-feature block][C layout]
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+    // the stationary fragments are in registers before the loop - and hipcc must KNOW it (an asm that reads them makes it place the wait itself):
+    // with the loads still pending in its model it would put an s_waitcnt vmcnt(0) in front of their first use in every iteration, which
+    // also waits for the hand-issued DMA.  From here on vmcnt counts DMA only.
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) asm volatile("" ::"v"(sf[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int n_my = lds_tiles[DKDV32_MAXT];
+
+    // ---- DMA of one query tile: 32-bit byte offsets from the uniform bases (the host checked T * ld * 2 < 2^32).  The offsets of a tile are
+    // computed BEFORE the barrier that frees its ring slot (they only depend on the tile id), so that behind the barrier the wave issues its
+    // DMA instructions and nothing else.
+    const char* qbase = reinterpret_cast<const char*>(p.Q) + (int64_t)kvh * p.group * 256;
+    const char* dobase = reinterpret_cast<const char*>(p.dO) + (int64_t)kvh * p.group * 256;
+    const unsigned q_ldb = (unsigned)p.q_ld * 2u, do_ldb = (unsigned)p.do_ld * 2u;
+    struct TileAddr { unsigned q[2], o[2]; unsigned st_t, st_si; };      // byte offsets (the statistics: element indices, n_heads * T < 2^30)
+    auto tile_addr = [&](int qi, TileAddr& ta) {
+        const unsigned Rq0 = (unsigned)qi * 64u;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                  // lane constants are rebuilt here (a handful of VALU), not kept live / spilled
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned row = 4u * (wave * 2 + j) + ((unsigned)ln >> 4);
+            unsigned R = Rq0 + row; R = R < nR ? R : nR - 1;
+            const unsigned tu = p.group == 1 ? R : __umulhi(R, p.group_magic);
+            const unsigned hb = (R - tu * (unsigned)p.group) * 256u + (unsigned)(((ln & 15) ^ skey(row & 15)) << 4);
+            ta.q[j] = tu * q_ldb + hb; ta.o[j] = tu * do_ldb + hb;
+        }
+        if (wave == 7) {
+            unsigned R = Rq0 + (unsigned)ln; R = R < nR ? R : nR - 1;
+            const unsigned tu = p.group == 1 ? R : __umulhi(R, p.group_magic);
+            ta.st_t = tu;
+            ta.st_si = (unsigned)(kvh * p.group + (int)(R - tu * (unsigned)p.group)) * (unsigned)p.T + tu;
+        }
+    };
+    // The DMA instructions are written in assembly: for the builtin, hipcc tracks the asynchronous LDS write and puts an s_waitcnt vmcnt(0)
+    // in front of the next LDS read it cannot prove disjoint (all of them: one dynamic LDS array) - the "prefetch" then completes before the
+    // first operand read of the tile, i.e. nothing is prefetched.  Landing is ordered by the hand-placed vmcnt wait + barrier at the loop top.
+    const unsigned lds_base = (unsigned)(uintptr_t)(att_lptr_t)dyn_lds;
+    const float* dlt_base = p.delta;
+    const int *pre_base = p.pre, *lo_base = p.lo, *hi_base = p.hi;
+#define DMA16(voff, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory", "m0")
+#define DMA4(voff, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory", "m0")
+    auto issue_tile = [&](const TileAddr& ta, int slot) {
+        const unsigned buf = lds_base + slot * BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned dst = buf + (wave * 2 + j) * 1024;
+            DMA16(ta.q[j], qbase, dst);
+            DMA16(ta.o[j], dobase, dst + TILE);
+        }
+        if (wave == 7) {                                              // row statistics (a role-1 wave: its tile work is the lighter one)
+            const unsigned mb = buf + 2 * TILE;
+            const unsigned so = ta.st_si * 4u, to = ta.st_t * 4u;
+            DMA4(so, lse2, mb);
+            DMA4(so, dlt_base, mb + 256);
+            DMA4(to, pre_base, mb + 512);
+            DMA4(to, lo_base, mb + 768);
+            DMA4(to, hi_base, mb + 1024);
+        }
+    };
+#undef DMA16
+#undef DMA4
+    TileAddr ta;
+    if (n_my > 0) { tile_addr(__builtin_amdgcn_readfirstlane(lds_tiles[0]), ta); issue_tile(ta, 0); }
+    if (n_my > 1) { tile_addr(__builtin_amdgcn_readfirstlane(lds_tiles[1]), ta); issue_tile(ta, 1); }
+
+    // ---- LDS addressing.  All reads go through 32-bit LDS addresses built by hand: every tile image, ring slot and half-tile offset is a
+    // multiple of 256 bytes and the swizzle only touches address bits 4..7, so a fragment address is (per-tile base) ^ (compile-time constant)
+    // + an immediate offset - ONE v_xor per distinct fragment column (8 + 8 per tile).  Written as pointer arithmetic, hipcc spent ~3 VALU on
+    // every one of the 60 LDS reads of a tile (v_add3 / v_xad / v_subrev against the rotating slot base): 395 VALU per wave and tile made
+    // the kernel VALU-bound (44 % VALU busy against 29 % MFMA busy).
+    typedef const __attribute__((address_space(3))) bf16x8_t* lds_b128_t;
+    typedef const __attribute__((address_space(3))) f32x4_t* lds_f128_t;
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    typedef const __attribute__((address_space(3))) i32x4_t* lds_i128_t;
+#define LDS_B128(addr) (*(lds_b128_t)(uintptr_t)(addr))
+#define LDS_F128(addr) (*(lds_f128_t)(uintptr_t)(addr))
+#define LDS_I128(addr) (*(lds_i128_t)(uintptr_t)(addr))
+#define LDS_TR16(addr) __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)(addr)))
+    const int ti = lane & 15, tgrp = (lane >> 4) & 1;
+    // b128 A fragment of row c32 (+32 per half): chunk (ks*2 + h) ^ skey(row)      -> byte (ks*32) ^ a_lane inside the row
+    const unsigned a_lane = (unsigned)(c32 * 256 + ((h ^ skey(c32 & 15)) << 4));
+    // transposing read: row 4h + ti/4 (+8: second half, chunk key ^ 2), chunk (db*4 + tgrp*2 + (ti&3)/2) ^ skey(row), 8 bytes at (ti&1)*8
+    const unsigned t_lane = (unsigned)((4 * h + (ti >> 2)) * 256 + (ti & 1) * 8 + (((tgrp * 2 + ((ti & 3) >> 1)) ^ (((ti >> 2) << 2) | h)) << 4));
+    const unsigned pex_lane = lds_base + NB * BUF + pair * PEX + lane * 16;
+    const unsigned st_lane = (unsigned)(16 * h);                      // row statistics: 4 floats / ints from row 4h (+ 8i + 32 qb)
+
+    // phase-1 product of one 32-row half of a tile: c = X[rows qb*32..+31] . sf  (S for role 0 with X = Q, dP for role 1 with X = dO).
+    // Operand reads run a fixed distance ahead of their MFMAs (explicit register ring + scheduling fences): left alone, hipcc hoists every
+    // LDS read of the phase to its top and spills.
+    auto product1 = [&](unsigned xa, f32x16_t& c) {                   // xa: tile rows + qb * 8192 + a_lane (LDS byte address)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        constexpr int AH = 3;                                         // k-steps of lookahead
+        bf16x8_t a[AH + 1];
+#pragma unroll
+        for (int ks = 0; ks < AH; ++ks) a[ks] = LDS_B128(xa ^ (ks * 32));
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            if (ks + AH < D / 16) a[(ks + AH) % (AH + 1)] = LDS_B128(xa ^ ((ks + AH) * 32));
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (AH + 1)], sf[ks], c, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // phase-2 product over two 16-row chunks: acc^T[feature][key] += Y^T[feature][q] * frag[q][key]
+    auto product2 = [&](unsigned ya, const bf16x8_t& f0, const bf16x8_t& f1) {      // ya: tile rows + first chunk * 4096 + t_lane
+        constexpr int TH = 2;                                         // MFMAs of lookahead (3 tips the kernel over the 256-register budget)
+        bf16x8_t a[TH + 1];
+#define P2_LD(n) make_frag(LDS_TR16((ya ^ (((n) & 3) * 64)) + ((n) >> 2) * 4096), LDS_TR16((ya ^ (((n) & 3) * 64 + 32)) + ((n) >> 2) * 4096 + 2048))
+#pragma unroll
+        for (int n = 0; n < TH; ++n) a[n] = P2_LD(n);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {                                 // n = chunk * 4 + db
+            if (n + TH < 8) a[(n + TH) % (TH + 1)] = P2_LD(n + TH);
+            acc[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n % (TH + 1)], (n >> 2) ? f1 : f0, acc[n & 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef P2_LD
+    };
+    // role 0: S of one 32-row half (in c) -> P, packed to two B fragments of the dV product and written to the exchange buffer
+    auto make_p = [&](f32x16_t& c, int qb, unsigned sa, bool full, int rows_valid, bf16x8_t& f0, bf16x8_t& f1, unsigned pex) {   // sa: statistics + st_lane
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4_t l4 = LDS_F128(sa + (qb * 32 + 8 * i) * 4);
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[4 * i + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * i + j], p.scale_log2, -l4[j]));
+            } else {
+                const i32x4_t p4 = LDS_I128(sa + 512 + (qb * 32 + 8 * i) * 4), lo4 = LDS_I128(sa + 768 + (qb * 32 + 8 * i) * 4),
+                              hi4 = LDS_I128(sa + 1024 + (qb * 32 + 8 * i) * 4);
+                const int q1 = qb * 32 + 8 * i + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = kv_ok & att_visible_nb(kv, p4[j], lo4[j], hi4[j]) & (q1 + j < rows_valid);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * i + j], p.scale_log2, -l4[j]));
+                    c[4 * i + j] = ok ? e : 0.f;
+                }
+            }
+        }
+        f0 = pack8(c, 0); f1 = pack8(c, 8);
+        *(__attribute__((address_space(3))) bf16x8_t*)(uintptr_t)(pex + (2 * qb) * 1024) = f0;
+        *(__attribute__((address_space(3))) bf16x8_t*)(uintptr_t)(pex + (2 * qb + 1) * 1024) = f1;
+    };
+    // role 1: dP of one 32-row half (in c) and the partner's P -> dS, packed to two B fragments of the dK product
+    auto make_ds = [&](const f32x16_t& c, int qb, unsigned sa, unsigned pex, bf16x8_t& f0, bf16x8_t& f1) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const u32x4_t pw = __builtin_bit_cast(u32x4_t, LDS_B128(pex + (2 * qb + hf) * 1024));     // P[q rows of the chunk][key]: 8 bf16 in k-slot order
+            const f32x4_t d0 = LDS_F128(sa + 256 + (qb * 32 + hf * 16) * 4), d1 = LDS_F128(sa + 256 + (qb * 32 + hf * 16 + 8) * 4);
+            const int b = hf * 8;
+            u32x4_t w;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                             // masked entries carry P = 0
+                w[e] = pack2bf(bflo(pw[e]) * (c[b + 2 * e] - d0[2 * e]), bfhi(pw[e]) * (c[b + 2 * e + 1] - d0[2 * e + 1]));
+                w[2 + e] = pack2bf(bflo(pw[2 + e]) * (c[b + 4 + 2 * e] - d1[2 * e]), bfhi(pw[2 + e]) * (c[b + 4 + 2 * e + 1] - d1[2 * e + 1]));
+            }
+            if (hf == 0) f0 = __builtin_bit_cast(bf16x8_t, w); else f1 = __builtin_bit_cast(bf16x8_t, w);
+        }
+    };
+
+    // prologue: tile 0 has landed (this wave's share; tile 1 may still be in flight: 4 instructions, wave 7 carries 5 statistics rows more)
+    if (n_my > 1) {
+        if (wave == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (role == 0 && n_my > 0) {                                      // P of tile 0
+        const int qi0 = __builtin_amdgcn_readfirstlane(lds_tiles[0]);
+        const int rv = (int)(nR - (unsigned)qi0 * 64u < 64u ? nR - (unsigned)qi0 * 64u : 64u);
+        const bool full0 = __builtin_amdgcn_readfirstlane(lds_full[0]) != 0;
+        f32x16_t c;
+        bf16x8_t f0, f1;
+        product1(lds_base + a_lane, c);
+        make_p(c, 0, lds_base + 2 * TILE + st_lane, full0, rv, f0, f1, pex_lane);
+        product1(lds_base + 8192 + a_lane, c);
+        make_p(c, 1, lds_base + 2 * TILE + st_lane, full0, rv, f0, f1, pex_lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // One tile loop PER ROLE (same trip count, same barriers): with both roles inside one loop body hipcc gave the accumulators different
+    // registers on the two paths and moved all 64 of them at the join - 130-190 v_mov per tile.
+#define TILE_TOP()                                                                                                                        \
+        BWD_STAMPS;                                                                                                                       \
+        BWD_STAMP(it, 0);                                                                                                                 \
+        if (it + 2 < n_my) tile_addr(__builtin_amdgcn_readfirstlane(lds_tiles[it + 2]), ta);   /* DMA addresses of the tile requested behind the barrier */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* this wave's share of tile it+1 (requested one iteration ago) has landed */ \
+        BWD_STAMP(it, 1);                                                                                                                 \
+        __builtin_amdgcn_s_barrier();                              /* tile it+1 and P(it) are published; everybody is done with tile it-1 */ \
+        asm volatile("" ::: "memory");                                                                                                    \
+        BWD_STAMP(it, 2);                                                                                                                 \
+        if (it + 2 < n_my) issue_tile(ta, (it + 2) % NB);         /* = the slot of tile it-1 */                                           \
+        BWD_STAMP(it, 3);                                                                                                                 \
+        const unsigned buf = lds_base + (unsigned)(it % NB) * BUF;                                                                        \
+        const unsigned pex = pex_lane + (unsigned)(it & 1) * (NP * PEX);   /* P(it): written by the pair's role-0 wave one iteration ago */ \
+        f32x16_t c;                                                                                                                       \
+        bf16x8_t f0, f1
+#define TILE_BOTTOM()                                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        /* all LDS traffic of this tile is complete before the barrier that publishes / frees */ \
+        BWD_STAMP(it, 7);                                                                                                                 \
+        BWD_FLUSH(it)
+    if (role == 0) {
+        for (int it = 0; it < n_my; ++it) {
+            TILE_TOP();
+            // per 32-row half: S(it+1) -> dV(it) over P(it) read back from the exchange buffer (the MFMAs the exp / pack work of S hides under) -> P(it+1)
+            const bool more = it + 1 < n_my;
+            const unsigned nbuf = lds_base + (unsigned)((it + 1) % NB) * BUF;
+            const unsigned npex = pex_lane + (unsigned)((it + 1) & 1) * (NP * PEX);
+            int rv = 64; bool fulln = false;
+            if (more) {
+                const int qn = __builtin_amdgcn_readfirstlane(lds_tiles[it + 1]);
+                rv = (int)(nR - (unsigned)qn * 64u < 64u ? nR - (unsigned)qn * 64u : 64u);
+                fulln = __builtin_amdgcn_readfirstlane(lds_full[it + 1]) != 0;
+            }
+            const unsigned xa = nbuf + a_lane, ya = buf + TILE + t_lane, sa = nbuf + 2 * TILE + st_lane;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (more) product1(xa + hf * 8192, c);
+                if (hf == 0) BWD_STAMP(it, 4);
+                f0 = LDS_B128(pex + (2 * hf) * 1024);
+                f1 = LDS_B128(pex + (2 * hf + 1) * 1024);
+                product2(ya + hf * 8192, f0, f1);
+                if (more) make_p(c, hf, sa, fulln, rv, f0, f1, npex);
+                if (hf == 0) BWD_STAMP(it, 5);
+            }
+            BWD_STAMP(it, 6);
+            TILE_BOTTOM();
+        }
+    } else {
+        for (int it = 0; it < n_my; ++it) {
+            TILE_TOP();
+            const unsigned xa = buf + TILE + a_lane, ya = buf + t_lane, sa = buf + 2 * TILE + st_lane;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                product1(xa + hf * 8192, c);                          // dP = dO V^T, 32 rows
+                if (hf == 0) BWD_STAMP(it, 4);
+                make_ds(c, hf, sa, pex, f0, f1);
+                product2(ya + hf * 8192, f0, f1);                     // dK^T += Q^T dS
+                if (hf == 0) BWD_STAMP(it, 5);
+            }
+            BWD_STAMP(it, 6);
+            TILE_BOTTOM();
+        }
+    }
+#undef TILE_TOP
+#undef TILE_BOTTOM
+#undef LDS_B128
+#undef LDS_F128
+#undef LDS_I128
+#undef LDS_TR16
+    // lane holds acc^T[feature = db*32 + 8i + 4h + j][key c32]: role 0 -> dV, role 1 -> dK (scaled).  The lane coordinates are rebuilt from a
+    // laundered thread id: values kept live across the tile loop for the epilogue get spilled, and ANY scratch access makes hipcc wait on
+    // vmcnt inside the loop - which would also wait for the hand-issued DMA
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int e_c32 = tid2 & 31, e_h = (tid2 >> 5) & 1;
+    const int e_kv = kvb0 + pair * 32 + e_c32;
+    if (e_kv < p.n_slots) {
+        const float scale = role == 0 ? 1.f : p.scale_log2 * 0.6931471805599453f;
+        if (part_k) {
+            const int64_t kvd = (int64_t)p.n_kv * D;
+            float* pp = (role == 0 ? part_v : part_k) + ((int64_t)qz * p.n_slots + e_kv) * kvd + (int64_t)kvh * D;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4_t v = {acc[db][4 * i], acc[db][4 * i + 1], acc[db][4 * i + 2], acc[db][4 * i + 3]};
+                    *reinterpret_cast<f32x4_t*>(pp + db * 32 + 8 * i + 4 * e_h) = v;     // unscaled partials; the reduce kernel scales dK
+                }
+        } else {
+            bf16_t* rowp = (role == 0 ? p.dV + (int64_t)e_kv * p.dv_ld : p.dK + (int64_t)e_kv * p.dk_ld) + (int64_t)kvh * D;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2_t w = {pack2bf(acc[db][4 * i] * scale, acc[db][4 * i + 1] * scale), pack2bf(acc[db][4 * i + 2] * scale, acc[db][4 * i + 3] * scale)};
+                    *reinterpret_cast<u32x2_t*>(rowp + db * 32 + 8 * i + 4 * e_h) = w;
+                }
+        }
+    }
+}
+
 // dK = scale * sum_z part_k[z], dV = sum_z part_v[z]  -> bf16
 __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const float* __restrict__ part_v, bf16_t* __restrict__ dK, int64_t dk_ld,
                                        bf16_t* __restrict__ dV, int64_t dv_ld, int n_slots, int kvd, int QS, float scale) {
@@ -837,7 +1222,7 @@ static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) 
     }
     if (qs > n_qtiles) qs = n_qtiles;
     if (qs < 1) qs = 1;
-    while ((n_qtiles + qs - 1) / qs > DKDV_MAXT) ++qs;
+    while ((n_qtiles + qs - 1) / qs > DKDV32_MAXT) ++qs;
     return (int)qs;
 }
 
@@ -873,6 +1258,18 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dma);
         dma_attr = true;
     }
+    // TR1_DKDV32 (default 1): the 32x32x16-MFMA role-split kernel (round 3) for head dim 128; 0 = the 16x16x32 forms selected by TR1_DKDV_DMA
+    static int v32 = -1;
+    if (v32 < 0) { const char* e = getenv("TR1_DKDV32"); v32 = e ? atoi(e) : 1; }
+    constexpr int V32_NB = 3;
+    const size_t dyn_v32 = V32_NB * (2 * 64 * 256 + 64 * 5 * 4) + 2 * 4 * (64 * 32 * 2) + (2 * DKDV32_MAXT + 2) * 4;
+    static bool v32_attr = false;
+    if (D == 128 && !v32_attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv32_kernel<V32_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_v32);
+        v32_attr = true;
+    }
+    const bool use_v32 = D == 128 && p.d_real == 128 && v32 > 0 && lse2 != nullptr &&
+                         (uint64_t)p.T * (uint64_t)(p.q_ld > p.do_ld ? p.q_ld : p.do_ld) * 2ull < 0xffffffffull;      // 32-bit DMA byte offsets
     const bool use_dma = D == 128 && p.d_real == 128 && dma > 0 && lse2 != nullptr;
     const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots, KB);
     const int64_t kvd = (int64_t)p.n_kv * p.d_real;
@@ -882,7 +1279,8 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
         pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
     }
-    if (use_dma && dma == 2) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
+    if (use_v32) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
+    else if (use_dma && dma == 2) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
     else if (use_dma) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(256), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
     else if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
@@ -900,7 +1298,7 @@ extern "C" int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int
     return QS > 1 ? 2 * (int64_t)QS * n_slots * n_kv * head_dim : 0;
 }
 
-// Scratch: qmeta_ws int32 [4*ceil(T*group/64)], delta fp32 [2*n_heads*T] (delta | log2-scaled LSE), ws_f32 of tr1_attn_bwd_workspace_floats() floats.
+// Scratch: qmeta_ws int32 [8*ceil(T*group/64)], delta fp32 [2*n_heads*T] (delta | log2-scaled LSE), ws_f32 of tr1_attn_bwd_workspace_floats() floats.
 extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
                             int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
                             const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,

@@ -459,7 +459,7 @@ class HipOps:
         dk = self.empty(n_slots, n_kv * head_dim)
         dv = dv_out if dv_out is not None else self.empty(n_slots, n_kv * head_dim)
         delta = self.empty(2 * n_heads, T, dtype=F32)       # [delta | log2-scaled LSE], both written by the backward's first kernel
-        qmeta = self._workspace("attn_qmeta", 4 * ((T * group + 63) // 64), I32)
+        qmeta = self._workspace("attn_qmeta", 8 * ((T * group + 63) // 64), I32)
         nws = self.L.raw("tr1_attn_bwd_workspace_floats")(T, n_heads, n_kv, n_slots, head_dim)
         ws = self._workspace("attn_bwd_part", nws, F32) if nws else None
         self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), None, 0, _p(qt), _ld(qt) if qt is not None else 0, _p(dot), _ld(dot) if dot is not None else 0,
