@@ -853,10 +853,10 @@ TR1_DEV bf16x8_t pack8(const f32x16_t& c, int b) {
     return __builtin_bit_cast(bf16x8_t, w);
 }
 
-template <int NB>
-__global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int n_qtiles, const float* __restrict__ lse2, float* __restrict__ part_k,
+template <int NB, int NP>
+__global__ __launch_bounds__(NP * 128) void attn_bwd_dkdv32_kernel(AttnParams p, int n_qtiles, const float* __restrict__ lse2, float* __restrict__ part_k,
                                                               float* __restrict__ part_v) {
-    constexpr int D = 128, NP = 4, KB = NP * 32;                      // 4 wave pairs x 32 keys
+    constexpr int D = 128, KB = NP * 32, SW = 2 * NP - 1;             // NP wave pairs x 32 keys; SW: the wave that also carries the row statistics
     constexpr int TILE = 64 * 256, META = 64 * 5 * 4, BUF = 2 * TILE + META, PEX = 64 * 32 * 2;      // P exchange: bf16, one buffer per tile parity
     static_assert(NB == 3, "ring depth (the top-of-tile wait is vmcnt(0): tile it+1 was requested one iteration ago)");
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][Q rows | dO rows | lse2, delta, pre, lo, hi] | [2][NP] P exchange | tile list
@@ -865,7 +865,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int 
     int* lds_full = lds_tiles + DKDV32_MAXT + 1;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c32 = lane & 31, h = lane >> 5;
-    const int role = wave >> 2, pair = wave & 3;
+    const int role = wave / NP, pair = wave - role * NP;              // waves w, w + 4, w + 8 share a SIMD: every SIMD hosts both roles
+    const bool dma_wave = wave < 8;                                   // the 32 row-group DMA instructions of a tile: 4 each for waves 0..7
     const int QS = gridDim.x / p.n_kv;
     const int kvh = blockIdx.x % p.n_kv, qz = blockIdx.x / p.n_kv;
     const int kvb0 = blockIdx.z * KB;
@@ -928,13 +929,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int 
         asm volatile("" : "+v"(ln));                                  // lane constants are rebuilt here (a handful of VALU), not kept live / spilled
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if (!dma_wave) break;
             const unsigned row = 4u * (wave * 2 + j) + ((unsigned)ln >> 4);
             unsigned R = Rq0 + row; R = R < nR ? R : nR - 1;
             const unsigned tu = p.group == 1 ? R : __umulhi(R, p.group_magic);
             const unsigned hb = (R - tu * (unsigned)p.group) * 256u + (unsigned)(((ln & 15) ^ skey(row & 15)) << 4);
             ta.q[j] = tu * q_ldb + hb; ta.o[j] = tu * do_ldb + hb;
         }
-        if (wave == 7) {
+        if (wave == SW) {
             unsigned R = Rq0 + (unsigned)ln; R = R < nR ? R : nR - 1;
             const unsigned tu = p.group == 1 ? R : __umulhi(R, p.group_magic);
             ta.st_t = tu;
@@ -953,11 +955,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int 
         const unsigned buf = lds_base + slot * BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if (!dma_wave) break;
             const unsigned dst = buf + (wave * 2 + j) * 1024;
             DMA16(ta.q[j], qbase, dst);
             DMA16(ta.o[j], dobase, dst + TILE);
         }
-        if (wave == 7) {                                              // row statistics (a role-1 wave: its tile work is the lighter one)
+        if (wave == SW) {                                             // row statistics (a role-1 wave: its tile work is the lighter one)
             const unsigned mb = buf + 2 * TILE;
             const unsigned so = ta.st_si * 4u, to = ta.st_t * 4u;
             DMA4(so, lse2, mb);
@@ -998,22 +1001,31 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int 
     // Operand reads run a fixed distance ahead of their MFMAs (explicit register ring + scheduling fences): left alone, hipcc hoists every
     // LDS read of the phase to its top and spills.
     auto product1 = [&](unsigned xa, f32x16_t& c) {                   // xa: tile rows + qb * 8192 + a_lane (LDS byte address)
+        // 8 waves (2 per SIMD): two accumulators (even / odd k-steps) - a single chain of 8 dependent 32x32x16 MFMAs runs at the instruction's
+        // latency (64 cycles), not its issue rate (32).  12 waves (3 per SIMD, 168 registers): one chain, the other waves fill the pipe.
+        constexpr bool TWO = NP == 4;
+        f32x16_t c1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = 0.f;
-        constexpr int AH = 3;                                         // k-steps of lookahead
+        for (int r = 0; r < 16; ++r) { c[r] = 0.f; if (TWO) c1[r] = 0.f; }
+        constexpr int AH = NP == 4 ? 3 : 2;                           // k-steps of lookahead
         bf16x8_t a[AH + 1];
 #pragma unroll
         for (int ks = 0; ks < AH; ++ks) a[ks] = LDS_B128(xa ^ (ks * 32));
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) {
             if (ks + AH < D / 16) a[(ks + AH) % (AH + 1)] = LDS_B128(xa ^ ((ks + AH) * 32));
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (AH + 1)], sf[ks], c, 0, 0, 0);
+            if (TWO && (ks & 1)) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (AH + 1)], sf[ks], c1, 0, 0, 0);
+            else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (AH + 1)], sf[ks], c, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TWO) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] += c1[r];
         }
     };
     // phase-2 product over two 16-row chunks: acc^T[feature][key] += Y^T[feature][q] * frag[q][key]
     auto product2 = [&](unsigned ya, const bf16x8_t& f0, const bf16x8_t& f1) {      // ya: tile rows + first chunk * 4096 + t_lane
-        constexpr int TH = 2;                                         // MFMAs of lookahead (3 tips the kernel over the 256-register budget)
+        constexpr int TH = NP == 4 ? 3 : 2;                           // MFMAs of lookahead
         bf16x8_t a[TH + 1];
 #define P2_LD(n) make_frag(LDS_TR16((ya ^ (((n) & 3) * 64)) + ((n) >> 2) * 4096), LDS_TR16((ya ^ (((n) & 3) * 64 + 32)) + ((n) >> 2) * 4096 + 2048))
 #pragma unroll
@@ -1068,9 +1080,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int 
     };
 
     // prologue: tile 0 has landed (this wave's share; tile 1 may still be in flight: 4 instructions, wave 7 carries 5 statistics rows more)
-    if (n_my > 1) {
-        if (wave == 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4) : "memory");
+    if (n_my > 1) {                                                   // (NP = 4: wave 7 issues 4 + 5 instructions per tile; NP = 6: wave 11 only the 5)
+        if (wave == SW) { if (SW < 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5) : "memory"); }
+        else if (dma_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4) : "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1189,6 +1201,190 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv32_kernel(AttnParams p, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- dQ on 32x32x16 MFMA tiles (head dim 128)
+// Round 3.  A wave owns 32 packed query rows (block = 8 waves = 256 rows), Q and dO stay in registers as B operands, 64-key K / V row tiles
+// stream through a 4-deep LDS ring (asm-issued LDS DMA, swizzled on the source address like the dK/dV kernel above).  Scores are computed
+// transposed, S^T[kv][q] = K Q^T and dP^T = V dO^T (A = the K / V rows as stored, two independent MFMA chains), so a lane holds ONE query row:
+// lse2 / delta / the mask intervals are lane-local scalars, and dS^T comes out in the accumulator layout that is the B operand of
+// dQ^T[d][q] += K^T[d][kv] dS^T[kv][q] after the k-permutation (K^T fragments: transposing reads of the same K row tile).
+// 48 MFMAs per wave and tile against 32 b128 + 32 transposing reads (half the LDS bytes per FLOP of the 16x16x32 form), 2 waves per SIMD.
+__global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const float* __restrict__ lse2) {
+    constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE;
+    extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][K rows | V rows] + block mask summary
+    int* lds_meta = reinterpret_cast<int*>(dyn_lds + NB * BUF);      // [8][3]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c32 = lane & 31, h = lane >> 5;
+    const int kvh = blockIdx.y;
+    const unsigned nR = (unsigned)p.T * (unsigned)p.group;
+    const unsigned Rw0 = (unsigned)(gridDim.x - 1 - blockIdx.x) * 256u + (unsigned)wave * 32u;      // heaviest query blocks first
+    const unsigned R = Rw0 + (unsigned)c32;
+    const bool valid = R < nR;
+    int tq, hq;
+    att_split_row(p, valid ? R : nR - 1, tq, hq);
+    const int pre = valid ? p.pre[tq] : 0, lo = valid ? p.lo[tq] : 1, hi = valid ? p.hi[tq] : 0;
+    const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + tq;
+    const float lse = valid ? lse2[si] : INFINITY;                    // log2-scaled; +inf (no visible key / padding row) -> P = 0
+    const float dlt = valid ? p.delta[si] : 0.f;
+    // wave summary of the masks: which tiles every row of the wave sees completely, which it sees at all
+    int wmaxpre = valid ? pre : 0, wminpre = valid ? pre : 0x7fffffff;
+    int wminlo = (valid && hi >= lo) ? lo : 0x7fffffff, wmaxhi = (valid && hi >= lo) ? hi : -1;
+    int wmaxlo = valid ? (hi >= lo ? lo : 0x7fffffff) : -1, wminhi = valid ? (hi >= lo ? hi : -1) : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminpre = min(wminpre, __shfl_xor(wminpre, o, 64));
+        wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
+        wmaxlo = max(wmaxlo, __shfl_xor(wmaxlo, o, 64)); wminhi = min(wminhi, __shfl_xor(wminhi, o, 64));
+    }
+    wmaxpre = __builtin_amdgcn_readfirstlane(wmaxpre); wminpre = __builtin_amdgcn_readfirstlane(wminpre);
+    wminlo = __builtin_amdgcn_readfirstlane(wminlo); wmaxhi = __builtin_amdgcn_readfirstlane(wmaxhi);
+    wmaxlo = __builtin_amdgcn_readfirstlane(wmaxlo); wminhi = __builtin_amdgcn_readfirstlane(wminhi);
+    const bool wave_rows_all = Rw0 + 32u <= nR;
+    if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
+    // stationary B fragments: Q / dO row of this lane, features ks*16 + h*8 .. +7
+    bf16x8_t qf[D / 16], dof[D / 16];
+    {
+        const int64_t hoff = (int64_t)(kvh * p.group + hq) * D;
+        const bf16_t* qrow = p.Q + (int64_t)tq * p.q_ld + hoff;
+        const bf16_t* drow = p.dO + (int64_t)tq * p.do_ld + hoff;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) { qf[ks] = load_row_frag(qrow, ks * 16 + h * 8, D, valid); dof[ks] = load_row_frag(drow, ks * 16 + h * 8, D, valid); }
+    }
+    f32x16_t acc[4];                                                  // dQ^T[feature block][C layout]
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+    // (an asm that reads the fragments makes hipcc place the wait for their loads itself - see the dK/dV kernel; from here on vmcnt counts DMA only)
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) asm volatile("" ::"v"(qf[ks]), "v"(dof[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
+    const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
+    const int n_my = tr.n_rel;
+
+    // ---- DMA of one key tile (K rows + V rows): 4 instructions per wave, 32-bit byte offsets from uniform bases
+    const unsigned lds_base = (unsigned)(uintptr_t)(att_lptr_t)dyn_lds;
+    const char* kbase = reinterpret_cast<const char*>(p.K) + (int64_t)kvh * 256;
+    const char* vbase = reinterpret_cast<const char*>(p.V) + (int64_t)kvh * 256;
+    const unsigned k_ldb = (unsigned)p.k_ld * 2u, v_ldb = (unsigned)p.v_ld * 2u;
+#define DMA16(voff, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(sbase) : "memory", "m0")
+    auto issue_tile = [&](int tile, int slot) {
+        const unsigned buf = lds_base + slot * BUF;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned row = 4u * (wave * 2 + j) + ((unsigned)ln >> 4);
+            unsigned kv = (unsigned)tile * 64u + row; kv = kv < (unsigned)p.n_slots ? kv : (unsigned)p.n_slots - 1u;
+            const unsigned ch = (unsigned)(((ln & 15) ^ skey(row & 15)) << 4);
+            const unsigned dst = buf + (wave * 2 + j) * 1024;
+            DMA16(kv * k_ldb + ch, kbase, dst);
+            DMA16(kv * v_ldb + ch, vbase, dst + TILE);
+        }
+    };
+#undef DMA16
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j)
+        if (j < n_my) issue_tile(att_tile_at(tr, j), j);
+
+    typedef const __attribute__((address_space(3))) bf16x8_t* lds_b128_t;
+#define LDS_B128(addr) (*(lds_b128_t)(uintptr_t)(addr))
+#define LDS_TR16(addr) __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)(addr)))
+    const int ti = lane & 15, tgrp = (lane >> 4) & 1;
+    const unsigned a_lane = (unsigned)(c32 * 256 + ((h ^ skey(c32 & 15)) << 4));
+    const unsigned t_lane = (unsigned)((4 * h + (ti >> 2)) * 256 + (ti & 1) * 8 + (((tgrp * 2 + ((ti & 3) >> 1)) ^ (((ti >> 2) << 2) | h)) << 4));
+
+    for (int it = 0; it < n_my; ++it) {
+        {   // this wave's share of tile `it` has landed when at most (tiles requested after it) x 4 instructions are outstanding
+            const int after = (n_my - 1 - it) < (NB - 2) ? (n_my - 1 - it) : (NB - 2);
+            if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                                 // tile `it` is complete for everybody; everybody is done with tile it-1
+        asm volatile("" ::: "memory");
+        if (it + NB - 1 < n_my) issue_tile(att_tile_at(tr, it + NB - 1), (it + NB - 1) % NB);
+        const int kv0 = att_tile_at(tr, it) * 64;
+        // wave-uniform: does any row of the wave see a key of the tile / does every row see every key
+        const bool any = (kv0 < wmaxpre) || (kv0 + 63 >= wminlo && kv0 <= wmaxhi);
+        const bool full = wave_rows_all && (kv0 + 64 <= p.n_slots) && ((kv0 + 64 <= wminpre) || (wmaxlo <= kv0 && kv0 + 63 <= wminhi));
+        if (any) {
+            const unsigned kb_ = lds_base + (unsigned)(it % NB) * BUF;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {                          // 32-key halves of the tile
+                const unsigned xa = kb_ + kb * 8192 + a_lane;
+                f32x16_t cs, cp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { cs[r] = 0.f; cp[r] = 0.f; }
+                constexpr int AH = 2;
+                bf16x8_t ka[AH + 1], va[AH + 1];
+#pragma unroll
+                for (int ks = 0; ks < AH; ++ks) { ka[ks] = LDS_B128(xa ^ (ks * 32)); va[ks] = LDS_B128((xa ^ (ks * 32)) + TILE); }
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    if (ks + AH < D / 16) { ka[(ks + AH) % (AH + 1)] = LDS_B128(xa ^ ((ks + AH) * 32)); va[(ks + AH) % (AH + 1)] = LDS_B128((xa ^ ((ks + AH) * 32)) + TILE); }
+                    cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks % (AH + 1)], qf[ks], cs, 0, 0, 0);
+                    cp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks % (AH + 1)], dof[ks], cp, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // lane holds S^T / dP^T [kv = kv0 + kb*32 + 8i + 4h + j][q = its row] in register 4i + j
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[r], p.scale_log2, -lse));
+                        cs[r] = pv * (cp[r] - dlt);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre, lo, hi);
+                        const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(cs[r], p.scale_log2, -lse)) : 0.f;
+                        cs[r] = pv * (cp[r] - dlt);
+                    }
+                }
+                const bf16x8_t f0 = pack8(cs, 0), f1 = pack8(cs, 8);
+                const unsigned ya = kb_ + kb * 8192 + t_lane;
+                constexpr int TH = 2;
+                bf16x8_t a[TH + 1];
+#define P2_LD(n) make_frag(LDS_TR16((ya ^ (((n) & 3) * 64)) + ((n) >> 2) * 4096), LDS_TR16((ya ^ (((n) & 3) * 64 + 32)) + ((n) >> 2) * 4096 + 2048))
+#pragma unroll
+                for (int n = 0; n < TH; ++n) a[n] = P2_LD(n);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    if (n + TH < 8) a[(n + TH) % (TH + 1)] = P2_LD(n + TH);
+                    acc[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n % (TH + 1)], (n >> 2) ? f1 : f0, acc[n & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef P2_LD
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // all LDS reads of this tile have returned before the barrier that frees its slot
+    }
+#undef LDS_B128
+#undef LDS_TR16
+    // lane holds dQ^T[feature = db*32 + 8i + 4h + j][its query row]
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const unsigned e_R = Rw0 + (unsigned)(tid2 & 31);
+    const int e_h = (tid2 >> 5) & 1;
+    if (e_R < nR) {
+        int t2, hq2;
+        att_split_row(p, e_R, t2, hq2);
+        const float scale = p.scale_log2 * 0.6931471805599453f;
+        bf16_t* row = p.dQ + (int64_t)t2 * p.dq_ld + (int64_t)(kvh * p.group + hq2) * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x2_t w = {pack2bf(acc[db][4 * i] * scale, acc[db][4 * i + 1] * scale), pack2bf(acc[db][4 * i + 2] * scale, acc[db][4 * i + 3] * scale)};
+                *reinterpret_cast<u32x2_t*>(row + db * 32 + 8 * i + 4 * e_h) = w;
+            }
+    }
+}
+
 // dK = scale * sum_z part_k[z], dV = sum_z part_v[z]  -> bf16
 __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const float* __restrict__ part_v, bf16_t* __restrict__ dK, int64_t dk_ld,
                                        bf16_t* __restrict__ dV, int64_t dv_ld, int n_slots, int kvd, int QS, float scale) {
@@ -1208,7 +1404,21 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const f
     }
 }
 
-static int dkdv_keys_per_block(int d_pad) { return (d_pad == 64 || d_pad == 128) ? 128 : 64; }   // 8-wave blocks where 8*D/512 is integral
+// wave pairs per block of the 32x32x16 kernel (TR1_DKDV32_NP = 4 | 6): 6 pairs = 12 waves = 3 per SIMD, 192 keys per block
+static int dkdv32_pairs() {
+    static int np = -1;
+    if (np < 0) { const char* e = getenv("TR1_DKDV32_NP"); np = (e && atoi(e) == 4) ? 4 : 6; }
+    return np;
+}
+static int dkdv32_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TR1_DKDV32"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int dkdv_keys_per_block(int d_pad) {      // 8-wave blocks where 8*D/512 is integral; head dim 128: the 32x32x16 kernel's pairs x 32
+    if (d_pad == 128 && dkdv32_on()) return dkdv32_pairs() * 32;
+    return (d_pad == 64 || d_pad == 128) ? 128 : 64;
+}
 
 static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) {
     const int64_t n_qtiles = (T * group + 63) / 64;
@@ -1246,7 +1456,16 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (NW == 8) hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
+    // TR1_DQ32 (default 1): the 32x32x16-MFMA dQ kernel (round 3) for head dim 128
+    static int dq32 = -1;
+    if (dq32 < 0) { const char* e = getenv("TR1_DQ32"); dq32 = e ? atoi(e) : 1; }
+    const size_t dyn_dq32 = 4 * (2 * 64 * 256) + 128;
+    static bool dq32_attr = false;
+    if (D == 128 && !dq32_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq32); dq32_attr = true; }
+    const bool use_dq32 = D == 128 && p.d_real == 128 && dq32 > 0 && lse2 != nullptr &&
+                          (uint64_t)p.n_slots * (uint64_t)(p.k_ld > p.v_ld ? p.k_ld : p.v_ld) * 2ull < 0xffffffffull;      // 32-bit DMA byte offsets
+    if (use_dq32) hipLaunchKernelGGL(attn_bwd_dq32_kernel, dim3((unsigned)((nR + 255) / 256), p.n_kv), dim3(512), dyn_dq32, s, p, lse2);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
     // head dim 128: the LDS-DMA staged forms.  TR1_DKDV_DMA = 0: register-staged 8 waves x 16 keys; 1: DMA, 4 waves x 32 keys; 2: DMA, 8 waves x 16 keys
     static int dma = -1;
     if (dma < 0) { const char* e = getenv("TR1_DKDV_DMA"); dma = e ? atoi(e) : 2; }
@@ -1259,19 +1478,20 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         dma_attr = true;
     }
     // TR1_DKDV32 (default 1): the 32x32x16-MFMA role-split kernel (round 3) for head dim 128; 0 = the 16x16x32 forms selected by TR1_DKDV_DMA
-    static int v32 = -1;
-    if (v32 < 0) { const char* e = getenv("TR1_DKDV32"); v32 = e ? atoi(e) : 1; }
+    const int v32 = dkdv32_on();
     constexpr int V32_NB = 3;
-    const size_t dyn_v32 = V32_NB * (2 * 64 * 256 + 64 * 5 * 4) + 2 * 4 * (64 * 32 * 2) + (2 * DKDV32_MAXT + 2) * 4;
+    const int v32_np = dkdv32_pairs();
+    const size_t dyn_v32 = V32_NB * (2 * 64 * 256 + 64 * 5 * 4) + 2 * v32_np * (64 * 32 * 2) + (2 * DKDV32_MAXT + 2) * 4;
     static bool v32_attr = false;
     if (D == 128 && !v32_attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv32_kernel<V32_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_v32);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv32_kernel<V32_NB, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv32_kernel<V32_NB, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         v32_attr = true;
     }
     const bool use_v32 = D == 128 && p.d_real == 128 && v32 > 0 && lse2 != nullptr &&
                          (uint64_t)p.T * (uint64_t)(p.q_ld > p.do_ld ? p.q_ld : p.do_ld) * 2ull < 0xffffffffull;      // 32-bit DMA byte offsets
     const bool use_dma = D == 128 && p.d_real == 128 && dma > 0 && lse2 != nullptr;
-    const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots, KB);
+    const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots, use_v32 ? v32_np * 32 : KB);
     const int64_t kvd = (int64_t)p.n_kv * p.d_real;
     float *pk = nullptr, *pv = nullptr;
     if (QS > 1) {
@@ -1279,7 +1499,8 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
         pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
     }
-    if (use_v32) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
+    if (use_v32 && v32_np == 6) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB, 6>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 191) / 192)), dim3(768), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
+    else if (use_v32) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB, 4>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
     else if (use_dma && dma == 2) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
     else if (use_dma) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(256), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
     else if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
@@ -1294,8 +1515,15 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
 
 extern "C" int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim) {
     if (n_kv <= 0 || T <= 0) return 0;
-    const int QS = dkdv_qsplit(T, (int)(n_heads / n_kv), (int)n_kv, n_slots, dkdv_keys_per_block((int)((head_dim + 31) / 32 * 32)));
-    return QS > 1 ? 2 * (int64_t)QS * n_slots * n_kv * head_dim : 0;
+    const int d_pad = (int)((head_dim + 31) / 32 * 32);
+    // the launch picks its key-block size (and with it the number of query slices) from the shape; size the partials for every form it may take
+    int64_t need = 0;
+    for (int kb : {dkdv_keys_per_block(d_pad), d_pad == 128 ? 128 : 64}) {
+        const int QS = dkdv_qsplit(T, (int)(n_heads / n_kv), (int)n_kv, n_slots, kb);
+        const int64_t n = QS > 1 ? 2 * (int64_t)QS * n_slots * n_kv * head_dim : 0;
+        if (n > need) need = n;
+    }
+    return need;
 }
 
 // Scratch: qmeta_ws int32 [8*ceil(T*group/64)], delta fp32 [2*n_heads*T] (delta | log2-scaled LSE), ws_f32 of tr1_attn_bwd_workspace_floats() floats.
