@@ -203,6 +203,15 @@ def masks_segments(lengths):
     return torch.zeros(a, dtype=torch.int32), torch.tensor(lo, dtype=torch.int32), torch.tensor(hi, dtype=torch.int32)
 
 
+def masks_prefix_only(P, n):
+    """P causal prompt rows, then n rows that see the prompt through `pre` only: every third has an EMPTY [lo, hi], the others a 1-key interval."""
+    pre = torch.cat([torch.zeros(P), torch.full((n,), P)]).int()
+    idx = P + torch.arange(n)
+    lo = torch.cat([torch.zeros(P), idx.float()]).int()
+    hi = torch.cat([torch.arange(P).float(), torch.where(torch.arange(n) % 3 == 0, idx - 1, idx).float()]).int()
+    return pre, lo, hi
+
+
 ATT_CASES = [
     ("causal", 4, 2, 128, masks_causal(200)),
     ("causal-small-d", 4, 4, 32, masks_causal(77)),
@@ -210,6 +219,11 @@ ATT_CASES = [
     ("prefix-shared-128", 14, 2, 128, masks_prefix_shared(150, 4, 21)),
     ("vit-segments", 4, 4, 80, masks_segments([60, 60, 60, 45])),
     ("windows", 2, 2, 80, masks_segments([16] * 9 + [4, 4, 7])),
+    # head dim 128 takes the 32x32x16-MFMA backward kernels (round 3): ragged sizes, group 1 / 7, segments, rows that see only the prefix
+    ("segments-128", 4, 4, 128, masks_segments([70, 3, 130, 64])),
+    ("prefix-shared-128-g7", 7, 1, 128, masks_prefix_shared(333, 3, 50)),
+    ("prefix-only-rows-128", 4, 2, 128, masks_prefix_only(90, 45)),
+    ("tiny-128", 2, 2, 128, masks_causal(9)),
 ]
 
 
