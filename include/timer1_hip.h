@@ -104,6 +104,11 @@ int tr1_embed_bwd(const void* dout, const void* ids, void* dtable_f32, int64_t T
  * problem b uses Q/O/mask rows [b*T, (b+1)*T) and cache slots starting at b*kv_batch_slots (decode over several prompts' caches). */
 int tr1_attn_fwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* stream);
 int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit);
+/* The same attention (nsplit = 1, one problem, head_dim = 128) with K AND V row-major ([n_slots, n_kv*128], any leading dims % 8 == 0): the
+ * 32x32x16-MFMA kernel of round 3 transposes V in its LDS reads, so the LLM's training / prefill / reference-policy forwards (TF:521-556 via
+ * timer1_trainer.py:452-457, attn_implementation=flash_attention_2 in scripts/posttrain/train_rl.sh:33) need no V^T copy.  Same results as
+ * tr1_attn_fwd up to the order of the fp32 accumulation. */
+int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
 /* Split-KV decode over the layers of ONE decode step (same pre/lo/hi in every layer of model.generate's step, timer1_trainer.py:568-573): the
  * launch with plan_mode 1 publishes each query tile's relevant-tile list in `plan` (int32[tr1_attn_plan_ints()]), launches with plan_mode 2 start
  * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */

@@ -20,7 +20,7 @@
 // lane 0 of every wave of ONE block (blockIdx.x == 0, blockIdx.z == 2) stamps s_memtime at up to 8 points of its first 64 tiles
 #ifdef TR1_PROBE
 __device__ unsigned long long* tr1_bwd_probe = nullptr;
-extern "C" int tr1_bwd_probe_set(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_bwd_probe), &ptr, sizeof(ptr)); }
+extern "C" int probe_bwd_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_bwd_probe), &ptr, sizeof(ptr)); }
 // the stamps of a tile stay in scalar registers and are written in one burst by BWD_FLUSH: reading an s_memtime result costs an
 // s_waitcnt lgkmcnt(0), which would drain the LDS reads in flight at the stamped point
 #define BWD_STAMPS unsigned long long bwd_st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 // Transposed MFMA operands straight from a ROW-major LDS tile: ds_read_b64_tr_b16.  Every lane supplies its own 8-byte address; inside a 16-lane
 // group lane i supplies row i/4, columns 4(i%4)..+3 of a 4 x 16 block and receives column i of that block (probed on MI355X).
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 TR1_DEV u32x2_t lds_read_tr16(const char* p) {
     const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
     return __builtin_bit_cast(u32x2_t, v);
@@ -578,8 +577,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnParams p, in
 // Ordering: each wave counts its own DMA instructions (s_waitcnt vmcnt(n)), then ONE barrier per tile publishes the tile to the block and
 // retires the buffer consumed in the previous iteration, which is refilled right behind the barrier.
 TR1_DEV int dkey(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
-typedef const __attribute__((address_space(1))) void* att_gptr_t;
-typedef __attribute__((address_space(3))) void* att_lptr_t;
 
 template <int NW, int KT, int NB>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_dma_kernel(AttnParams p, int n_qtiles, const float* __restrict__ lse2, float* __restrict__ part_k,
@@ -846,12 +843,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_dma_kernel(AttnParams p
 // Tile images as in the DMA kernel above (64 rows x 256 B, unpadded, global_load_lds with the swizzle applied on the SOURCE address), but
 // keyed with skey(row) = (row&3)<<2 | (row>>2)&3: the 16 rows of a b128 service group get 16 distinct chunk positions, and the 4 rows x 4
 // chunks of a 32-lane transposing read land in 4 disjoint aligned chunk groups - both read shapes are bank-conflict free.
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-TR1_DEV int skey(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-TR1_DEV bf16x8_t pack8(const f32x16_t& c, int b) {
-    u32x4_t w = {pack2bf(c[b], c[b + 1]), pack2bf(c[b + 2], c[b + 3]), pack2bf(c[b + 4], c[b + 5]), pack2bf(c[b + 6], c[b + 7])};
-    return __builtin_bit_cast(bf16x8_t, w);
-}
 
 template <int NB, int NP>
 __global__ __launch_bounds__(NP * 128) void attn_bwd_dkdv32_kernel(AttnParams p, int n_qtiles, const float* __restrict__ lse2, float* __restrict__ part_k,

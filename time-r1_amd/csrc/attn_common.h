@@ -282,3 +282,16 @@ TR1_DEV TileRange att_tile_range(int max_pre, int min_lo, int max_hi, int n_slot
     return tr;
 }
 TR1_DEV int att_tile_at(const TileRange& tr, int i) { return i < tr.pre_tiles ? i : tr.start2 + (i - tr.pre_tiles); }
+
+// ---- pieces shared by the 32x32x16-MFMA kernels (round 3: attn_bwd_dkdv32 / attn_bwd_dq32 / attn_fwd32) -------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;       // 32x32 accumulator: lane (column n = lane & 31, half h = lane >> 5), register r -> row (r&3) + 8(r>>2) + 4h
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+// swizzle key of row (mod 16) of an unpadded 256-byte-row tile image: logical 16-byte chunk c of the row is stored at chunk c ^ skey(row)
+TR1_DEV int skey(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// registers b .. b+7 of a 32x32 accumulator -> one bf16 MFMA operand fragment (k-slot j of lane half h = accumulator row 16(b/8) + (j&3) + 8(j>>2) + 4h)
+TR1_DEV bf16x8_t pack8(const f32x16_t& c, int b) {
+    u32x4_t w = {pack2bf(c[b], c[b + 1]), pack2bf(c[b + 2], c[b + 3]), pack2bf(c[b + 4], c[b + 5]), pack2bf(c[b + 6], c[b + 7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}

@@ -274,20 +274,29 @@ class Engine:
             xn, rstd1, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=save, out=dst(i, "xn"), rstd_out=dst(i, "rstd1"))
             qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"), out=dst(i, "qkv"))
             q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cos, sin, out=dst(i, "q"))
+            # head dim 128: the forward kernel reads V row-major (it transposes in its LDS reads); V^T is then only built where a later decode
+            # needs it in the cache (rollout prefill / continuation), not for the reference-policy and plain training forwards
+            rows_ok = getattr(ops, "attn_fwd_rows_ok", lambda *a: False)(hd)
+            v_rows = None
             if kv_cache is not None:
                 kc, vtc = kv_cache[i]
                 k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin, out=kc[row0:S])
                 if row0 == 0:
                     vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc)
+                    v_rows = qkv[:, qd + kvd:] if rows_ok else None
                 else:
                     vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc[:, row0:], zero_pad=False)
                     vt = vtc
+                    if rows_ok and inplace:      # the prefix rows' V sits in the shared activation buffers (written by the prefill)
+                        v_rows = bufs[i]["qkv"][:S, qd + kvd:]
                 k_all = kc
             else:
                 k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin)
-                vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd)
+                v_rows = qkv[:, qd + kvd:] if rows_ok else None
+                vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd) if v_rows is None else None
                 k_all = k
-            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save, out=dst(i, "o"))
+            o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save, out=dst(i, "o"),
+                                  **({"v_rows": v_rows} if v_rows is not None else {}))
             h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h, out=dst(i, "h2"))
             xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save, out=dst(i, "xn2"), rstd_out=dst(i, "rstd2"))
             gu = ops.gemm_nt(xn2, arena.w(p + "gu.w"), out=dst(i, "gu"))

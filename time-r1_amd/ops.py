@@ -422,17 +422,28 @@ class HipOps:
         """int32 buffer for attn_fwd(plan=..., plan_mode=1|2): the relevant-tile lists of one decode step, shared by its layers."""
         return self.zeros(self.L.raw("tr1_attn_plan_ints")(T, n_heads, n_kv, n_batch), dtype=I32)
 
+    FWD32 = os.environ.get("TR1_FWD32", "1") != "0"      # head dim 128, nsplit 1: the 32x32x16-MFMA forward over row-major K / V (A/B switch)
+
     def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
-                 kv_batch_slots=0, plan=None, plan_mode=0):
+                 kv_batch_slots=0, plan=None, plan_mode=0, v_rows=None):
         """n_batch > 1: q/out/masks hold n_batch problems of T = rows/n_batch tokens each; problem b reads cache slots from b*kv_batch_slots.
-        plan / plan_mode: split-KV decode only - mode 1 publishes the tile lists of these masks in `plan`, mode 2 reuses them (same masks)."""
-        self._chk(q, k, vt)
+        plan / plan_mode: split-KV decode only - mode 1 publishes the tile lists of these masks in `plan`, mode 2 reuses them (same masks).
+        v_rows: V row-major [n_slots, n_kv*head_dim] (a view is fine).  With it, head dim 128 single-pass launches take the 32x32x16-MFMA
+        kernel, which reads K and V as stored; `vt` may then be None."""
         assert pre.dtype == I32 and lo.dtype == I32 and hi.dtype == I32
         rows = q.shape[0]
         assert rows % n_batch == 0
         T = rows // n_batch
         o = out if out is not None else self.empty(rows, n_heads * head_dim)
         lse = self.empty(n_batch * n_heads, T, dtype=F32) if need_lse else None
+        if v_rows is not None and self.attn_fwd_rows_ok(head_dim, nsplit, n_batch):
+            self._chk(q, k, v_rows)
+            assert k.shape[0] >= n_slots and v_rows.shape[0] >= n_slots
+            self.L.call("tr1_attn_fwd_rows", _p(q), _ld(q), _p(k), _ld(k), _p(v_rows), _ld(v_rows), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
+                        n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
+            return o, lse
+        assert vt is not None, "attention: this shape needs the V^T operand"
+        self._chk(q, k, vt)
         ws, nws = None, 0
         if nsplit > 1:
             nws = n_batch * self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
@@ -445,6 +456,10 @@ class HipOps:
         self.L.call("tr1_attn_fwd", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
                     n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, self._s())
         return o, lse
+
+    def attn_fwd_rows_ok(self, head_dim, nsplit=1, n_batch=1):
+        """True when attn_fwd(v_rows=...) would take the row-major K / V kernel (callers can then skip building V^T)."""
+        return self.FWD32 and head_dim == 128 and nsplit == 1 and n_batch == 1
 
     def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):
         """-> dq [T, n_heads*hd], dk, dv [n_slots, n_kv*hd]. Builds the transposed operand copies it needs."""

@@ -42,7 +42,7 @@ def main():
     q, k, v, do = rnd(M, H * HD), rnd(M, NKV * HD), rnd(M, NKV * HD), rnd(M, H * HD, sc=0.1)
     scale = HD ** -0.5
     vt = ops.pack_transpose(v, NKV, NKV, HD)
-    o, lse = ops.attn_fwd(q, k, vt, pre, lo, hi, H, NKV, M, HD, scale)
+    o, lse = ops.attn_fwd(q, k, vt, pre, lo, hi, H, NKV, M, HD, scale, v_rows=v)
     dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, pre, lo, hi, H, NKV, M, HD, scale)
     torch.cuda.synchronize()
     out = {"shape": dict(P=a.P, G=a.G, C=a.C, M=M, H=H, NKV=NKV, HD=HD), "env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("TR1_")}}
@@ -57,7 +57,7 @@ def main():
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.iters
-    t_f = timed(lambda: ops.attn_fwd(q, k, vt, pre, lo, hi, H, NKV, M, HD, scale))
+    t_f = timed(lambda: ops.attn_fwd(q, k, vt, pre, lo, hi, H, NKV, M, HD, scale, v_rows=v))
     t_b = timed(lambda: ops.attn_bwd(q, k, v, o, do, lse, pre, lo, hi, H, NKV, M, HD, scale))
     out["fwd_ms"], out["fwd_TFLOPs_visible"] = round(t_f, 4), round(fl_fwd / t_f / 1e9, 1)
     out["bwd_ms"], out["bwd_TFLOPs_2p5x"] = round(t_b, 4), round(2.5 * fl_fwd / t_b / 1e9, 1)
@@ -82,11 +82,11 @@ def main():
     if a.probe:
         from time_r1_amd import hip
         buf = torch.zeros(16 * 64 * 8, dtype=torch.int64, device="cuda")
-        rc = hip.lib().cdll.tr1_bwd_probe_set(ctypes.c_void_p(buf.data_ptr()))
+        rc = hip.lib().cdll.probe_bwd_set_ptr(ctypes.c_void_p(buf.data_ptr()))
         assert rc == 0, rc
         ops.attn_bwd(q, k, v, o, do, lse, pre, lo, hi, H, NKV, M, HD, scale)
         torch.cuda.synchronize()
-        hip.lib().cdll.tr1_bwd_probe_set(ctypes.c_void_p(0))
+        hip.lib().cdll.probe_bwd_set_ptr(ctypes.c_void_p(0))
         st = buf.cpu().view(16, 64, 8).numpy()
         t0 = int(st[st > 0].min())
         lines = []
