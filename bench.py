@@ -64,7 +64,9 @@ class Workload:
         self.cfg = PRESETS[args.model]()
         self.args, self.ops, self.rank = args, ops, rank
         dp = DataParallel()
-        self.shard = bool(args.shard_optimizer) and dp.enabled      # sharded: master / m / v are allocated as 1/world shards only (AdamWFlat -> Arena.set_shard)
+        # N > 1 defaults to the sharded optimizer (every reference multi-GPU script runs ZeRO, scripts/zero3.json): master / m / v are allocated as
+        # 1/world shards only (AdamWFlat -> Arena.set_shard); --replicated-optimizer opts out, world sizes other than 2 / 4 / 8 fall back
+        self.shard = dp.enabled and dp.world in (2, 4, 8) and not args.replicated_optimizer
         self.params = ModelParams(self.cfg, ops, init="none", optimizer_state=not self.shard)
         if hasattr(self.params, "init_random_device"):
             self.params.init_random_device(seed=0)
@@ -425,7 +427,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-engine-leg", action="store_true", help="skip the short bare-engine-loop cross-check that follows the timed region")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
     ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
-                    "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json)")
+                    "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json).  This is the DEFAULT for N in {2, 4, 8}: same "
+                    "wire bytes as the all-reduce, 1/N of the AdamW + grad-norm streams per rank")
+    ap.add_argument("--replicated-optimizer", action="store_true", help="N > 1: keep master / m / v whole on every rank and all-reduce the gradient")
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.ga < 1:
         ap.error("--gpus/--steps/--ga must be >= 1 and --warmup >= 0")
@@ -473,6 +477,8 @@ def main(argv=None):
     ops = HipOps(device)
     ops.use_priority_stream()            # main chain ahead of the weight-gradient side stream in the dispatcher (same call as the trainer)
     peaks = measure_peaks(ops, device) if (rank == 0 and not args.no_peak_probe) else None
+    from time_r1_amd.dist import dist_diagnostics, exposed_ms
+    diag = dist_diagnostics(device)          # collectives: every rank; N = 1: a local stub.  A hang here ends in the process-group timeout.
     wl = Workload(args, ops, device, rank)
     dp = DataParallel()
     tr = wl.trainer
@@ -483,6 +489,7 @@ def main(argv=None):
     tr._flush_metrics()
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     tok0, ph0 = tr.generated_tokens, dict(tr.phase_ms_total)
+    exposed_ms(wl.opt.sync)                  # drop the warm-up's exchange waits
     timed_plan = window_plan(args.steps, args.ga)
     t0 = time.perf_counter()
     for n in timed_plan:
@@ -494,6 +501,11 @@ def main(argv=None):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     tr._flush_metrics()
+    exch_ms = exposed_ms(wl.opt.sync) if dp.enabled else 0.0     # compute-stream time spent waiting on the gradient exchange in the timed windows
+    if dp.enabled:
+        et = torch.tensor([exch_ms], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
+        exch_ms = float(et.item())
     if args.engine_path:
         gen_tokens = args.steps * world * args.G * args.C        # the bare loop keeps no token counter; all C tokens are generated (EOS suppressed)
         phases = {}
@@ -529,6 +541,9 @@ def main(argv=None):
             "generated_tokens_per_sec_end_to_end": gen_tokens / dt,
             "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
             "engine_path": engine_leg,
+            "distributed": {**diag, "grad_exchange_exposed_ms_per_optimizer_step": round(exch_ms / max(len(timed_plan), 1), 3),
+                            "optimizer_sharded": bool(wl.shard), "grad_wire_dtype": "bf16",
+                            "process_group_timeout_s": float(os.environ.get("TR1_DIST_TIMEOUT_S", "600"))},
             "trainer_log_last": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (logs[-1] if logs else {}).items()},
             "optimizer_steps": len(timed_plan), "windows": "%d x %d" % (args.steps // args.ga, args.ga) + (" + 1 x %d" % (args.steps % args.ga) if args.steps % args.ga else ""),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 1e9, 1), "reserved_peak": round(torch.cuda.max_memory_reserved() / 1e9, 1),

@@ -48,11 +48,15 @@ def test_ragged_eos_run_counts_only_tokens_up_to_the_injected_eos():
 
 @pytest.mark.parametrize("shard", [False, True])
 def test_self_spawned_two_rank_run(shard):
-    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-peak-probe"] + (["--shard-optimizer"] if shard else []),
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline", "--no-peak-probe"] + ([] if shard else ["--replicated-optimizer"]),
                env={"TR1_FORCE_DEVICE": "0", "TR1_DIST_BACKEND": "gloo"})
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["steps"] == 3
     assert abs(out["value"] - 2 * 1000.0 / out["ms_per_step"]) < 1e-6 * out["value"]       # whole-job aggregate over both ranks
     assert ("zero-sharded" in out["config"]["optimizer"]) == shard
+    d = out["distributed"]                                      # a first multi-GPU run must be diagnosable from its JSON line
+    assert d["backend"] == "gloo" and d["world"] == 2 and d["ranks_seen"] == [0, 1] and d["ranks_seen_ok"] and len(d["devices"]) == 2
+    assert d["optimizer_sharded"] == shard and d["grad_exchange_exposed_ms_per_optimizer_step"] >= 0.0 and d["process_group_timeout_s"] > 0
+    assert "rccl_version" in d
 
 
 def test_world_size_mismatch_is_an_error():

@@ -32,7 +32,7 @@ def _worker(rank, world, port, q, wire):
     from helpers import load_case
     from test_trainer_host_logic import make_trainer
     fx = load_case("grpo_beta")
-    cfg, tr = make_trainer(fx, grad_wire_dtype=wire)
+    cfg, tr = make_trainer(fx, grad_wire_dtype=wire, shard_optimizer=False)       # the replicated all-reduce path (N > 1 defaults to sharding)
     assert tr.dp.enabled and tr.dp.world == 2 and tr.dp.rank == rank
     row = _rows(fx)[rank]
     tr._video_inputs = lambda ex: ([ex["_frames"]], [2.0])
@@ -181,3 +181,52 @@ def test_arena_segments_split_evenly_for_every_world_size():
                     cover[ca:cb] += 1
                 assert loc == a.numel // world
             assert bool((cover == 1).all())
+
+
+# ------------------------------------------------------------------------------------------ 4 ranks, dataset not divisible by the world size
+def _worker_train4(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), TR1_DIST_TIMEOUT_S="240")
+    torch.set_num_threads(1)
+    from time_r1_amd.dist import init_from_env, dist_diagnostics, ShardSync
+    r, _, w = init_from_env("cpu")                 # the product's own rendezvous (explicit process-group timeout), gloo on CPU
+    assert (r, w) == (rank, world)
+    diag = dist_diagnostics("cpu")
+    from helpers import load_case
+    from test_trainer_host_logic import make_trainer, _dataset
+    fx = load_case("grpo_beta")
+    cfg, tr = make_trainer(fx, disable_log_print=True)       # shard_optimizer=None: N > 1 defaults to the sharded optimizer
+    assert isinstance(tr.optimizer.sync, ShardSync) and tr.params.train.shard == (rank, world)
+    tr.args.learning_rate = 1e-3
+    tr.args.num_train_epochs = 1
+    tr.train_dataset = _dataset(fx, 5)             # 5 rows over 4 ranks: the sampler wraps to 8 = 2 batches per rank (no rank may run short)
+    res = tr.train()
+    q.put((rank, tr.params.train.w16.float().numpy().copy(), res.global_step, diag, tr.state.log_history[-1]["reward"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_dataset_not_divisible_by_world():
+    """4 ranks over gloo, len(dataset) % world != 0, default (sharded) optimizer, the product's rendezvous with its
+    explicit timeout: every rank takes the same number of optimizer steps (no dead-lock in the exchange), ends with identical weights,
+    and the start-up diagnostics see all four ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker_train4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(4)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [2, 2, 2, 2]
+    for r in res[1:]:
+        assert (r[1] == res[0][1]).all(), "ranks must hold identical bf16 weights after the all-gather"
+        assert r[4] == res[0][4]                   # gathered metric means agree on every rank
+    d = res[0][3]
+    assert d["backend"] == "gloo" and d["world"] == 4 and d["ranks_seen"] == [0, 1, 2, 3] and d["ranks_seen_ok"] and len(d["devices"]) == 4

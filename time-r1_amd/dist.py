@@ -98,12 +98,43 @@ class GradSync:
             if a > pos:
                 self.ready(pos, a)
             pos = max(pos, b)
+        ev = _exposed_begin(self.g)
         for x, y, work in self.pending:
             work.wait()
             if self.stage is not None and copy_back:
                 self.g[x:y].copy_(self.stage[x:y])
+        _exposed_end(self, ev)
         self.pending, self.done = [], []
         self.active = False
+
+
+def _exposed_begin(t):
+    """HIP event on the compute stream in front of the waits on the exchange: the time until the matching end event is what the compute
+    stream spent WAITING for the gradient exchange (the part the backward did not hide)."""
+    if t.device.type != "cuda":
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _exposed_end(sync, e0):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    sync.exposed_events = (getattr(sync, "exposed_events", []) + [(e0, e1)])[-256:]
+
+
+def exposed_ms(sync, clear=True):
+    """Sum of the waits recorded by GradSync / ShardSync.finish since the last call (synchronises on the last event)."""
+    evs = getattr(sync, "exposed_events", [])
+    if clear:
+        sync.exposed_events = []
+    if not evs:
+        return 0.0
+    evs[-1][1].synchronize()
+    return float(sum(a.elapsed_time(b) for a, b in evs))
 
 
 class ShardSync:
@@ -165,10 +196,12 @@ class ShardSync:
             return
         for _, a, b in self.arena.segments:        # every segment nobody announced
             self.ready(a, b)
+        ev = _exposed_begin(self.g)
         for x, y, work in self.pending:
             work.wait()
             if self.stage is not None:
                 self.gshard[x:y].copy_(self.recv[x:y])
+        _exposed_end(self, ev)
         self.pending, self.done = [], set()
         self.active = False
 
@@ -184,5 +217,37 @@ def init_from_env(device_type="cuda"):
         backend = os.environ.get("TR1_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")   # "nccl" IS RCCL on ROCm
         if device_type == "cuda":
             torch.cuda.set_device(int(os.environ.get("TR1_FORCE_DEVICE", local)))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # explicit timeout: a rank that never arrives (wrong device mapping, a dead peer, an xGMI link that does not train) becomes an error line
+        # after TR1_DIST_TIMEOUT_S seconds instead of a job that hangs until the node lease kills it
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("TR1_DIST_TIMEOUT_S", "600")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
+
+
+def dist_diagnostics(device):
+    """What a first multi-GPU run needs to be debuggable from its one JSON line: which ranks actually took part in a collective on this
+    backend (sum / count of rank ids through an all-reduce, device names through an all-gather), the RCCL version torch was built against, the
+    backend name.  Every rank must call it (collectives); returns a dict (identical on all ranks)."""
+    out = {"backend": None, "world": 1, "ranks_seen": [0], "rccl_version": None, "devices": None}
+    try:
+        v = torch.cuda.nccl.version()
+        out["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:      # informative only
+        out["rccl_version"] = "unavailable: %r" % (e,)
+    dev = torch.device(device)
+    name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        out["devices"] = [name]
+        return out
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out["backend"], out["world"] = dist.get_backend(), world
+    onehot = torch.zeros(world, dtype=torch.int32, device=dev)
+    onehot[rank] = 1
+    dist.all_reduce(onehot)                                   # rank r contributed iff entry r == 1
+    out["ranks_seen"] = [i for i, x in enumerate(onehot.tolist()) if x == 1]
+    out["ranks_seen_ok"] = onehot.tolist() == [1] * world
+    names = [None] * world
+    dist.all_gather_object(names, "%s (cuda:%s)" % (name, dev.index) if dev.type == "cuda" else name)
+    out["devices"] = names
+    return out

@@ -79,7 +79,8 @@ class GRPOConfig:
     rollout_batching: bool = True           # decode the prompts of one accumulation window together (same weights, same results)
     grad_wire_dtype: str = "bf16"           # data-parallel gradient exchange wire format ("bf16" | "fp32")
     shard_optimizer: Optional[bool] = None  # ZeRO-style: master/m/v on 1/world of every arena segment, reduce-scatter grads, all-gather bf16 weights.
-                                            # None = follow `deepspeed` (a zero2 / zero3 json, as in every reference script) ; no effect on one GPU
+                                            # None = on for 2 / 4 / 8 ranks (what a zero2 / zero3 `deepspeed` json of the reference scripts selects;
+                                            # a non-zero json or False selects the replicated optimizer); no effect on one GPU
     gpu_video_preprocess: Optional[bool] = None   # uint8 frames -> fused HIP resize/normalise/patchify instead of the host processor's pixel path.
                                             # None = automatic: on whenever the row carries pre-decoded uint8 frames; False forces the host processor
     rollout_weight_dtype: str = "bf16"      # "fp8": the SAMPLING policy reads e4m3 copies of the decoder matrices (row scales, re-quantised every window);
@@ -355,7 +356,14 @@ class TimeR1_Trainer:
     def _wants_shard(args, dp=None):
         so = getattr(args, "shard_optimizer", None)
         ds = getattr(args, "deepspeed", None)       # reference scripts: --deepspeed scripts/zero3.json | zero3_offload.json | zero2.json
-        want = bool(so) if so is not None else (isinstance(ds, str) and "zero" in os.path.basename(ds).lower())
+        # None: follow `deepspeed` when one is given (every reference multi-GPU script passes a zero json); without one, N > 1 ranks still
+        # default to sharding - the exchange moves the same bytes as the all-reduce and each rank streams 1/N of the AdamW state
+        if so is not None:
+            want = bool(so)
+        elif isinstance(ds, str):
+            want = "zero" in os.path.basename(ds).lower()
+        else:
+            want = dp is not None and dp.enabled
         if want and dp is not None and dp.enabled and dp.world not in (2, 4, 8):
             # arena segments split into 1/2/4/8 equal 128-byte-aligned chunks (params.SEG_ALIGN); other world sizes train with the replicated
             # optimizer (same results, more optimizer-state memory) instead of failing at construction where the reference script ran
