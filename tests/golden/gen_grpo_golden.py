@@ -113,7 +113,10 @@ class FakeProc:
         return [fake_decode(r.tolist(), skip=(self.eos_token_id, self.pad_token_id) if skip_special_tokens else ()) for r in ids]
 
 
-def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8, model="qwen2_vl", frames_shape=(4, 3, 56, 84)):
+def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8, model="qwen2_vl", frames_shape=(4, 3, 56, 84), dtype=torch.float32, like=None):
+    """dtype=torch.bfloat16 + like=<fp32 case name>: the SAME micro-step (weights, frames, completion ids forced to the fp32 capture's) run by
+    the unmodified reference with the model in bf16 - every reference script trains in bf16 (timer1_trainer.py:244-246, :469).  The distance
+    of this capture from the fp32 one is the reference's own bf16 noise: the yardstick for the HIP path's tolerances (tests/test_trainer_gpu.py)."""
     ref_main = load_ref_main()
     t1, _ = load_ref_trainers()
     from transformers import GenerationConfig
@@ -140,6 +143,12 @@ def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8, model="qwen2_vl", 
     def tok(*idx):
         return [26 * 2 + i for i in idx]
     force_rows = {0: tok(0, 22, 1, 2, 8, 4, 14, 3), 1: tok(0, 18, 1, 2, 6, 4, 7, 3), 3: tok(2, 7, 4, 6, 7, 3, 16, 16)}
+    if like is not None:        # every row forced to the fp32 capture's completion (sampling from bf16 logits would pick other tokens)
+        comp32 = torch.load(os.path.join(HERE, "grpo_step_%s.pt" % like), weights_only=False)["completion_ids"]
+        force_rows, force_eos = {g_: comp32[g_].tolist() for g_ in range(G)}, None
+    if dtype != torch.float32:
+        hf, hf_ref = hf.to(dtype), hf_ref.to(dtype)
+        frames = frames.to(dtype).float()      # (values are integers 0..255: exact in bf16)
     policy = Shim(hf, cfg.video_token_id, force_eos=force_eos, force_rows=force_rows)
     tr.__dict__.update(processing_class=proc, accelerator=acc, num_generations=G, beta=beta, use_grpo=use_grpo, epsilon_low=0.2, epsilon_high=0.2,
                        epsilon=0.2, reward_funcs=[ref_main.iou_timestamp_reward_v2, ref_main.format_reward], reward_processing_classes=[None, None],
@@ -165,16 +174,16 @@ def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8, model="qwen2_vl", 
     P = ids.shape[1] - C
     comp = ids[:, P:]
     fx = {
-        "case": name, "use_grpo": use_grpo, "beta": beta, "G": G, "C": C, "seed": seed, "param_seed": 0,
+        "case": name, "use_grpo": use_grpo, "beta": beta, "G": G, "C": C, "seed": seed, "param_seed": 0, "dtype": str(dtype).replace("torch.", ""), "like": like,
         "frames_seed": 7, "frames_shape": tuple(frames_shape), "model": model, "row": {k: v for k, v in row.items()}, "prompt_ids": ids[0, :P].tolist(), "completion_ids": comp.clone(),
-        "completions": proc.batch_decode(comp), "logp": cap["calls"][0]["logp"][:, P - 1:], "entropy": cap["calls"][0]["ent"][:, P - 1:],
-        "ref_logp": cap["calls"][1]["logp"][:, P - 1:] if beta != 0 else None, "loss": loss.detach().clone(),
+        "completions": proc.batch_decode(comp), "logp": cap["calls"][0]["logp"][:, P - 1:].float(), "entropy": cap["calls"][0]["ent"][:, P - 1:].float(),
+        "ref_logp": cap["calls"][1]["logp"][:, P - 1:].float() if beta != 0 else None, "loss": loss.detach().float().clone(),
         "metrics": {k: list(v) for k, v in tr._metrics.items()},
         "ref_noise_seed": 99,
-        "grads": {k: p.grad.detach().clone() for k, p in hf.named_parameters() if p.grad is not None and
+        "grads": {k: p.grad.detach().float().clone() for k, p in hf.named_parameters() if p.grad is not None and
                   any(s in k for s in ("lm_head", "layers.0.self_attn.q_proj", "layers.1.mlp.down_proj", "merger.mlp.2", "merger.ln_q", "norm.weight", "layers.0.self_attn.v_proj.bias"))},
         "grad_norms": {k: float(p.grad.norm()) for k, p in hf.named_parameters() if p.grad is not None},
-        "embed_grad_rows": {int(i): hf.model.language_model.embed_tokens.weight.grad[int(i)].clone() for i in set(comp.reshape(-1).tolist()[:6] + [5, 10])},
+        "embed_grad_rows": {int(i): hf.model.language_model.embed_tokens.weight.grad[int(i)].float().clone() for i in set(comp.reshape(-1).tolist()[:6] + [5, 10])},
     }
     out = os.path.join(HERE, "grpo_step_%s.pt" % name)
     torch.save(fx, out)
@@ -188,7 +197,9 @@ if __name__ == "__main__":
         run_case("clip_beta", False, 0.04, {0: 2, 2: 5}, 124)
         run_case("grpo_nobeta_ragged", True, 0.0, {1: 0, 3: 6}, 125)
         run_case("clip_nobeta", False, 0.0, None, 126)
+        run_case("grpo_beta_bf16", True, 0.04, None, 123, dtype=torch.bfloat16, like="grpo_beta")
     if "qwen2_5_vl" in which:
         # Qwen2.5-VL (the family the reference hard-codes): windowed ViT with ragged windows (84x112 -> 3x4 merged tokens, 2x2 windows)
         run_case("q25_grpo_beta", True, 0.04, None, 223, model="qwen2_5_vl", frames_shape=(4, 3, 84, 112))
         run_case("q25_clip_beta_ragged", False, 0.04, {0: 3, 2: 5}, 224, model="qwen2_5_vl", frames_shape=(6, 3, 56, 140))
+        run_case("q25_grpo_beta_bf16", True, 0.04, None, 223, model="qwen2_5_vl", frames_shape=(4, 3, 84, 112), dtype=torch.bfloat16, like="q25_grpo_beta")

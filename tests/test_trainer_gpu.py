@@ -119,3 +119,44 @@ def test_trainer_path_gradients_equal_engine_path_gradients(hip_ops):
     # same kernels on the same inputs; the only freedom is the order of the fp32 atomic adds in the embedding / norm-weight gradient kernels
     rel = float((grad_a - grad_b).norm() / grad_b.norm())
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("case", ["grpo_beta", "q25_grpo_beta"])
+def test_hip_path_is_as_close_to_fp32_as_the_reference_in_bf16(hip_ops, case):
+    """the 0.06 / 6 % tolerances above are assertions; this turns them into a measurement.  `grpo_step_<case>_bf16.pt` is the
+    SAME micro-step (weights, frames, completion ids) run by the unmodified reference with its model in bf16 - what every reference script
+    does (timer1_trainer.py:244-246, :469).  Its distance from the fp32 capture is the reference's own bf16 noise; the HIP path (bf16 storage,
+    fp32 accumulation / softmax / statistics) must not be further from fp32 than 1.5 x that noise (+ a small absolute floor)."""
+    fx, fx16 = load_case(case), load_case(case + "_bf16")
+    assert fx16["dtype"] == "bfloat16" and torch.equal(fx16["completion_ids"], fx["completion_ids"])
+    cfg, tr = _make(fx, hip_ops)
+    frames = frames_for(fx)
+    tr._video_inputs = lambda ex: ([frames], [2.0])
+    seen = {}
+    orig = tr.core.loss_backward
+
+    def spy(st, *a, **k):
+        seen["logp"], seen["ent"] = st.logp.float().cpu(), st.entropy.float().cpu()
+        seen["ref_logp"] = st.ref_logp.float().cpu() if st.ref_logp is not None else None
+        return orig(st, *a, **k)
+    tr.core.loss_backward = spy
+    row = dict(fx["row"])
+    row["_forced_completion_ids"] = fx["completion_ids"].numpy()
+    loss = float(tr.compute_loss(tr.model, [row]))
+    report = {}
+    for key in ("logp", "ref_logp"):
+        e_ref = float((fx16[key] - fx[key]).abs().max())
+        e_hip = float((seen[key] - fx[key]).abs().max())
+        report[key] = (e_hip, e_ref)
+        assert e_hip <= 1.5 * e_ref + 2e-3, (key, e_hip, e_ref)
+    e_ref, e_hip = abs(float(fx16["loss"]) - float(fx["loss"])), abs(loss - float(fx["loss"]))
+    assert e_hip <= 1.5 * e_ref + 2e-4, ("loss", e_hip, e_ref)
+    g = tr.params.train
+    for hk, gold in fx["grads"].items():
+        if hk in HF_GRAD_KEYS:
+            mine = pick_grad(cfg, g.g, hk).float().cpu()
+            r_hip = float((mine - gold).norm() / gold.norm().clamp(min=1e-12))
+            r_ref = float((fx16["grads"][hk] - gold).norm() / gold.norm().clamp(min=1e-12))
+            report[hk] = (r_hip, r_ref)
+            assert r_hip <= 1.5 * r_ref + 5e-3, (hk, r_hip, r_ref)
+    print("HIP-vs-fp32 error against the reference's own bf16-vs-fp32 error:", {k: (round(a, 5), round(b, 5)) for k, (a, b) in report.items()})
