@@ -25,6 +25,9 @@ extern "C" {
 int tr1_version(void);
 const char* tr1_last_error(void);
 int tr1_device_info(int device, char* arch, int64_t arch_len, int64_t* n_cu, int64_t* hbm_bytes);
+/* Measurement helper (bench.py `peak_probe`, SURVEY 8d roofline): reads `bytes` of device memory once with row-contiguous 1 KiB wave requests;
+ * timed by the caller, it gives the practical HBM read ceiling of the box that the decode GEMMs' `roofline.frac_of_measured` is read against. */
+int tr1_probe_hbm_read(const void* buf, int64_t bytes, void* sink_u32, void* stream);
 
 /* ---- GEMM: C[M,N] = A[M,K] * B[N,K]^T (+bias[N]) (+residual[M,N]); bf16 in, fp32 accumulate on MFMA ------------------- */
 /* ref: every nn.Linear on the path - TF:501-504 (q/k/v/o), TF:459-466 (MLP), TF:251-274 (patch embed), TF:277-290 (merger),

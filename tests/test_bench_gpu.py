@@ -34,7 +34,11 @@ def test_driver_argument_shape_runs_and_reports_contract_fields():
     assert {"preprocess", "vision", "rollout", "logps", "backward", "optimizer"} <= set(out["phases_ms_per_step"])
     for k in ("roofline", "roofline_secondary"):
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "peak_measured"} <= set(out[k])
-    assert out["peak_probe"]["hbm_copy_GBs"] > 500
+    assert out["peak_probe"]["hbm_copy_GBs"] > 500 and out["peak_probe"]["hbm_read_stream_GBs"] > 500
+    for k in ("roofline", "roofline_secondary"):                # `peak_measured` >= the best own launch, so the fraction cannot exceed 1
+        assert out[k]["frac_of_measured"] is None or out[k]["frac_of_measured"] <= 1.0 + 1e-9, out[k]
+        assert "traffic_guard" in out[k]
+    assert {"samples_per_sec", "rollout_tokens_per_sec", "perf/decode_hbm_frac", "perf/train_mfma_frac"} <= set(out["trainer_log_last"])
 
 
 def test_ragged_eos_run_counts_only_tokens_up_to_the_injected_eos():

@@ -20,3 +20,32 @@ extern "C" int tr1_device_info(int device, char* arch, int64_t arch_len, int64_t
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
     return 0;
 }
+
+// ---- HBM read-stream probe (bench.py peak_probe): every wave instruction reads 1 KiB contiguous (64 lanes x 16 B), 8 in flight per wave,
+// non-temporal (the bytes are touched once).  The rate of this kernel over a buffer larger than the 256 MB Infinity Cache is the practical
+// ceiling the HBM-bound decode kernels are read against (`roofline.peak_measured`); a torch device-to-device copy - the round-2 probe - moves
+// read + write streams and measured below the library's own gate/up kernel.
+typedef __attribute__((ext_vector_type(4))) unsigned int probe_u32x4_t;
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const probe_u32x4_t* __restrict__ src, int64_t n16, unsigned* __restrict__ sink) {
+    const int64_t per_block = (n16 + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per_block;
+    const int64_t b1 = b0 + per_block < n16 ? b0 + per_block : n16;
+    probe_u32x4_t acc = {0, 0, 0, 0};
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 256 * 8) {
+        probe_u32x4_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = i + (int64_t)j * 256;
+            v[j] = __builtin_nontemporal_load(src + (k < b1 ? k : b1 - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc ^= v[j];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) sink[0] = 1;       // keeps the loads alive; practically never true
+}
+// Reads `bytes` (multiple of 16) of device memory once.  The caller times it with HIP events on `stream`.
+extern "C" int tr1_probe_hbm_read(const void* buf, int64_t bytes, void* sink_u32, void* stream) {
+    TR1_CHECK_ARG(buf && sink_u32 && bytes >= 16 && bytes % 16 == 0, "hbm read probe: bytes must be a positive multiple of 16");
+    hipLaunchKernelGGL(hbm_read_probe_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const probe_u32x4_t*)buf, bytes / 16, (unsigned*)sink_u32);
+    TR1_LAUNCH_CHECK();
+}

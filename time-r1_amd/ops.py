@@ -49,6 +49,10 @@ class HipOps:
             torch.cuda.set_stream(self._main_stream)
         return self._main_stream
 
+    def probe_hbm_read(self, buf, sink):
+        """Measurement helper: one streaming read of `buf` (bench.py times it)."""
+        self.L.call("tr1_probe_hbm_read", _p(buf), buf.numel() * buf.element_size(), _p(sink), self._s())
+
     # ---- memory helpers -------------------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.act_dtype, device=self.device)

@@ -27,9 +27,14 @@ def main():
         a[1] += v
     out = {k: {"launches": c, "fetch_bytes_per_launch_corrected": 2.0 * 1024.0 * t / c} for k, (c, t) in sorted(acc.items()) if c and t / c > 1024}
     out["_note"] = sys.argv[3] if len(sys.argv) > 3 else ""
+    # fingerprint of the kernel sources this pass measured: bench.py attaches these numbers as `roofline.traffic` only while the sources are
+    # unchanged (a kernel edit that alters traffic must not keep quoting the old counters)
+    import hashlib, os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "time-r1_amd", "csrc")
+    out["_source_sha16"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in ("gemm.hip", "decode.hip")}
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     for k, v in out.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print("%-40s %7d launches  %10.2f MB/launch" % (k, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6))
 
 
