@@ -160,3 +160,26 @@ def test_hip_path_is_as_close_to_fp32_as_the_reference_in_bf16(hip_ops, case):
             report[hk] = (r_hip, r_ref)
             assert r_hip <= 1.5 * r_ref + 5e-3, (hk, r_hip, r_ref)
     print("HIP-vs-fp32 error against the reference's own bf16-vs-fp32 error:", {k: (round(a, 5), round(b, 5)) for k, (a, b) in report.items()})
+
+
+@pytest.mark.parametrize("wdtype", ["bf16", "fp8-mfma"])
+def test_rollout_logp_drift_is_logged_on_hip(hip_ops, wdtype):
+    """Config 5 (fp8 sampling policy): the drift of the sampled tokens' log-probs against the bf16 update policy is a logged metric; with bf16
+    rollout weights (decode kernels vs training kernels, same weights) it is numerical noise."""
+    from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig
+    from time_r1_amd import rewards as R
+    from time_r1_amd.config import tiny_test
+    from time_r1_amd.params import ModelParams
+    from oracle.text import FakeProcessor
+    cfg = tiny_test(n_layers=3)
+    args = GRPOConfig(output_dir="/tmp/tr1_gpu_drift", num_generations=8, max_completion_length=10, beta=0.0, use_grpo=True, temperature=1.0,
+                      save_strategy="no", rollout_weight_dtype=wdtype, log_rollout_drift=True, disable_log_print=True)
+    tr = TimeR1_Trainer(ModelParams(cfg, hip_ops, seed=1), [R.format_reward], [], args=args, processing_class=FakeProcessor(cfg), ops=hip_ops)
+    frames = torch.randint(0, 256, (8, 3, 84, 112), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    row = {"problem": "person sits down", "video_path": "x.mp4", "video_frames": frames, "solution": (2.0, 12.0), "durations": 30.0}
+    tr.compute_loss(tr.model, [row])
+    d = tr._metrics["rollout_logp_drift"][0]
+    assert np.isfinite(d) and d >= 0
+    assert d < (0.02 if wdtype == "bf16" else 0.2), d
+    if wdtype != "bf16":
+        assert d > 1e-5, "an fp8 sampling policy cannot reproduce the bf16 log-probs exactly"

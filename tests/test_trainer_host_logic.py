@@ -273,3 +273,44 @@ def test_constructor_accepts_a_loaded_transformers_model(case, tmp_path):
     assert tr2.cfg.text == cfg.text and tr2.cfg.vision == cfg.vision
     bf = lambda x: x.to(torch.bfloat16).float()          # save_model writes 16-bit weights (zero3.json:32); the oracle arena is fp32
     assert torch.equal(bf(tr2.params.train.w16), bf(tr.params.train.w16)) and torch.equal(bf(tr2.params.frozen.w16), bf(tr.params.frozen.w16))
+
+
+def test_rollout_drift_metric_and_importance_cap_flag():
+    """a quantised sampling policy's drift is a logged number, and a truncated importance weight exists behind a flag that
+    leaves the reference algebra untouched when off.  On the CPU oracle the sampling policy IS the policy, so the drift is ~0, rho == 1 and the
+    capped run reproduces the plain run; a perturbed sampling log-prob then moves the gradient by exactly (1 - rho) * A * w."""
+    fx = load_case("grpo_beta")
+    outs = {}
+    for name, over in (("plain", {}), ("drift", dict(log_rollout_drift=True)), ("cap", dict(rollout_importance_cap=2.0))):
+        cfg, tr = make_trainer(fx, disable_log_print=True, **over)
+        assert tr.core.roll.track_logp == (name != "plain")
+        tr._video_inputs = lambda ex: ([frames_for(fx)], [2.0])
+        loss = float(tr.compute_loss(tr.model, [dict(fx["row"])]))
+        outs[name] = (loss, tr.params.train.grad.clone(), dict(tr._metrics))
+    assert "rollout_logp_drift" not in outs["plain"][2]
+    for name in ("drift", "cap"):
+        assert outs[name][2]["rollout_logp_drift"][0] < 1e-4                      # same weights, same arithmetic: decode logits == training logits
+        assert abs(outs[name][0] - outs["plain"][0]) < 1e-6 and torch.allclose(outs[name][1], outs["plain"][1], atol=1e-6, rtol=1e-4)
+    # a sampling policy that is 0.5 nats more confident than the update policy on every token: rho = exp(-0.5), loss shifts by sum (1 - rho) A w
+    cfg, tr = make_trainer(fx, disable_log_print=True, rollout_importance_cap=2.0)
+    tr._video_inputs = lambda ex: ([frames_for(fx)], [2.0])
+    orig = tr.core.rollout
+
+    def shifted(st):
+        out = orig(st)
+        st.sample_logp = st.sample_logp + 0.5
+        return out
+    tr.core.rollout = shifted
+    seen = {}
+    lb = tr.core.loss_backward
+
+    def spy(st, mask, adv, scale, grad_sync=None, tok_weight=None):
+        seen["w"], seen["adv"], seen["mask"] = tok_weight.clone(), adv.clone(), mask.clone()
+        return lb(st, mask, adv, scale, grad_sync=grad_sync, tok_weight=tok_weight)
+    tr.core.loss_backward = spy
+    loss = float(tr.compute_loss(tr.model, [dict(fx["row"])]))
+    assert torch.allclose(seen["w"], torch.full_like(seen["w"], float(np.exp(-0.5))), atol=1e-3)
+    m = seen["mask"].float()
+    w = m / m.sum(1, keepdim=True) / fx["G"]
+    want = outs["plain"][0] + float(((1 - seen["w"]) * seen["adv"][:, None] * w).sum())
+    assert abs(loss - want) < 1e-5 and abs(tr._metrics["rollout_logp_drift"][0] - 0.5) < 1e-3

@@ -116,6 +116,7 @@ class GRPOCore:
         st.layout = lay
         st.completion_ids = tokens        # int32 [G, C] on device
         st.prefill = self.roll.last_prefill[0] if self.reuse_prefill else None
+        st.sample_logp = self.roll.last_sample_logp[0] if self.roll.last_sample_logp is not None else None
         self._pending_decode = (getattr(self, "_pending_decode", []) + [[st.P]])[-64:]
         return tokens
 
@@ -127,6 +128,7 @@ class GRPOCore:
         for b, (st, (tokens, lay)) in enumerate(zip(states, outs)):
             st.layout, st.completion_ids = lay, tokens
             st.prefill = self.roll.last_prefill[b] if self.reuse_prefill else None
+            st.sample_logp = self.roll.last_sample_logp[b] if self.roll.last_sample_logp is not None else None
         self._pending_decode = (getattr(self, "_pending_decode", []) + [[st.P for st in states]])[-64:]
         return [st.completion_ids for st in states]
 
@@ -198,7 +200,7 @@ class GRPOCore:
             st.ref_logp = self._to_gc(st, rlogp).contiguous()
 
     # ------------------------------------------------------------------------------------------------------- phase 4
-    def loss_backward(self, st, completion_mask, advantages, grad_scale=1.0, grad_sync=None):
+    def loss_backward(self, st, completion_mask, advantages, grad_scale=1.0, grad_sync=None, tok_weight=None):
         """completion_mask int32 [G, C], advantages fp32 [G] (device). Accumulates grads into the trainable arena.
         grad_sync: a dist.GradSync in its begin() state when this is the LAST micro-step of the accumulation window - parameter ranges
         are handed to the all-reduce as soon as their gradients are final, overlapping the exchange with the rest of the backward.
@@ -209,6 +211,16 @@ class GRPOCore:
         if grad_sync is not None and grad_sync.active:
             hook = lambda i: grad_sync.ready(*tr.range_of("l%d." % i))
         dlogp, out3, row_len, _ = ops.grpo_loss(st.logp, st.ref_logp, completion_mask, advantages, self.beta, self.use_grpo, grad_scale)
+        if tok_weight is not None:
+            # optional truncated importance weight rho[g, t] (a constant) on the advantage term, for completions drawn from a quantised sampling
+            # policy: l = -rho * A + beta * kl = l_plain + (1 - rho) * A, same normalisation as the kernel.  None (the default) leaves the
+            # reference algebra untouched - this branch is then not executed at all.
+            m = completion_mask.to(torch.float32)
+            w = (m / row_len.reshape(-1, 1).clamp(min=1.0) / float(st.layout.G)) if self.use_grpo else (m / out3[2].clamp(min=1.0))
+            corr = (1.0 - tok_weight.to(torch.float32)) * advantages.reshape(-1, 1).to(torch.float32) * w
+            dlogp = dlogp + (corr * float(grad_scale)).to(dlogp.dtype)
+            out3 = out3.clone()
+            out3[0] = out3[0] + corr.sum().to(out3.dtype)
         dl_pred = dlogp.reshape(-1)[st.perm].contiguous()
         dh = eng.head_bwd(st.head_ctx, dl_pred, st.layout.G)
         if hook is not None and not self.cfg.text.tie_word_embeddings:

@@ -43,6 +43,10 @@ class Rollout:
         #                               per call; "fp8" converts the codes to bf16 in registers (W8A16), "fp8-mfma" feeds them to the fp8 matrix
         #                               instruction with block-quantised e4m3 activations (W8A8, BASELINE config "CDNA4 fp8 MFMA")
         self._w8 = None
+        self.track_logp = False       # also record, per drawn token, its full-softmax log-prob under the logits it was SAMPLED from (one more pass
+        #                               over the step's L2-resident logits): the drift of a quantised sampling policy against the bf16 policy of the
+        #                               update is then a logged number (trainer metric rollout_logp_drift), and an importance weight is available
+        self.last_sample_logp = None
 
     def _kv(self, B, s_cap):
         t = self.eng.cfg.text
@@ -86,6 +90,7 @@ class Rollout:
         steps = ops.tensor(np.arange(C, dtype=np.int32), I32)
         tokens_all = ops.zeros(B * G, C, dtype=I32)
         finished_all = ops.zeros(B * G, dtype=I32)
+        slogp_all = ops.zeros(B * G, C, dtype=torch.float32) if self.track_logp else None
         per = []
         cos_rows, sin_rows = [], []
         lays = [PackedLayout(int(it[0].shape[0]), G, C) for it in items]
@@ -112,6 +117,8 @@ class Rollout:
             finished = finished_all[b * G:(b + 1) * G]
             ops.sample_tokens(logits.expand(G, logits.shape[1]), self.temperature, self.top_k, seed, steps[0:1], tokens, finished,
                               cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+            if slogp_all is not None:      # (the first token is drawn from the bf16 prefill's logits in every mode)
+                slogp_all[b * G:(b + 1) * G, 0] = ops.logp_entropy_fwd(logits.expand(G, logits.shape[1]).contiguous(), tokens[:, 0].contiguous())[0]
             # ---- per-step tables (positions, slots, masks) built once
             comp_pos = (P + delta + np.arange(C, dtype=np.int64))
             pos_c = ops.tensor(np.repeat(comp_pos[None, :], 3, 0).astype(np.int32), I32)            # [3, C]
@@ -168,6 +175,8 @@ class Rollout:
                 # all prompts of the window in ONE sampler launch set; every prompt keeps its own Philox stream (seed_b = seed_0 + 7919 b)
                 ops.sample_tokens(logits, self.temperature, self.top_k, per[0]["seed"], steps[s + 1:s + 2], tokens_all, finished_all, cfg.eos_token_id,
                                   cfg.pad_token_id, self.stop_at_eos, group_rows=G, seed_stride=7919)
+                if slogp_all is not None:
+                    slogp_all[:, s + 1] = ops.logp_entropy_fwd(logits, tokens_all[:, s + 1].contiguous())[0]
                 continue
             ids_s = tokens_all[:, s].contiguous()
             cs, sn = cos_all[s], sin_all[s]
@@ -216,9 +225,12 @@ class Rollout:
             for b, st in enumerate(per):
                 ops.sample_tokens(logits[b * G:(b + 1) * G], self.temperature, self.top_k, st["seed"], steps[s + 1:s + 2], st["tokens"],
                                   st["finished"], cfg.eos_token_id, cfg.pad_token_id, self.stop_at_eos)
+            if slogp_all is not None:
+                slogp_all[:, s + 1] = ops.logp_entropy_fwd(logits.contiguous(), tokens_all[:, s + 1].contiguous())[0]
         if timed:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             self.decode_events = (getattr(self, "decode_events", []) + [(ev0, ev1)])[-64:]
+        self.last_sample_logp = [slogp_all[b * G:(b + 1) * G] for b in range(B)] if slogp_all is not None else None
         self.last_prefill = [(st["prefill_ctx"], st["kv"]) for st in per]    # (saved prompt activations, cache views) per prompt
         return [(st["tokens"], st["lay"]) for st in per]

@@ -86,6 +86,10 @@ class GRPOConfig:
     rollout_weight_dtype: str = "bf16"      # "fp8": the SAMPLING policy reads e4m3 copies of the decoder matrices (row scales, re-quantised every window);
                                             # log-probs, KL and the update keep bf16 weights (BASELINE config "fp8 weights")
     disable_log_print: bool = False         # keep log() from printing on rank 0 (bench.py prints exactly one JSON line)
+    log_rollout_drift: Optional[bool] = None   # metric rollout_logp_drift = mean |logp under the SAMPLING policy's logits - policy logp| over the
+                                            # completion tokens; None = on whenever the rollout reads quantised weights (or an importance cap is set)
+    rollout_importance_cap: Optional[float] = None   # c: advantage term weighted by min(exp(policy logp - sampling logp), c) per token (truncated
+                                            # importance sampling for a quantised sampling policy); None = off, the reference algebra unchanged
     dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
@@ -334,6 +338,9 @@ class TimeR1_Trainer:
                              use_grpo=self.use_grpo, temperature=args.temperature, top_k=args.top_k, seed=args.seed + 1000 * self.dp.rank,
                              rope_index_mode=args.rope_index_mode, stop_at_eos=args.stop_at_eos)
         self.core.roll.weight_dtype = getattr(args, "rollout_weight_dtype", "bf16")
+        drift = getattr(args, "log_rollout_drift", None)
+        self._is_cap = getattr(args, "rollout_importance_cap", None)
+        self.core.roll.track_logp = bool(drift) if drift is not None else (self.core.roll.weight_dtype != "bf16" or self._is_cap is not None)
         if optimizers[0] is not None:
             raise NotImplementedError("custom torch optimizers are not supported; the engine owns a fused AdamW over its flat arena")
         self.optimizer = AdamWFlat(self.params, ops, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
@@ -503,15 +510,24 @@ class TimeR1_Trainer:
         if self._is_ft and not self.use_grpo:   # reference timer1_trainer_ft.py:820-842 (undefined there for use_grpo: coef_1 does not exist)
             lp = st.logp.float()
             clip3 = torch.stack(clip_ratio_metrics(lp, lp, adv_dev, maskf, self.epsilon_low, self.epsilon_high))   # old policy == policy (one update per rollout)
-        out3, row_len = self.core.loss_backward(st, mask_dev, adv_dev, scale, grad_sync=sync)
+        drift_t, tokw = None, None
+        slp = getattr(st, "sample_logp", None)
+        if slp is not None and ctx["forced"] is None:
+            d = (st.logp.float() - slp.to(st.logp.device).float())          # log importance ratio of every drawn token: update policy / sampling policy
+            drift_t = (d.abs() * maskf).sum() / maskf.sum().clamp(min=1)
+            if self._is_cap is not None:
+                tokw = torch.exp(d).clamp(max=float(self._is_cap))
+        out3, row_len = self.core.loss_backward(st, mask_dev, adv_dev, scale, grad_sync=sync, **({"tok_weight": tokw} if tokw is not None else {}))
         self._clock.mark("backward")
         out3f = out3.float()
-        dev = torch.cat([out3f[:2], ent_mean.reshape(1)] + ([clip3.float()] if clip3 is not None else []))
+        z = torch.zeros(3, dtype=torch.float32, device=out3f.device)
+        dev = torch.cat([out3f[:2], ent_mean.reshape(1).float(), clip3.float() if clip3 is not None else z,
+                         drift_t.reshape(1).float() if drift_t is not None else z[:1]])      # fixed layout: loss, kl, entropy, clip x 3, drift
         # ---- metrics (reference :739-777; ft adds metrics/<fn> and clip ratios :789-842): per-sample host values + the device vector,
         # turned into the reference's gathered means by _flush_metrics
         self._pending.append(dict(length=mask_np.sum(1).astype(np.float32), rpf=rewards_per_func.numpy().copy(), reward=rewards.numpy().copy(),
                                   std=std.numpy().copy(), mvals=None if metric_vals is None else metric_vals.numpy(), dev=dev,
-                                  has_clip=clip3 is not None))
+                                  has_clip=clip3 is not None, has_drift=drift_t is not None))
         self.last_completions = completions
         self.last_rewards = rewards
         return out3f[0]
@@ -563,6 +579,8 @@ class TimeR1_Trainer:
                 M["clip_ratio/high_mean"].append(g_high.nanmean().item())
                 M["clip_ratio/high_max"].append(g_high[~g_high.isnan()].max().item() if (~g_high.isnan()).any() else float("nan"))
                 M["clip_ratio/region_mean"].append(g_reg.nanmean().item())
+            if r.get("has_drift"):
+                M["rollout_logp_drift"].append(v[:, o_dev + 6].mean().item())
             self._tok_since_log += float(v[:, :G].sum())
             self.generated_tokens += float(v[:, :G].sum())        # cumulative, all ranks
 
