@@ -468,14 +468,19 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             o_0 = o_0.clone()
             o_2, _ = hip_ops.attn_fwd(q2.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit,
                                       need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=2)
-            assert torch.equal(o_w, o_h) and torch.equal(o_2, o_0), "planned split-KV attention must be bit-identical (nsplit=%d)" % nsplit
+            # publishing launch (mode 1) == plain launch bit for bit (same kernel); the reading launches (mode 2) take the LDS-DMA kernel at head
+            # dim 128 (round 3: attn_dec32_kernel) - same tiles, same masks, another accumulation order
+            assert torch.equal(o_w, o_h), "publishing the plan must not change the result (nsplit=%d)" % nsplit
+            close(o_2, o_0, 0.01, what="plan-reading decode attention nsplit=%d" % nsplit)
+            close(o_2, ref_ops.attn_fwd(q2.float(), k.float(), vt_r, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, n_batch=B, kv_batch_slots=s_cap)[0], 0.02,
+                  what="plan-reading decode attention vs oracle nsplit=%d" % nsplit)
             cnt = plan.view(B, -1, 1025)[:, :, 1024]
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
 
 def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):
     """A reader block holds one plan entry per thread: with few splits and many relevant tiles (n_rel > 256 * nsplit) the publishing launch stores
-    count -1 and the reading launches take the full path - still the same bits."""
+    count -1 and the reading launches take the full path - the same result."""
     G, C, step, nh, nkv, hd, P, nsplit = 4, 64, 63, 4, 1, 128, 40000, 2       # 625 prefix tiles + 4 suffix tiles > 256 * 2
     S = P + G * C
     k = (torch.randn(S, nkv * hd, generator=torch.Generator().manual_seed(1)) * 0.3).to(BF16).cuda()
@@ -491,7 +496,8 @@ def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_b
     o1 = o1.clone()
     assert int(plan[1024]) == -1, int(plan[1024])
     o2, _ = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, plan=plan, plan_mode=2)
-    assert torch.equal(o0, o1) and torch.equal(o0, o2)
+    assert torch.equal(o0, o1)
+    close(o2, o0, 0.01, what="plan fallback (count -1): the reading kernel walks the block's tile ranges itself")
     with pytest.raises(RuntimeError):       # a plan needs split-KV
         hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, nsplit=1, need_lse=False, plan=plan, plan_mode=1)
 

@@ -453,6 +453,8 @@ __global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_
     }
 }
 
+bool tr1_launch_attn_dec32(const AttnParams& p, dim3 grid, hipStream_t s);      // attn_fwd32.hip
+
 template <int D, int CB, int PF>
 static void launch_fwd(dim3 grid, hipStream_t s, const AttnParams& p) {
     const size_t dyn = 2 * (ATT_KV * (2 * D + 16) + D * 144) + 64 + (PF > 1 ? (ATT_LIST_CAP + 1) * 4 : 0);
@@ -515,7 +517,9 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
         grid = dim3((unsigned)p.xcd_pad, 1, 1);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (decode) {
+    if (decode && tr1_launch_attn_dec32(p, grid, s)) {
+        // head dim 128 reading the per-step plan: the LDS-DMA kernel of attn_fwd32.hip (all of a block's tiles in flight at once)
+    } else if (decode) {
         switch (d_pad) {
             case 32: launch_fwd<32, 1, 3>(grid, s, p); break;
             case 64: launch_fwd<64, 1, 3>(grid, s, p); break;

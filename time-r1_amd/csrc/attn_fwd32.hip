@@ -210,6 +210,342 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- split-KV decode (head dim 128)
+// One block = 64 packed query rows (2 waves x 32) of one (prompt, kv head) x one split of the key tiles; launched for the layers of a decode step
+// that read the per-step tile plan (plan_mode 2).  The old decode kernel stages K / V^T tiles through registers, where hipcc drains every load
+// before each tile is written to LDS; here all of a block's tiles (2-3 at config 3) are requested at once by asm-issued LDS DMA and consumed
+// behind hand-counted vmcnt waits, so a block costs ONE memory round trip.  K tile: 64 rows x 256 B (swizzled with skey); V^T tile: 128 feature
+// rows x 128 B straight from the cache's V^T layout (chunk ^ (row & 7)).  Partials go to the same workspace the combine kernel reads.
+#define DEC32_CAP 1024      // = ATT_LIST_CAP of attn_fwd.hip (plan entry layout: [CAP ids | count])
+#ifdef TR1_PROBE
+__device__ unsigned long long* tr1_dec_probe = nullptr;          // [blocks][4 waves][12 stamps]  (tools/bench_attn_decode.py PROBE=1, -DTR1_PROBE build)
+extern "C" int probe_dec_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_dec_probe), &ptr, sizeof(ptr)); }
+#define DEC_STAMPS unsigned long long dst_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DEC_STAMP(i) do { dst_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DEC_FLUSH() do { if (tr1_dec_probe && (threadIdx.x & 63) == 0) { const size_t bid_ = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+    _Pragma("unroll") for (int s_ = 0; s_ < 12; ++s_) tr1_dec_probe[(bid_ * 4 + (threadIdx.x >> 6)) * 12 + s_] = dst_[s_]; } } while (0)
+#else
+#define DEC_STAMPS do { } while (0)
+#define DEC_STAMP(i) do { } while (0)
+#define DEC_FLUSH() do { } while (0)
+#endif
+__global__ __launch_bounds__(512) void attn_dec32_kernel(AttnParams p) {
+    constexpr int D = 128, NB = 4, KT = 64 * 256, VT = 128 * 128, BUF = KT + VT;
+    DEC_STAMPS;
+    DEC_STAMP(0);
+    extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][K rows | V^T rows] | Q rows (64 x 256 B) | pre, lo, hi [64] | meta
+    constexpr int QOFF = NB * BUF, MOFF = QOFF + 64 * 256;
+    int* lds_meta = reinterpret_cast<int*>(dyn_lds + MOFF + 768);    // [2][3]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c32 = lane & 31, h = lane >> 5;
+    const int gx = gridDim.x, gy = gridDim.y, by = blockIdx.y, split = blockIdx.z;
+    const int b = by / p.n_kv, kvh = by - b * p.n_kv;
+    const int qtile = gx - 1 - (int)blockIdx.x;
+    p.Q += (int64_t)b * p.T * p.q_ld; p.pre += (int64_t)b * p.T; p.lo += (int64_t)b * p.T; p.hi += (int64_t)b * p.T;
+    const unsigned nR = (unsigned)p.T * (unsigned)p.group;
+    const int* plan_blk = p.plan + ((int64_t)b * gx + qtile) * (DEC32_CAP + 1);
+    // the plan words this block can need for its first NB tiles, requested TOGETHER at kernel entry (independent scalar loads, one wait much
+    // later): read one by one where they are used, they were four dependent L2 round trips (~3 us) in front of the late tiles' DMA
+    int plan_w[NB + 1];
+    plan_w[NB] = plan_blk[DEC32_CAP];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const int idx = split + j * p.nsplit; plan_w[j] = plan_blk[idx < DEC32_CAP ? idx : DEC32_CAP - 1]; }
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(att_lptr_t)dyn_lds;
+    const char* kbase = reinterpret_cast<const char*>(p.K) + ((int64_t)b * p.kv_batch_slots * p.k_ld + (int64_t)kvh * D) * 2;
+    const char* vbase = reinterpret_cast<const char*>(p.VT) + ((int64_t)kvh * D * p.vt_ld + (int64_t)b * p.kv_batch_slots) * 2;
+    const unsigned k_ldb = (unsigned)p.k_ld * 2u, vt_ldb = (unsigned)p.vt_ld * 2u;
+    // 8 waves: waves 0..3 compute - (row half rw, key half kh) of every 64 x 64 tile, so a wave's share of a tile is 8 + 8 MFMAs and 16 score
+    // elements per lane (the block is a latency chain: per-wave work is what the tiles cost) - and all 8 issue DMA, 4 instructions per tile and
+    // wave (an LDS-DMA instruction costs 60-280 issue cycles).  Lane constants of the DMA are hoisted; a tile adds one scalar multiple.
+    unsigned koff[2], voff[2], kdst[2], vdst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = wave * 2 + j;
+        const unsigned krow = 4u * i + ((unsigned)lane >> 4);        // K rows 4i .. 4i+3 (256 B each): lane -> row, physical chunk lane%16
+        koff[j] = krow * k_ldb + (unsigned)(((lane & 15) ^ skey(krow & 15)) << 4);
+        const unsigned vrow = 8u * i + ((unsigned)lane >> 3);        // V^T rows 8i .. 8i+7 (128 B = 64 slots each): physical chunk lane%8 = logical ^ (row & 7)
+        voff[j] = vrow * vt_ldb + (unsigned)(((lane & 7) ^ (vrow & 7)) << 4);
+        kdst[j] = (unsigned)i * 1024u; vdst[j] = (unsigned)KT + (unsigned)i * 1024u;
+    }
+#define DMA16(voff_, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff_), "s"(sbase) : "memory", "m0")
+    auto issue_tile = [&](int tile, int slot) {                       // (cache regions are whole tiles: s_cap % 64 == 0, checked by the launcher)
+        const unsigned buf = lds_base + slot * BUF;
+        const unsigned tk = (unsigned)tile * 64u * k_ldb, tv = (unsigned)tile * 128u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            DMA16(koff[j] + tk, kbase, buf + __builtin_amdgcn_readfirstlane(kdst[j]));
+            DMA16(voff[j] + tv, vbase, buf + __builtin_amdgcn_readfirstlane(vdst[j]));
+        }
+    };
+#undef DMA16
+    const bool cw = wave < 4;                                         // compute wave
+    const int rw = wave & 1, kh = (wave >> 1) & 1;
+    const unsigned Rw0 = (unsigned)qtile * 64u + (unsigned)rw * 32u;
+    const unsigned R = Rw0 + (unsigned)c32;
+    const bool valid = R < nR && cw;
+    int tq, hq;
+    att_split_row(p, R < nR ? R : nR - 1, tq, hq);
+    // Order of the block's memory requests (everything by hand: any load hipcc tracks itself would make it wait with vmcnt(0), i.e. for all
+    // the DMA as well): 1. the block's FIRST tile, speculated as tile `split` of the shared prefix (true for every decode row set whose prefix
+    // has more than nsplit tiles) - requested before the plan is even read; 2. Q fragments + the three mask words of the lane's row;
+    // 3. the plan (two dependent scalar loads); 4. the remaining tiles.  Tile 0 is then computed under the flight of the others.
+    const int spec_tile = split;
+#ifdef DEC_NO_SPEC
+    const bool spec = false;
+#else
+    const bool spec = spec_tile * 64 < p.n_slots;
+#endif
+    if (spec) issue_tile(spec_tile, 0);
+    DEC_STAMP(1);
+    // Q rows and the row masks travel by LDS DMA like the tiles (2 + (wave 0: 3) instructions): EVERY input is then ordered by the hand-counted
+    // vmcnt waits, and hipcc sees LDS reads only.  (Plain loads written in asm were tried: hipcc may copy their destination registers before the
+    // hand-placed wait - it believes them defined at the asm statement - and the copies then hold stale data.)
+    {
+#define DMA16Q(voff_, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff_), "s"(sbase) : "memory", "m0")
+#define DMA4Q(voff_, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(voff_), "s"(sbase) : "memory", "m0")
+        const char* qbase = reinterpret_cast<const char*>(p.Q) + (int64_t)kvh * p.group * 256;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = wave * 2 + j;                               // packed rows 4i .. 4i+3 of the block's 64
+            const unsigned row = 4u * i + ((unsigned)lane >> 4);
+            unsigned Rr = (unsigned)qtile * 64u + row; Rr = Rr < nR ? Rr : nR - 1u;
+            const unsigned tu = p.group == 1 ? Rr : __umulhi(Rr, p.group_magic);
+            const unsigned off = tu * ((unsigned)p.q_ld * 2u) + (Rr - tu * (unsigned)p.group) * 256u + (unsigned)(((lane & 15) ^ skey(row & 15)) << 4);
+            DMA16Q(off, qbase, lds_base + QOFF + (unsigned)i * 1024u);
+        }
+        if (wave == 0) {
+            unsigned Rr = (unsigned)qtile * 64u + (unsigned)lane; Rr = Rr < nR ? Rr : nR - 1u;
+            const unsigned to = (p.group == 1 ? Rr : __umulhi(Rr, p.group_magic)) * 4u;
+            DMA4Q(to, p.pre, lds_base + MOFF);
+            DMA4Q(to, p.lo, lds_base + MOFF + 256);
+            DMA4Q(to, p.hi, lds_base + MOFF + 512);
+        }
+#undef DMA16Q
+#undef DMA4Q
+    }
+    DEC_STAMP(2);
+    const int plan_n = __builtin_amdgcn_readfirstlane(plan_w[NB]);
+    DEC_STAMP(3);
+    int n_my; TileRange tr{0, 0, 0};
+    bool spec_hit = false;
+    int first_late = 0;                                               // tiles requested after the plain loads (their DMA is younger than Q / masks)
+    if (plan_n >= 0) {
+        n_my = (split < plan_n) ? (plan_n - split + p.nsplit - 1) / p.nsplit : 0;
+        const int t0 = n_my > 0 ? __builtin_amdgcn_readfirstlane(plan_w[0]) : -1;
+        spec_hit = spec && t0 == spec_tile;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < n_my && !(j == 0 && spec_hit)) { issue_tile(__builtin_amdgcn_readfirstlane(plan_w[j]), j); ++first_late; }
+    } else {
+        // no plan for this step (tile list too long for a reader block): the block walks its contiguous tile ranges; needs the masks first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool v0 = valid && kh == 0;
+        const int* mk = reinterpret_cast<const int*>(dyn_lds + MOFF) + rw * 32 + c32;
+        const int pre_ = v0 ? mk[0] : 0, lo_ = v0 ? mk[64] : 1, hi_ = v0 ? mk[128] : 0;
+        int wmaxpre = pre_, wminlo = (v0 && hi_ >= lo_) ? lo_ : 0x7fffffff, wmaxhi = (v0 && hi_ >= lo_) ? hi_ : -1;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            wmaxpre = max(wmaxpre, __shfl_xor(wmaxpre, o, 64)); wminlo = min(wminlo, __shfl_xor(wminlo, o, 64)); wmaxhi = max(wmaxhi, __shfl_xor(wmaxhi, o, 64));
+        }
+        if (lane == 0 && wave < 2) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
+        __syncthreads();
+        tr = att_tile_range(max(lds_meta[0], lds_meta[3]), min(lds_meta[1], lds_meta[4]), max(lds_meta[2], lds_meta[5]), p.n_slots);
+        n_my = (split < tr.n_rel) ? (tr.n_rel - split + p.nsplit - 1) / p.nsplit : 0;
+        spec_hit = spec && n_my > 0 && att_tile_at(tr, split) == spec_tile;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < n_my && !(j == 0 && spec_hit)) { issue_tile(att_tile_at(tr, split + j * p.nsplit), j); ++first_late; }
+    }
+    DEC_STAMP(4);
+    const int pw0 = __builtin_amdgcn_readfirstlane(plan_w[0]), pw1 = __builtin_amdgcn_readfirstlane(plan_w[1]), pw2 = __builtin_amdgcn_readfirstlane(plan_w[2]),
+              pw3 = __builtin_amdgcn_readfirstlane(plan_w[3]);
+    auto dec_tile = [&](int i) -> int {      // tile id of the block's i-th tile (scalar selects: no register-relative indexing)
+        if (plan_n < 0) return att_tile_at(tr, split + i * p.nsplit);
+        return i == 0 ? pw0 : i == 1 ? pw1 : i == 2 ? pw2 : i == 3 ? pw3 : __builtin_amdgcn_readfirstlane(plan_blk[split + i * p.nsplit]);
+    };
+#define DEC_TILE(i) dec_tile(i)
+    f32x16_t acc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+    float m = NEG_INF, l = 0.f;
+    // Q, masks and (on a speculation hit) tile 0 have landed once only the late tiles' DMA is outstanding: 4 instructions per tile and wave
+    if (spec_hit) {
+        if (first_late >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (first_late == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (first_late == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DEC_STAMP(5);
+    __builtin_amdgcn_s_barrier();                                     // Q rows, masks (and tile 0) of every wave's DMA share are in LDS
+    asm volatile("" ::: "memory");
+    bf16x8_t qf[D / 16];
+    int pre, lo, hi;
+    {
+        const unsigned qa = lds_base + QOFF + (unsigned)(rw * 8192 + c32 * 256 + ((h ^ skey(c32 & 15)) << 4));
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *(const __attribute__((address_space(3))) bf16x8_t*)(uintptr_t)(qa ^ (ks * 32));
+        const int* mk = reinterpret_cast<const int*>(dyn_lds + MOFF) + rw * 32 + c32;
+        pre = mk[0]; lo = mk[64]; hi = mk[128];
+    }
+    if (!valid) { pre = 0; lo = 1; hi = 0; }
+    int landed = spec_hit ? 1 : (n_my < NB ? n_my : NB);             // tiles whose DMA (this wave's share) is known complete
+    const int first_batch = n_my < NB ? n_my : NB;                    // tiles requested before the loop
+
+    typedef const __attribute__((address_space(3))) bf16x8_t* lds_b128_t;
+    typedef const __attribute__((address_space(3))) u32x2_t* lds_b64_t;
+#define LDS_B128(addr) (*(lds_b128_t)(uintptr_t)(addr))
+#define LDS_B64(addr) (*(lds_b64_t)(uintptr_t)(addr))
+    const unsigned a_lane = (unsigned)(kh * 8192 + c32 * 256 + ((h ^ skey(c32 & 15)) << 4));      // K rows kh*32 + c32
+    // V^T A fragment of feature row d = db*32 + c32, 16-key chunk cc (of this wave's key half: chunks 2kh, 2kh+1): keys 4h..4h+3 (first 8 bytes)
+    // and 8+4h..8+4h+3 (second): byte cc*32 + 8h (+16) of the 128-byte row -> logical 16-byte chunk 2cc (+1), half h; physical = logical ^ (row & 7)
+    const unsigned v_lane = (unsigned)(c32 * 128 + 8 * h), v_key = (unsigned)((c32 & 7) << 4);
+
+    for (int it = 0; it < n_my; ++it) {
+        if (it >= landed) {                                           // this wave's share of tile `it`: wait until only younger tiles are outstanding
+            const int issued = it < first_batch ? first_batch : (it + NB - 2 < n_my ? it + NB - 1 : n_my);      // ring refills trail the loop by one tile
+            const int younger = issued - 1 - it;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed = it + 1;
+        }
+        if (it > 0) __builtin_amdgcn_s_barrier();                     // (tile 0: the barrier in front of the Q / mask reads already covered it)
+        asm volatile("" ::: "memory");
+        if (it < 3) DEC_STAMP(6 + it);
+        if (it >= 1 && it + NB - 1 < n_my) issue_tile(DEC_TILE(it + NB - 1), (it + NB - 1) % NB);
+        if (!cw) { continue; }
+        const int kv0 = DEC_TILE(it) * 64 + kh * 32;                  // first key of this wave's half tile
+        const unsigned kb_ = lds_base + (unsigned)(it % NB) * BUF;
+        // S^T[32 keys][32 rows]: all 8 K fragments requested up front, two accumulators (even / odd k-steps)
+        bf16x8_t kf[D / 16];
+        {
+            const unsigned xa = kb_ + a_lane;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) kf[ks] = LDS_B128(xa ^ (ks * 32));
+        }
+        f32x16_t cs, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cs[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ks += 2) {
+            cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], cs, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks + 1], qf[ks + 1], c1, 0, 0, 0);
+        }
+        // the V^T fragments of the wave's two 16-key chunks, requested under the QK MFMAs
+        bf16x8_t vf[8];
+        {
+            const unsigned va = kb_ + KT + v_lane;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {                             // n = chunk * 4 + feature block
+                const int cc = 2 * kh + (n >> 2), db = n & 3;
+                const unsigned ra = va + db * 4096;
+                vf[n] = make_frag(LDS_B64(ra + (((unsigned)(2 * cc) << 4) ^ v_key)), LDS_B64(ra + (((unsigned)(2 * cc + 1) << 4) ^ v_key)));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[r] += c1[r];
+        // does every row of the wave see all 32 keys (every prefix tile of a decode step)?  One compare chain + a ballot per tile - a wave
+        // reduction of the masks up front cost 15 dependent cross-lane steps (~1 us) in front of the first tile
+#ifdef DEC_NO_FULL
+        const bool full = false;
+#else
+        const bool full = (kv0 + 32 <= p.n_slots) && __all(!valid | (kv0 + 32 <= pre) | ((lo <= kv0) & (kv0 + 31 <= hi)));
+#endif
+        float mx = NEG_INF;
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cs[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre, lo, hi);
+                const float v = ok ? cs[r] : NEG_INF;
+                cs[r] = v; mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * p.scale_log2);
+        const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_safe);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[r], p.scale_log2, -m_safe));
+            cs[r] = e; rs += e;
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs; m = m_new;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
+        }
+        const bf16x8_t f0 = pack8(cs, 0), f1 = pack8(cs, 8);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[n], (n >> 2) ? f1 : f0, acc[n & 3], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef LDS_B128
+#undef LDS_B64
+#undef DEC_TILE
+    DEC_STAMP(9);
+    // merge the two key halves of every row (waves rw + 2 hand their running state to waves rw through LDS; ring slot 0 is free by now)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x4_t* xch = reinterpret_cast<f32x4_t*>(dyn_lds) + (size_t)rw * (17 * 64);      // [16 accumulator quads + (m, l)][64 lanes] per row half, 16 B per lane
+    if (cw && kh == 1) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xch[(db * 4 + i) * 64 + lane] = (f32x4_t){acc[db][4 * i], acc[db][4 * i + 1], acc[db][4 * i + 2], acc[db][4 * i + 3]};
+        xch[16 * 64 + lane] = (f32x4_t){m, l, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (valid && kh == 0) {
+        const f32x4_t ml = xch[16 * 64 + lane];
+        const float m2 = ml[0], l2 = ml[1];
+        const float M = fmaxf(m, m2), Ms = (M == NEG_INF) ? 0.f : M;
+        const float w1 = __builtin_amdgcn_exp2f(m - Ms), w2 = __builtin_amdgcn_exp2f(m2 - Ms);
+        const float L = l * w1 + l2 * w2;
+        // partials: O^T accumulators (fp32) + running (m, l), in the workspace layout attn_combine_kernel reads
+        const int64_t nRpad = (int64_t)gx * 64;
+        const int64_t slot = ((int64_t)split * gy + by) * nRpad + R;
+        float* op = p.Opart + slot * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4_t o2 = xch[(db * 4 + i) * 64 + lane];
+                f32x4_t v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[db][4 * i + j] * w1 + o2[j] * w2;
+                *reinterpret_cast<f32x4_t*>(op + db * 32 + 8 * i + 4 * h) = v;
+            }
+        if (h == 0) { p.mpart[slot] = M; p.lpart[slot] = L; }
+    }
+    DEC_STAMP(10);
+    DEC_FLUSH();
+}
+
+// launched by attn_fwd_impl (attn_fwd.hip) for plan_mode 2 launches at head dim 128; returns false when the shape does not qualify
+bool tr1_launch_attn_dec32(const AttnParams& p, dim3 grid, hipStream_t s) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("TR1_DEC32"); on = e ? atoi(e) : 1; }
+    if (!on || p.d_real != 128 || p.plan_mode != 2 || !p.plan || p.n_slots % 64 != 0) return false;
+    const uint64_t kbytes = (uint64_t)p.kv_batch_slots * (uint64_t)p.k_ld * 2ull, vbytes = (uint64_t)128 * (uint64_t)p.vt_ld * 2ull;
+    if (kbytes >= 0xffffffffull || vbytes >= 0xffffffffull || (uint64_t)p.n_slots * (uint64_t)p.k_ld * 2ull >= 0xffffffffull) return false;
+    const size_t dyn = 4 * (64 * 256 + 128 * 128) + 64 * 256 + 768 + 64;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); attr = true; }
+    hipLaunchKernelGGL(attn_dec32_kernel, grid, dim3(512), dyn, s, p);
+    return true;
+}
+
 // Q/O: [T, n_heads*128]; K, V: [n_slots, n_kv*128] row-major (any leading dims that are multiples of 8); lse (optional): fp32 [n_heads, T].
 extern "C" int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse,
                                  const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots,

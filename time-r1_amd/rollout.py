@@ -167,6 +167,7 @@ class Rollout:
         if timed:          # HIP events around the decode loop (read by the trainer's log(), never waited for here)
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
+        host_plan = ops.attn_plan(G, t.n_heads, t.n_kv_heads, B) if (not native and fused and hasattr(ops, "attn_plan")) else None
         for s in range(C - 1):
             if native:
                 ids_buf.copy_(tokens_all[:, s])
@@ -198,8 +199,13 @@ class Rollout:
                 if qkv is not None:
                     q = ops.decode_qkv_post(qkv, cs, sn, cache.k[i], cache.vt[i], abs_slots[s], t.n_heads, t.n_kv_heads, hd)
                 # one launch for all prompts of the window: problem b = rows [b*G,(b+1)*G) over cache slots [b*s_cap, (b+1)*s_cap)
+                # the per-step tile plan, exactly as the native step drives it (layer 0 publishes, the others read): both paths then run the
+                # same kernels and sample the same tokens
+                pk = {}
+                if host_plan is not None and nsplit > 1:
+                    pk = dict(plan=host_plan, plan_mode=1 if i == 0 else 2)
                 o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
-                                    nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap)
+                                    nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap, **pk)
                 if Q is not None:
                     h2 = ops.gemm_w8(o, Q["o.w"][0], Q["o.w"][1], residual=h, a8=a8)
                     a = ops.gemm_w8(h2, Q["gu.w"][0], Q["gu.w"][1], lnw=arena.w(p + "ln2"), eps=t.rms_eps, glu=True, a8=a8)
