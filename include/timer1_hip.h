@@ -49,6 +49,10 @@ int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const vo
  * roped q -> q_out[M, n_heads*hd]; roped k -> kcache[slots[m], :]; v -> vtcache[:, slots[m]].  Wqkv: [(n_heads + 2 n_kv)*hd, K] (q | k | v rows).
  * ref: Qwen2VLAttention.forward TF:521-556 + DynamicCache.update inside generate (timer1_trainer.py:568-573).  head_dim % 32 == 0. */
 int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* stream);
+/* The same launch for <= 16 decode rows on twice the blocks (two per rotate-half column-group pair, split over K, ticketed in-kernel fixup):
+ * bit-identical results, all 256 CUs streaming.  ws_f32: tr1_norm_gemm_qkv_split_workspace_floats() floats, zero-initialised once by the caller. */
+int tr1_norm_gemm_qkv_split(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* ws_f32, int64_t ws_floats, void* stream);
+int64_t tr1_norm_gemm_qkv_split_workspace_floats(int64_t n_heads, int64_t n_kv, int64_t head_dim);
 /* Narrow decode projections (o_proj / down_proj at M <= 64 rows): C = A B^T (+bias)(+residual) with cross-block split-K and an in-kernel
  * fixup (the last block of a column group sums the fp32 partial tiles).  ws_f32: tr1_gemm_skinny_fixup_workspace_floats() floats whose
  * trailing ticket counters must be ZERO before the first call (the kernel re-arms them).  Same call sites as tr1_gemm_nt_bf16 in generate. */

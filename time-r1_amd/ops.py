@@ -145,6 +145,15 @@ class HipOps:
         assert slots.dtype == I32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (R, head_dim // 2) and cos.dtype == F32
         assert wqkv.shape == ((n_heads + 2 * n_kv) * head_dim, K) and x.stride(1) == 1 and wqkv.stride(1) == 1
         q = self.empty(R, n_heads * head_dim)
+        if R <= 16 and K >= 512 and os.environ.get("TR1_QKV_SPLIT", "0") == "1":      # two blocks per column-group pair (bit-identical; measured slower, see csrc/decode.hip)
+            nws = self.L.raw("tr1_norm_gemm_qkv_split_workspace_floats")(n_heads, n_kv, head_dim)
+            key = ("qkv_split", n_heads, n_kv, head_dim)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.zeros(nws, dtype=F32, device=self.device)      # zero ONCE: the ticket counters start disarmed
+            self.L.call("tr1_norm_gemm_qkv_split", _p(x), _p(lnw), _p(wqkv), _p(bias), _p(cos), _p(sin), _p(q), _ld(q), _p(kcache), _ld(kcache), _p(vtcache),
+                        _ld(vtcache), _p(slots), R, n_heads, n_kv, head_dim, K, x.stride(0), wqkv.stride(0), float(eps), _p(ws), nws, self._s())
+            return q
         self.L.call("tr1_norm_gemm_qkv", _p(x), _p(lnw), _p(wqkv), _p(bias), _p(cos), _p(sin), _p(q), _ld(q), _p(kcache), _ld(kcache), _p(vtcache),
                     _ld(vtcache), _p(slots), R, n_heads, n_kv, head_dim, K, x.stride(0), wqkv.stride(0), float(eps), self._s())
         return q
