@@ -630,6 +630,19 @@ def test_norm_gemm_qkv_fused(hip_ops, ref_ops, R, nh, nkv, hd, K):
     slots = torch.randperm(S, generator=torch.Generator().manual_seed(6))[:R].int()
     kc0, vt0 = rnd(S, nkv * hd, seed=7), rnd(nkv * hd, S, seed=8)
     outs = []
+    if R <= 16 and K >= 512:      # the two-blocks-per-pair form with the ticket fixup (TR1_QKV_SPLIT=1): bit-identical to the one-block launch, twice in a row
+        import os                 # (the second launch runs on the re-armed ticket counters)
+        plain = []
+        for flag in ("0", "1", "1"):
+            os.environ["TR1_QKV_SPLIT"] = flag
+            try:
+                kc, vt = kc0.clone().cuda(), vt0.clone().cuda()
+                q = hip_ops.norm_gemm_qkv(x.cuda(), lnw.cuda(), 1e-6, w.cuda(), b.cuda(), cos, sin, kc, vt, slots.cuda(), nh, nkv, hd)
+                plain.append((q.cpu(), kc.cpu(), vt.cpu()))
+            finally:
+                os.environ.pop("TR1_QKV_SPLIT", None)
+        for other in plain[1:]:
+            assert all(torch.equal(a, b_) for a, b_ in zip(plain[0], other)), "split-K fused QKV must equal the one-block form bit for bit"
     for fused in (True, False):
         kc, vt = kc0.clone().cuda(), vt0.clone().cuda()
         if fused:
