@@ -41,6 +41,10 @@ int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N
 /* Weight gradient without the X^T copy: C[M,N] fp32 (+)= A[M,K] B[K,N], B K-major with only its first b_rows rows valid (A = dY^T zero-padded to
  * K = tokens rounded up to 64, B = the saved activation as stored).  ref: autograd of nn.Linear inside HF Trainer.training_step (TF trainer.py:1892-1961). */
 int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int64_t b_rows, void* stream);
+/* Weight gradient with BOTH operands as the backward pass holds them (no dY^T, no X^T): C[N,K] fp32 (+)= dY[T,N]^T X[T,K], dY / X row-major bf16
+ * (token = row).  N, K multiples of 256; T * ld * 2 < 4 GiB.  ref: grad_weight = grad_output^T @ input of every nn.Linear under loss.backward()
+ * (src/time_r1/rl/timer1_trainer.py:709 -> HF Trainer.training_step, TF trainer.py:1892-1961). */
+int tr1_gemm_tn_acc_f32(const void* dY, const void* X, void* C_f32, int64_t T, int64_t N, int64_t K, int64_t ldp, int64_t ldq, int64_t ldc, int accumulate, void* stream);
 /* Decode-step fusion (M <= 64 rows): out = rmsnorm(x; lnw, eps) @ W[N,K]^T (+ bias), the norm folded into the GEMM's operand load
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
  * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */
@@ -168,6 +172,11 @@ int64_t tr1_decode_step_workspace_bytes(const int64_t* dims);
 int tr1_decode_step_w8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 /* Same step, every projection through tr1_gemm_skinny_w8a8 (fp8 MFMA). */
 int tr1_decode_step_w8a8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
+/* Measurement helpers (bench.py `roofline`): between begin and end every tr1_decode_step* call records a pair of HIP events on its
+ * stream around each projection GEMM it launches (families 0 qkv, 1 o, 2 gate/up, 3 down, 4 lm_head).  end() synchronises those events and
+ * writes, per family, the summed and the minimum launch duration in ms and the number of launches (host arrays of 5).  Not thread-safe. */
+int tr1_decode_profile_begin(void);
+int tr1_decode_profile_end(double* ms_by_family, double* min_ms_by_family, int64_t* launches_by_family);
 
 /* ---- video preprocessing (SURVEY 8f "next" row 1) ------------------------------------------------------------------------ */
 /* ref: torchvision resize(BICUBIC, antialias) at src/utils/vision_process.py:467-472 + Qwen2VLVideoProcessor rescale/normalize/patchify

@@ -670,3 +670,36 @@ def test_gemm_nn(hip_ops, M, N, K):
     close(got, ref.cpu(), 0.03, rtol=0.02, what="gemm_nn")
     nt = hip_ops.gemm_nt(a, b.t().contiguous())
     assert torch.equal(got, nt), "NN and NT forms accumulate in the same order"
+
+
+@pytest.mark.parametrize("T", [5, 32, 77, 160])
+@pytest.mark.parametrize("nbt", ["2", "4"])
+def test_wgrad_tn_matches_fp32_reference(T, nbt):
+    """csrc/gemm_tn.hip (opt-in TR1_WGRAD_TN=1): dY^T X with both operands as stored against an fp32 matmul of the same bf16 inputs (tolerance 2e-5 of
+    the largest entry: fp32 accumulation order only), overwrite and accumulate, partial last token tile, strided operand views, refusal of uncovered shapes.
+    The wave layout (TR1_TN_NBT) is read once per process, hence the subprocess."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import torch, sys
+        sys.path.insert(0, %r)
+        import time_r1_amd
+        from time_r1_amd.ops import HipOps
+        ops = HipOps("cuda:0")
+        T = %d
+        g = torch.Generator().manual_seed(T)
+        big = (torch.randn(T, 1024 + 512, generator=g) * 0.1).bfloat16()
+        ref = big[:, :512].float().t() @ big[:, 512:1280].float()
+        big = big.cuda()
+        dy, x = big[:, :512], big[:, 512:1280]                    # strided views, N = 512, K = 768
+        gw = torch.full((512, 768), 7.0, device="cuda")
+        assert ops.wgrad_tn(dy, x, gw, False)
+        tol = 2e-5 * ref.abs().max().item() + 1e-12
+        assert (gw.cpu() - ref).abs().max().item() <= tol, (gw.cpu() - ref).abs().max().item()
+        assert ops.wgrad_tn(dy, x, gw, True)
+        assert (gw.cpu() - 2 * ref).abs().max().item() <= 2 * tol
+        assert not ops.wgrad_tn(dy[:, :384], x, gw[:384], False)      # N not a multiple of 256: the caller falls back
+        print("ok")
+    """) % (root, T)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TR1_TN_NBT=nbt), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

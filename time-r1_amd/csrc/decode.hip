@@ -10,7 +10,26 @@
 #include "tr1_common.h"
 #include "../../include/timer1_hip.h"
 
+#include <vector>
+
 namespace {
+// ---- optional per-launch timing of the decode GEMM families (bench.py roofline): HIP events recorded by THIS driver around each GEMM launch,
+// i.e. with the launches back to back as in the timed region (events recorded from the host language bracket ~20 us of interpreter time per
+// launch, during which the stream idles - the round-2 bench line was conservative for that reason).  Off unless tr1_decode_profile_begin().
+struct DecProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev[5];        // families: 0 qkv, 1 o, 2 gate/up, 3 down, 4 lm_head; events in (start, stop) pairs
+};
+DecProf g_prof;
+struct ProfScope {
+    int fam; hipStream_t s; bool on;
+    ProfScope(int f, void* stream) : fam(f), s((hipStream_t)stream), on(g_prof.on) {
+        if (on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s); g_prof.ev[fam].push_back(e); }
+    }
+    ~ProfScope() {
+        if (on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s); g_prof.ev[fam].push_back(e); }
+    }
+};
 struct Carve {
     char* p; size_t left; bool ok = true;
     void* take(size_t bytes) {
@@ -84,9 +103,11 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
             CK(gemm8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
         } else if (use_qsp) {
+            ProfScope ps(0, stream);
             CK(tr1_norm_gemm_qkv_split(h, w[0], w[1], w[2], cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, hid, hid, hid,
                                        eps, qsp, qsp_floats, stream));
         } else if (hd % 32 == 0) {      // norm + q/k/v projection + M-RoPE + KV append in one launch
+            ProfScope ps(0, stream);
             CK(tr1_norm_gemm_qkv(h, w[0], w[1], w[2], cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, hid, hid, hid,
                                  eps, stream));
         } else {
@@ -95,18 +116,56 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
         }
         CK(tr1_attn_fwd_planned(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
                                 scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
-        if (w8) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
-        else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
-        if (w8) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
-        else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
+        {
+            ProfScope ps(1, stream);
+            if (w8) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
+            else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
+        }
+        {
+            ProfScope ps(2, stream);
+            if (w8) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
+            else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
+        }
+        ProfScope ps3(3, stream);
         if (w8 == 2 && down_fixup8) CK(tr1_gemm_skinny_fixup_w8a8(a, w[6], w[12], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else if (w8) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
         else if (down_fixup) CK(tr1_gemm_skinny_fixup(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
     }
-    if (w8) CK(gemm8(h, final_norm, lm_head, lm_head_scale, nullptr, nullptr, logits, R, V, hid, hid, hid, V, 0, eps, 0, stream));
-    else CK(tr1_norm_gemm_skinny(h, final_norm, lm_head, nullptr, logits, R, V, hid, hid, hid, V, eps, 0, stream));
+    {
+        ProfScope ps(4, stream);
+        if (w8) CK(gemm8(h, final_norm, lm_head, lm_head_scale, nullptr, nullptr, logits, R, V, hid, hid, hid, V, 0, eps, 0, stream));
+        else CK(tr1_norm_gemm_skinny(h, final_norm, lm_head, nullptr, logits, R, V, hid, hid, hid, V, eps, 0, stream));
+    }
 #undef CK
+    return 0;
+}
+
+// Measurement helpers (bench.py `roofline`): between begin and end every decode step records HIP events around its GEMM launches.
+// end() synchronises, writes per family (qkv, o, gate/up, down, lm_head) the summed and minimum milliseconds and the launch count, frees the events.
+extern "C" int tr1_decode_profile_begin(void) {
+    for (auto& v : g_prof.ev) { for (auto e : v) hipEventDestroy(e); v.clear(); }
+    g_prof.on = true;
+    return 0;
+}
+extern "C" int tr1_decode_profile_end(double* ms_by_family, double* min_ms_by_family, int64_t* launches_by_family) {
+    g_prof.on = false;
+    for (int f = 0; f < 5; ++f) {
+        double ms = 0.0, mn = 0.0;
+        auto& v = g_prof.ev[f];
+        for (size_t i = 0; i + 1 < v.size(); i += 2) {
+            hipEventSynchronize(v[i + 1]);
+            float t = 0.f;
+            hipEventElapsedTime(&t, v[i], v[i + 1]);
+            ms += t;
+            if (i == 0 || t < mn) mn = t;
+        }
+        if (ms_by_family) ms_by_family[f] = ms;
+        if (min_ms_by_family) min_ms_by_family[f] = mn;
+        if (launches_by_family) launches_by_family[f] = (int64_t)(v.size() / 2);
+        for (auto e : v) hipEventDestroy(e);
+        v.clear();
+    }
     return 0;
 }
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TR1_HIP_LIB") or os.path.join(_HERE, "lib", "libtimer
 _CT = {
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
     "int64_t*": ctypes.POINTER(ctypes.c_int64), "const int64_t*": ctypes.POINTER(ctypes.c_int64), "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "int": ctypes.c_int,
-    "float": ctypes.c_float,
+    "float": ctypes.c_float, "double*": ctypes.POINTER(ctypes.c_double),
 }
 
 

@@ -35,6 +35,7 @@ class Engine:
         self._gw_ver = {}
         self.fused_head = os.environ.get("TR1_FUSED_HEAD", "1") != "0"    # lm_head -> logp / entropy in the GEMM epilogue where the logits are not kept
         self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
+        self.wgrad_tn = os.environ.get("TR1_WGRAD_TN", "0") == "1"      # ... and dy as stored too (round 3, csrc/gemm_tn.hip): measured, NOT adopted
         self._side = None
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
@@ -44,13 +45,19 @@ class Engine:
         version changed) overwrites gw instead of accumulating - AdamW left it at zero, so the result is identical and the GEMM epilogue skips
         reading 4 bytes per parameter (33 GB per accumulation window at 7B)."""
         ops = self.ops
-        dyt = ops.transpose(dy)          # [N, Mp], zero-padded columns
         acc = True
         if key is not None and self.wgrad_overwrite_first:
             ver = getattr(self.params.train, "version", None)
             if ver is not None and self._gw_ver.get(key) != ver:
                 self._gw_ver[key] = ver
                 acc = False
+        # TR1_WGRAD_TN=1: both operands as stored (round 3, csrc/gemm_tn.hip) - no dy^T / x^T copies at all where N and K are multiples of 256.
+        # Off by default: the transposing LDS reads on BOTH operands hold that GEMM at 0.83-0.9 x the NT kernel's rate, and the copies it saves
+        # cost 7 ms of the 154 ms backward (measured with stale non-zero copies), so the backward came out 6 ms SLOWER (DESIGN.md).
+        tn = getattr(ops, "wgrad_tn", None)
+        if tn is not None and self.wgrad_tn and tn(dy, x, gw, acc):
+            return
+        dyt = ops.transpose(dy)          # [N, Mp], zero-padded columns
         # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out).
         # Its transposing LDS reads cost 8-17 % of the GEMM rate (tools/bench_wgrad.py: 1060 against 1244 TFLOP/s at the down-projection
         # shape), so it only pays where the saved transpose is the larger piece: x at least twice as wide as dy (the down projection,

@@ -53,6 +53,17 @@ class HipOps:
         """Measurement helper: one streaming read of `buf` (bench.py times it)."""
         self.L.call("tr1_probe_hbm_read", _p(buf), buf.numel() * buf.element_size(), _p(sink), self._s())
 
+    def decode_profile_begin(self):
+        """Measurement helper: native decode steps record HIP events around their projection GEMMs until decode_profile_end()."""
+        self.L.call("tr1_decode_profile_begin")
+
+    def decode_profile_end(self):
+        """-> {family: (sum_ms, min_ms, launches)} for qkv / o / gate_up / down / lm_head since decode_profile_begin()."""
+        import ctypes
+        ms, mn, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+        self.L.call("tr1_decode_profile_end", ms, mn, n)
+        return {k: (ms[i], mn[i], int(n[i])) for i, k in enumerate(("qkv", "o", "gate_up", "down", "lm_head"))}
+
     # ---- memory helpers -------------------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.act_dtype, device=self.device)
@@ -112,6 +123,19 @@ class HipOps:
         self._chk(dyt, x)
         assert gw.dtype == F32 and gw.shape == (N, K)
         self.L.call("tr1_gemm_nn_acc_f32", _p(dyt), _p(x), _p(gw), N, K, Mp, _ld(dyt), _ld(x), _ld(gw), int(accumulate), M, self._s())
+        return True
+
+    def wgrad_tn(self, dy, x, gw, accumulate):
+        """gw[N,K] fp32 (+)= dy[T,N]^T @ x[T,K], both operands as stored (csrc/gemm_tn.hip).  Returns False when the shape is not covered (the caller
+        then falls back to the transposed-copy forms)."""
+        T, N = dy.shape
+        K = x.shape[1]
+        if not (x.shape[0] == T and N % 256 == 0 and K % 256 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+                and T * max(dy.stride(0), x.stride(0)) * 2 < 0xffffffff and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+            return False
+        self._chk(dy, x)
+        assert gw.dtype == F32 and gw.shape == (N, K) and gw.stride(1) == 1
+        self.L.call("tr1_gemm_tn_acc_f32", _p(dy), _p(x), _p(gw), T, N, K, _ld(dy), _ld(x), _ld(gw), int(accumulate), self._s())
         return True
 
     def gemm_nt(self, a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
