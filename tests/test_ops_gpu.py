@@ -374,7 +374,8 @@ def test_adamw_and_clip(hip_ops, ref_ops):
     close(st_h[0], pt.detach(), 1e-6, rtol=1e-5, what="adamw vs torch.optim.AdamW")
 
 
-@pytest.mark.parametrize("R,V,K", [(48, 512, 128), (300, 1024, 256), (7, 256, 64), (1600, 152064, 3584)])
+@pytest.mark.parametrize("R,V,K", [(48, 512, 128), (300, 1024, 256), (7, 256, 64), (1600, 152064, 3584),
+                                   (64, 320, 128), (33, 448, 64), (1600, 151936, 1536)])       # V % 256 != 0: the 2B vocabulary (151936 = 593.5 x 256)
 def test_lmhead_lse_fused_epilogue(hip_ops, ref_ops, R, V, K):
     """lm_head with the log-softmax statistics reduced in the GEMM epilogue (no [R, V] logits in HBM) == the materialised path
     (GEMM -> bf16 logits -> one-pass logp / entropy kernel), and == the oracle at sizes it runs in seconds."""

@@ -296,7 +296,8 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                         te += __shfl_xor(te, 1, 64); te += __shfl_xor(te, 2, 64); te += __shfl_xor(te, 4, 64);
                         if (m < M) {
                             f32x4_t* prow = reinterpret_cast<f32x4_t*>(Cv) + m * ldc;
-                            if (c8 == 0) prow[ncol0 >> 6] = (f32x4_t){mx, se, te, 0.f};
+                            if (c8 == 0 && ncol0 < N) prow[ncol0 >> 6] = (f32x4_t){mx, se, te, 0.f};   // a wave's 64-column slice past N (N % 256 != 0) has no slot:
+                            //                                                                            slot N/64 is the target logit, N/64 + 1 the next row
                             if (ok && tg >= n && tg < n + 8) reinterpret_cast<float*>(prow + (ldc - 1))[0] = v[tg - n];
                         }
                         continue;

@@ -1,0 +1,32 @@
+"""Round 3: do the LDS-streamed decode GEMMs (gate/up, down projection) run faster when their weights are already in the 256 MB Infinity Cache?
+cold = rotating HBM-resident copies, warm = the same (<= 136 MB) weight every launch."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time_r1_amd  # noqa
+from time_r1_amd.ops import HipOps
+ops = HipOps("cuda:0")
+BF = torch.bfloat16
+rnd = lambda *s: (torch.randn(*s, device="cuda") * 0.05).to(BF)
+def timeit(f, reps=100):
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+M = 16
+x = rnd(M, 3584); lnw = rnd(3584); a = rnd(M, 18944); h = rnd(M, 3584)
+for name, mk, call, mb in (
+    ("down 3584x18944 (LDS fixup)", lambda: rnd(3584, 18944), lambda w: ops.gemm_skinny_fixup(a, w, residual=h), 135.8),
+    ("gate/up HALF 18944x3584 (glu LDS)", lambda: rnd(18944, 3584), lambda w: ops.norm_gemm(x, lnw, 1e-6, w, glu=True), 135.8),
+    ("qkv-size 4608x3584 (norm_gemm)", lambda: rnd(4608, 3584), lambda w: ops.norm_gemm(x, lnw, 1e-6, w), 33.0),
+    ("o-size 3584x3584 (gemm_nt)", lambda: rnd(3584, 3584), lambda w: ops.gemm_nt(x, w, residual=h), 25.7)):
+    ws = [mk() for _ in range(10)]
+    i = [0]
+    def cold():
+        call(ws[i[0] % len(ws)]); i[0] += 1
+    def warm():
+        call(ws[0])
+    tc, tw = timeit(cold), timeit(warm)
+    print("%-36s cold %6.1f us (%5.0f GB/s)   warm %6.1f us (%5.0f GB/s)" % (name, tc, mb / tc * 1e3, tw, mb / tw * 1e3), flush=True)
