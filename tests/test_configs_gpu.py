@@ -83,6 +83,18 @@ def test_config2_full_width_2b_tied_head_vs_oracle(hip_ops, ref_ops):
             st.completion_ids = toks.clone()
         core.forward_logps(st)
         if name == "hip":
+            # reference-policy path (beta != 0) with the reference arena = the policy's own weights: the full forward + FUSED lm_head epilogue
+            # (no logits kept; V = 151936 is not a multiple of the 256-column GEMM tile) must reproduce the policy's log-probs
+            core.beta, core.ref_arena = 0.04, params.train
+            lp_policy = st.logp.float().clone()
+            st_r = core.prepare(ids, pix, g)
+            st_r.layout, st_r.completion_ids = st.layout, st.completion_ids
+            core.forward_logps(st_r)
+            assert torch.isfinite(st_r.ref_logp).all(), "reference log-probs through the fused head must be finite"
+            # (the policy's log-probs came from the prefill-continuation forward: a bf16 logit may differ by one ulp = 0.0156 at |x| < 4)
+            assert float((st_r.ref_logp.float() - lp_policy).abs().max()) < 0.04, float((st_r.ref_logp.float() - lp_policy).abs().max())
+            assert float((st_r.ref_logp.float() - lp_policy).abs().mean()) < 0.01
+            core.beta, core.ref_arena = 0.0, None
             # decode kernels (2B shapes: hidden 1536, 2 kv heads, tied lm_head over V = 151936) vs the training forward, per decode step
             hl = st.head_ctx["logits"].float()
             scale = float(hl.abs().max())
