@@ -9,6 +9,9 @@
 // the source address with skey().  32 MFMAs per wave and tile against 16 b128 + 32 transposing LDS reads.
 #include "attn_common.h"
 #include <stdlib.h>
+#ifndef TR1_ABL
+#define TR1_ABL 0        // timing-ablation bits for the forward loop (tools/build_variant.py <name> -DTR1_ABL=<bits>; results are WRONG by design):
+#endif                   // 1 no exp2, 2 no PV MFMAs, 4 no S MFMAs, 8 no per-tile barrier
 
 __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE;
@@ -105,7 +108,9 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#if !(TR1_ABL & 8)
         __builtin_amdgcn_s_barrier();                                 // tile `it` is complete for everybody; everybody is done with tile it-1
+#endif
         asm volatile("" ::: "memory");
         if (it + NB - 1 < n_my) issue_tile(att_tile_at(tr, it + NB - 1), (it + NB - 1) % NB);
         const int kv0 = att_tile_at(tr, it) * 64;
@@ -126,8 +131,12 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
                     if (ks + AH < D / 16) { k0[(ks + AH) % (AH + 1)] = LDS_B128(xa ^ ((ks + AH) * 32)); k1[(ks + AH) % (AH + 1)] = LDS_B128((xa ^ ((ks + AH) * 32)) + 8192); }
+#if !(TR1_ABL & 4)
                     cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0[ks % (AH + 1)], qf[ks], cs[0], 0, 0, 0);
                     cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1[ks % (AH + 1)], qf[ks], cs[1], 0, 0, 0);
+#else
+                    cs[0][ks] += bf2f((bf16_t)k0[ks % (AH + 1)][0]); cs[1][ks] += bf2f((bf16_t)k1[ks % (AH + 1)][0]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -158,7 +167,11 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if !(TR1_ABL & 1)
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[kb][r], p.scale_log2, -m_safe));
+#else
+                    const float e = __builtin_fmaf(cs[kb][r], p.scale_log2, -m_safe);
+#endif
                     cs[kb][r] = e; rs += e;
                 }
             rs += __shfl_xor(rs, 32, 64);
@@ -180,7 +193,11 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             for (int n = 0; n < 16; ++n) {                            // n = chunk (16 keys) * 4 + feature block
                 if (n + TH < 16) a[(n + TH) % (TH + 1)] = P2_LD(n + TH);
                 const bf16x8_t f = pack8(cs[n >> 3], ((n >> 2) & 1) * 8);
+#if !(TR1_ABL & 2)
                 acc[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n % (TH + 1)], f, acc[n & 3], 0, 0, 0);
+#else
+                acc[n & 3][n] += bf2f((bf16_t)a[n % (TH + 1)][0]) * bf2f((bf16_t)f[0]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef P2_LD
