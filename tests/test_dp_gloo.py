@@ -207,26 +207,28 @@ def _worker_train4(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_four_ranks_dataset_not_divisible_by_world():
-    """4 ranks over gloo, len(dataset) % world != 0, default (sharded) optimizer, the product's rendezvous with its
-    explicit timeout: every rank takes the same number of optimizer steps (no dead-lock in the exchange), ends with identical weights,
-    and the start-up diagnostics see all four ranks."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_ranks_dataset_not_divisible_by_world(world):
+    """4 (and 8: the driver's scaling run) ranks over gloo, len(dataset) % world != 0, default (sharded) optimizer, the
+    product's rendezvous with its explicit timeout: every rank takes the same number of optimizer steps (no dead-lock in the exchange), ends
+    with identical weights, and the start-up diagnostics see every rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_worker_train4, args=(r, 4, port, q)) for r in range(4)]
+    procs = [ctx.Process(target=_worker_train4, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(4)], key=lambda x: x[0])
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[2] for r in res] == [2, 2, 2, 2]
+    steps = 2 if world == 4 else 1               # 5 rows wrap to 8: 2 batches per rank at 4 ranks (GA = 1 each), 1 at 8
+    assert [r[2] for r in res] == [steps] * world, [r[2] for r in res]
     for r in res[1:]:
         assert (r[1] == res[0][1]).all(), "ranks must hold identical bf16 weights after the all-gather"
         assert r[4] == res[0][4]                   # gathered metric means agree on every rank
     d = res[0][3]
-    assert d["backend"] == "gloo" and d["world"] == 4 and d["ranks_seen"] == [0, 1, 2, 3] and d["ranks_seen_ok"] and len(d["devices"]) == 4
+    assert d["backend"] == "gloo" and d["world"] == world and d["ranks_seen"] == list(range(world)) and d["ranks_seen_ok"] and len(d["devices"]) == world

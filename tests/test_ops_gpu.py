@@ -704,3 +704,39 @@ def test_wgrad_tn_matches_fp32_reference(T, nbt):
     """) % (root, T)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TR1_TN_NBT=nbt), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_down_projection_56_column_blocks_bit_identical(tmp_path):
+    """Round 3: the LDS-streamed split-K down projection on 56-column blocks (64 x 4 = 256 blocks at N = 3584: every CU) stores exactly the bits of the
+    64-column form (TR1_DOWN_COLS=64: 224 blocks) - same K-slabs, same per-wave stage order, same ordered fixup; also with residual and < 16 rows.
+    The block shape is read once per process, hence the subprocesses."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import torch, sys
+        sys.path.insert(0, %r)
+        import time_r1_amd
+        from time_r1_amd.ops import HipOps
+        ops = HipOps("cuda:0")
+        g = torch.Generator().manual_seed(11)
+        w = (torch.randn(3584, 18944, generator=g) * 0.02).bfloat16().cuda()
+        outs = []
+        for M in (16, 9, 1):
+            a = (torch.randn(M, 18944, generator=g) * 0.5).bfloat16().cuda()
+            h = torch.randn(M, 3584, generator=g).bfloat16().cuda()
+            for _ in range(2):                                   # second call: the ticket counters were re-armed by the first
+                outs.append(ops.gemm_skinny_fixup(a, w, residual=h).cpu())
+            outs.append(ops.gemm_skinny_fixup(a, w).cpu())
+            ref = (a.float() @ w.float().t() + h.float()).cpu()
+            assert (outs[-3].float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
+        torch.save(outs, sys.argv[1])
+        print("ok")
+    """) % root
+    files = []
+    for cols in ("56", "64"):
+        f = str(tmp_path / ("down_%s.pt" % cols))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, TR1_DOWN_COLS=cols), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+        files.append(torch.load(f))
+    for a, b in zip(*files):
+        assert torch.equal(a, b)

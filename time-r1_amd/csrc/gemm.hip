@@ -1616,7 +1616,10 @@ extern "C" int tr1_lmhead_lse_fwd(const void* hn, const void* W, const void* tar
 // the 16 x 64 activation stages travel HBM/L2 -> LDS as full 128-byte row runs (global_load_lds), each wave has its own two-slot ring and
 // takes the slab's 64-wide stages round-robin, so the only ordering in the stream is the issuing wave's counted vmcnt.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WAVES, int MG = 1>
+// NWI = weight DMA instructions (8 rows each) per stage: 8 = 64-column blocks; 7 = 56-column blocks (round 3): 3584 columns are then 64 groups, and
+// 64 x 4 K-slabs fill all 256 CUs (56 x 4 = 224 left 32 of them idle).  The MFMAs still run on four 16-row weight tiles - rows 56..63 of a stage are
+// never written and only feed the eight output columns that are not stored - so every stored value is the same sum in the same order as with NWI = 8.
+template <int WAVES, int MG = 1, int NWI = 8>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int M,
                                                                          int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr,
@@ -1626,15 +1629,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // [WAVES][2][STAGE]; afterwards red[WAVES][NC][MG][16][17] f32; ticket at the end
     int* s_ticket = reinterpret_cast<int*>(sk_lds + WAVES * 2 * STAGE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * (16 * NC);
+    constexpr int COLS = NWI * 8;                                           // output columns a block owns
+    const int64_t n0 = (int64_t)blockIdx.x * COLS;
     const int64_t kslab = K / gridDim.y, k0 = (int64_t)blockIdx.y * kslab;
     const int nst = (int)(kslab / 64);
     const int n_my = wave < nst ? (nst - wave + WAVES - 1) / WAVES : 0;       // stages wave, wave + WAVES, ...
     char* ring = sk_lds + wave * 2 * STAGE;
     // DMA lane map (8 rows x 128 bytes per instruction): lane -> row 8j + (lane >> 3), physical chunk lane & 7, logical chunk ^ keyA(row)
-    const bf16_t* pw[8]; const bf16_t* px[2 * MG];
+    const bf16_t* pw[NWI]; const bf16_t* px[2 * MG];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NWI; ++j) {
         const int r = 8 * j + (lane >> 3);
         int64_t row = n0 + r; if (row >= N) row = N - 1;
         pw[j] = W + row * ldw + k0 + (int64_t)wave * 64 + (((lane & 7) ^ keyA(r)) << 3);
@@ -1646,7 +1650,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     }
 #define SKL_ISSUE(SLOT) do {                                                                                              \
         char* dst__ = ring + (SLOT) * STAGE;                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)pw[j], (lptr_t)(dst__ + j * 1024), 16, 0, TR1_W_AUX); pw[j] += WAVES * 64; } \
+        _Pragma("unroll") for (int j = 0; j < NWI; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)pw[j], (lptr_t)(dst__ + j * 1024), 16, 0, TR1_W_AUX); pw[j] += WAVES * 64; } \
         _Pragma("unroll") for (int j = 0; j < 2 * MG; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)px[j], (lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 64; } \
     } while (0)
     f32x4_t acc[NC][MG][2];
@@ -1671,10 +1675,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     } while (0)
     if (n_my > 0) SKL_ISSUE(0);
     for (int i = 0; i < n_my; i += 2) {
-        if (i + 1 < n_my) { SKL_ISSUE(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * MG) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i + 1 < n_my) { SKL_ISSUE(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWI + 2 * MG) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SKL_CONSUME(0);
         if (i + 1 < n_my) {
-            if (i + 2 < n_my) { SKL_ISSUE(0); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * MG) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (i + 2 < n_my) { SKL_ISSUE(0); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWI + 2 * MG) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             SKL_CONSUME(1);
         }
     }
@@ -1709,7 +1713,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
         float v = 0.f;
         for (int ks = 0; ks < (int)gridDim.y; ++ks)
             v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (mm < M && n < N) {
+        if (mm < M && n < N && c * 16 + nn < COLS) {
             if (bias) v += bf2f(bias[n]);
             if (residual) v += bf2f(residual[(int64_t)mm * ldr + n]);
             C[(int64_t)mm * ldc + n] = f2bf(v);
@@ -1727,12 +1731,21 @@ static int skinny_fix_cfg(int64_t M, int64_t N, int64_t K, int* ncol, int* mg) {
     return K >= 2048 ? 4 : 1;
 }
 
+// 56-column blocks for the LDS-streamed <= 16-row form when that is what fills the chip: N % 56 == 0 and N/56 x ks <= 256 < more blocks than N/64 x ks
+// (7B down projection: 64 x 4 = 256 blocks instead of 56 x 4 = 224).  TR1_DOWN_COLS=64 keeps the 64-column blocks (A/B measurements).
+static bool skinny_fix_cols56(int64_t N, int ks, int ncol, int mg) {
+    static int cols = -1;
+    if (cols < 0) { const char* e = getenv("TR1_DOWN_COLS"); cols = e ? atoi(e) : 56; }
+    return cols == 56 && mg == 1 && ncol == 4 && ks > 1 && N % 56 == 0 && (N / 56) * ks <= 256 && (N / 56) > (N + 63) / 64;
+}
+
 extern "C" int64_t tr1_gemm_skinny_fixup_workspace_floats(int64_t M, int64_t N, int64_t K) {
     // fp32 tiles [ksplit][column groups][NCOL*MG*256] followed by one int32 ticket counter per column group (zero-initialised ONCE by
     // the caller; the kernel re-arms them)
     int ncol, mg;
     const int ks = skinny_fix_cfg(M, N, K, &ncol, &mg);
-    const int64_t groups = (N + 16 * ncol - 1) / (16 * ncol);
+    int64_t groups = (N + 16 * ncol - 1) / (16 * ncol);
+    if (skinny_fix_cols56(N, ks, ncol, mg)) groups = N / 56;
     return ks * groups * ncol * mg * 256 + groups;
 }
 
@@ -1743,7 +1756,10 @@ extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, cons
     TR1_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_skinny_fixup: N%8, ld%8 required");
     int ncol, mg;
     const int ks = skinny_fix_cfg(M, N, K, &ncol, &mg);
-    const int64_t groups = (N + 16 * ncol - 1) / (16 * ncol);
+    static int down_lds = -1;                        // TR1_DOWN_LDS=0 selects the register-fragment form (A/B measurements); 6 / 7 = waves per block
+    if (down_lds < 0) { const char* e = getenv("TR1_DOWN_LDS"); down_lds = e ? atoi(e) : 7; }
+    const bool c56 = down_lds && (K / ks) % 64 == 0 && skinny_fix_cols56(N, ks, ncol, mg);
+    const int64_t groups = c56 ? N / 56 : (N + 16 * ncol - 1) / (16 * ncol);
     TR1_CHECK_ARG(ws_f32 && ws_floats >= ks * groups * ncol * mg * 256 + groups, "gemm_skinny_fixup: workspace too small");
     float* tiles = (float*)ws_f32;
     int* cnt = (int*)(tiles + ks * groups * ncol * mg * 256);
@@ -1752,12 +1768,16 @@ extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, cons
     hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC, MGR>), dim3((unsigned)groups, (unsigned)ks), dim3(WV * 64), 0, s,            \
                        (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, \
                        (int)M, N, K, lda, ldb, ldc, ldr, tiles, ks > 1 ? cnt : (int*)nullptr)
-    static int down_lds = -1;                        // TR1_DOWN_LDS=0 selects the register-fragment form (A/B measurements); 6 / 7 = waves per block
-    if (down_lds < 0) { const char* e = getenv("TR1_DOWN_LDS"); down_lds = e ? atoi(e) : 7; }
     if (mg == 2 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {       // 17 .. 32 rows: 12 KiB stages, 6 waves
         static bool attr2 = false;
         if (!attr2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 2 * 12288 + 16); attr2 = true; }
         hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<6, 2>), dim3((unsigned)groups, (unsigned)ks), dim3(384), 6 * 2 * 12288 + 16, s, (const bf16_t*)A, (const bf16_t*)B,
+                           (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr, tiles, cnt);
+    }
+    else if (c56) {
+        static bool attr56 = false;
+        if (!attr56) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<7, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2 * 10240 + 16); attr56 = true; }
+        hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<7, 1, 7>), dim3((unsigned)groups, (unsigned)ks), dim3(448), 7 * 2 * 10240 + 16, s, (const bf16_t*)A, (const bf16_t*)B,
                            (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr, tiles, cnt);
     }
     else if (mg == 1 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {
