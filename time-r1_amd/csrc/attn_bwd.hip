@@ -1228,7 +1228,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
     wmaxpre = __builtin_amdgcn_readfirstlane(wmaxpre); wminpre = __builtin_amdgcn_readfirstlane(wminpre);
     wminlo = __builtin_amdgcn_readfirstlane(wminlo); wmaxhi = __builtin_amdgcn_readfirstlane(wmaxhi);
     wmaxlo = __builtin_amdgcn_readfirstlane(wmaxlo); wminhi = __builtin_amdgcn_readfirstlane(wminhi);
-    const bool wave_rows_all = Rw0 + 32u <= nR;
+    // (rows past nR - the padding of the last block - never force the masked path: they compute finite garbage that is not stored.  With an
+    //  `all 32 rows valid` term in `full`, the ONE partially valid wave of the heaviest block took the per-element mask path on every tile:
+    //  3 900 instead of 1 200 cycles of softmax, all other waves waiting for it at the barrier - wave timeline in DESIGN.md)
     if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
     // stationary B fragments: Q / dO row of this lane, features ks*16 + h*8 .. +7
     bf16x8_t qf[D / 16], dof[D / 16];
@@ -1300,7 +1302,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
         const int kv0 = att_tile_at(tr, it) * 64;
         // wave-uniform: does any row of the wave see a key of the tile / does every row see every key
         const bool any = (kv0 < wmaxpre) || (kv0 + 63 >= wminlo && kv0 <= wmaxhi);
-        const bool full = wave_rows_all && (kv0 + 64 <= p.n_slots) && ((kv0 + 64 <= wminpre) || (wmaxlo <= kv0 && kv0 + 63 <= wminhi));
+        const bool full = (kv0 + 64 <= p.n_slots) && ((kv0 + 64 <= wminpre) || (wmaxlo <= kv0 && kv0 + 63 <= wminhi));
         if (any) {
             const unsigned kb_ = lds_base + (unsigned)(it % NB) * BUF;
 #pragma unroll

@@ -13,6 +13,28 @@
 #define TR1_ABL 0        // timing-ablation bits for the forward loop (tools/build_variant.py <name> -DTR1_ABL=<bits>; results are WRONG by design):
 #endif                   // 1 no exp2, 2 no PV MFMAs, 4 no S MFMAs, 8 no per-tile barrier
 
+#ifdef TR1_PROBE
+// wave-timeline probe (tools/bench_attn.py --probe-fwd against tools/_probe_lib.so): the stamps of a tile stay in scalar registers, go to a spare LDS
+// area at the end of the tile (no global store inside the loop: stores share vmcnt with the tile DMA) and are dumped once when the block is done
+__device__ unsigned long long* tr1_fwd_probe = nullptr;
+extern "C" int probe_fwd_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_fwd_probe), &ptr, sizeof(ptr)); }
+#define FWD_PROBE_LDS (8 * 48 * 8 * 8)
+#define FWD_STAMPS unsigned long long fwd_st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FWD_STAMP(slot) do { fwd_st_[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FWD_FLUSH(it) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (it) < 48) { \
+    unsigned long long* pl_ = reinterpret_cast<unsigned long long*>(dyn_lds + 4 * (2 * 64 * 256) + 128); \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) pl_[(((threadIdx.x >> 6) * 48 + (it)) * 8 + s_)] = fwd_st_[s_]; } } while (0)
+#define FWD_DUMP() do { if (tr1_fwd_probe && blockIdx.x == 0) { __syncthreads(); \
+    const unsigned long long* pl_ = reinterpret_cast<const unsigned long long*>(dyn_lds + 4 * (2 * 64 * 256) + 128); \
+    for (int i_ = threadIdx.x; i_ < 8 * 48 * 8; i_ += 512) tr1_fwd_probe[i_] = pl_[i_]; } } while (0)
+#else
+#define FWD_PROBE_LDS 0
+#define FWD_STAMPS do { } while (0)
+#define FWD_STAMP(slot) do { } while (0)
+#define FWD_FLUSH(it) do { } while (0)
+#define FWD_DUMP() do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE;
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][K rows | V rows] + block mask summary
@@ -46,7 +68,9 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     wmaxpre = __builtin_amdgcn_readfirstlane(wmaxpre); wminpre = __builtin_amdgcn_readfirstlane(wminpre);
     wminlo = __builtin_amdgcn_readfirstlane(wminlo); wmaxhi = __builtin_amdgcn_readfirstlane(wmaxhi);
     wmaxlo = __builtin_amdgcn_readfirstlane(wmaxlo); wminhi = __builtin_amdgcn_readfirstlane(wminhi);
-    const bool wave_rows_all = Rw0 + 32u <= nR;
+    // (rows past nR - the padding of the last block - never force the masked path: they compute finite garbage that is not stored.  With an
+    //  `all 32 rows valid` term in `full`, the ONE partially valid wave of the heaviest block took the per-element mask path on every tile:
+    //  3 900 instead of 1 200 cycles of softmax, all other waves waiting for it at the barrier - wave timeline in DESIGN.md)
     if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
     bf16x8_t qf[D / 16];                                              // Q row of this lane, features ks*16 + h*8 .. +7 (B operand)
     {
@@ -102,6 +126,8 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     const unsigned t_lane = (unsigned)((4 * h + (ti >> 2)) * 256 + (ti & 1) * 8 + (((tgrp * 2 + ((ti & 3) >> 1)) ^ (((ti >> 2) << 2) | h)) << 4));
 
     for (int it = 0; it < n_my; ++it) {
+        FWD_STAMPS;
+        FWD_STAMP(0);
         {
             const int after = (n_my - 1 - it) < (NB - 2) ? (n_my - 1 - it) : (NB - 2);
             if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -112,10 +138,11 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
         __builtin_amdgcn_s_barrier();                                 // tile `it` is complete for everybody; everybody is done with tile it-1
 #endif
         asm volatile("" ::: "memory");
+        FWD_STAMP(1);
         if (it + NB - 1 < n_my) issue_tile(att_tile_at(tr, it + NB - 1), (it + NB - 1) % NB);
         const int kv0 = att_tile_at(tr, it) * 64;
         const bool any = (kv0 < wmaxpre) || (kv0 + 63 >= wminlo && kv0 <= wmaxhi);
-        const bool full = wave_rows_all && (kv0 + 64 <= p.n_slots) && ((kv0 + 64 <= wminpre) || (wmaxlo <= kv0 && kv0 + 63 <= wminhi));
+        const bool full = (kv0 + 64 <= p.n_slots) && ((kv0 + 64 <= wminpre) || (wmaxlo <= kv0 && kv0 + 63 <= wminhi));
         if (any) {
             const unsigned kb_ = lds_base + (unsigned)(it % NB) * BUF;
             // S^T[kv][q]: two independent chains (the tile's 32-key halves)
@@ -140,6 +167,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            FWD_STAMP(2);
             // lane holds S^T[kv = kv0 + kb*32 + 8i + 4h + j][its query row] in cs[kb][4i + j]; lane ^ 32 holds the other 32 keys of the row
             float mx = NEG_INF;
             if (full) {
@@ -182,6 +210,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
             }
+            FWD_STAMP(3);
             // O^T[feature][q] += V^T[feature][kv] P^T[kv][q], 16 keys per MFMA; V^T fragments are transposing reads of the V row tile
             const unsigned ya = kb_ + TILE + t_lane;
             constexpr int TH = 2;
@@ -201,9 +230,13 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef P2_LD
+            FWD_STAMP(4);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // all LDS reads of this tile have returned before the barrier that frees its slot
+        FWD_STAMP(5);
+        FWD_FLUSH(it);
     }
+    FWD_DUMP();
 #undef LDS_B128
 #undef LDS_TR16
     // lane holds O^T[feature = db*32 + 8i + 4h + j][its query row]
@@ -589,7 +622,7 @@ extern "C" int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int
         p.xcd_pad = ((nqb + per - 1) / per) * 8;
         blocks = (unsigned)p.xcd_pad;
     }
-    const size_t dyn = 4 * (2 * 64 * 256) + 128;
+    const size_t dyn = 4 * (2 * 64 * 256) + 128 + FWD_PROBE_LDS;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); attr = true; }
     hipLaunchKernelGGL(attn_fwd32_kernel, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--probe-fwd", action="store_true", help="needs TR1_HIP_LIB=tools/_probe_lib.so: s_memtime stamps of the heaviest forward block (tile top, after barrier, after S, after softmax, after PV, end)")
     ap.add_argument("--probe", action="store_true", help="needs TR1_HIP_LIB=tools/_probe_lib.so: dump the s_memtime stamps of one dK/dV block")
     ap.add_argument("--P", type=int, default=3474)
     ap.add_argument("--G", type=int, default=8)
@@ -79,6 +80,23 @@ def main():
         rel = lambda x, y: float((x.float() - y.float()).norm() / y.float().norm().clamp(min=1e-20))
         out["rel_l2"] = dict(o=rel(o, ref.detach()), dq=rel(dq, qf.grad), dk=rel(dk, kf.grad), dv=rel(dv, vf.grad))
         out["nan"] = bool(torch.isnan(dq.float()).any() or torch.isnan(dk.float()).any() or torch.isnan(dv.float()).any())
+    if a.probe_fwd:
+        from time_r1_amd import hip
+        buf = torch.zeros(8 * 48 * 8, dtype=torch.int64, device="cuda")
+        rc = hip.lib().cdll.probe_fwd_set_ptr(ctypes.c_void_p(buf.data_ptr()))
+        assert rc == 0, rc
+        ops.attn_fwd(q, k, vt, pre, lo, hi, H, NKV, M, HD, scale, v_rows=v)
+        torch.cuda.synchronize()
+        hip.lib().cdll.probe_fwd_set_ptr(ctypes.c_void_p(0))
+        st = buf.cpu().view(8, 48, 8).numpy()
+        t0 = int(st[st > 0].min())
+        lines = []
+        for w in range(8):
+            for it in range(48):
+                if st[w, it].max() == 0:
+                    break
+                lines.append("w%d it%02d " % (w, it) + " ".join("%7d" % (int(x) - t0 if x > 0 else -1) for x in st[w, it][:6]))
+        out["probe_fwd"] = lines
     if a.probe:
         from time_r1_amd import hip
         buf = torch.zeros(16 * 64 * 8, dtype=torch.int64, device="cuda")
