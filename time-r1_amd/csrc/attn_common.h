@@ -290,6 +290,8 @@ typedef const __attribute__((address_space(1))) void* att_gptr_t;
 typedef __attribute__((address_space(3))) void* att_lptr_t;
 // swizzle key of row (mod 16) of an unpadded 256-byte-row tile image: logical 16-byte chunk c of the row is stored at chunk c ^ skey(row)
 TR1_DEV int skey(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// max of three without the canonicalising v_max x, x that fmaxf() costs per operand (no NaN can reach the score tiles: -inf masks, finite inputs)
+TR1_DEV float att_max3(float a, float b, float c) { float o; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c)); return o; }
 // registers b .. b+7 of a 32x32 accumulator -> one bf16 MFMA operand fragment (k-slot j of lane half h = accumulator row 16(b/8) + (j&3) + 8(j>>2) + 4h)
 TR1_DEV bf16x8_t pack8(const f32x16_t& c, int b) {
     u32x4_t w = {pack2bf(c[b], c[b + 1]), pack2bf(c[b + 2], c[b + 3]), pack2bf(c[b + 4], c[b + 5]), pack2bf(c[b + 6], c[b + 7])};

@@ -9,6 +9,12 @@
 // the source address with skey().  32 MFMAs per wave and tile against 16 b128 + 32 transposing LDS reads.
 #include "attn_common.h"
 #include <stdlib.h>
+#ifndef FWD_AH
+#define FWD_AH 2        // K fragments / V^T fragments requested ahead of the MFMA that uses them (forward kernel)
+#endif
+#ifndef FWD_TH
+#define FWD_TH 2
+#endif
 #ifndef TR1_ABL
 #define TR1_ABL 0        // timing-ablation bits for the forward loop (tools/build_variant.py <name> -DTR1_ABL=<bits>; results are WRONG by design):
 #endif                   // 1 no exp2, 2 no PV MFMAs, 4 no S MFMAs, 8 no per-tile barrier
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) { cs[0][r] = 0.f; cs[1][r] = 0.f; }
             {
                 const unsigned xa = kb_ + a_lane;
-                constexpr int AH = 2;
+                constexpr int AH = FWD_AH;
                 bf16x8_t k0[AH + 1], k1[AH + 1];
 #pragma unroll
                 for (int ks = 0; ks < AH; ++ks) { k0[ks] = LDS_B128(xa ^ (ks * 32)); k1[ks] = LDS_B128((xa ^ (ks * 32)) + 8192); }
@@ -169,39 +175,45 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             }
             FWD_STAMP(2);
             // lane holds S^T[kv = kv0 + kb*32 + 8i + 4h + j][its query row] in cs[kb][4i + j]; lane ^ 32 holds the other 32 keys of the row
-            float mx = NEG_INF;
-            if (full) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cs[kb][r]);
-            } else {
+            // (vector-ALU work is what this kernel pays for next to its MFMAs - the two do not overlap on a SIMD, see DESIGN.md: the masked path
+            //  only rewrites cs in place, so both paths share ONE copy of the code below and no register copies appear at the join; the max runs
+            //  as two independent v_max3 chains; scale / subtract and the row sum are packed-fp32 instructions, two values each)
+            if (!full) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                         const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre, lo, hi);
-                        const float v = ok ? cs[kb][r] : NEG_INF;
-                        cs[kb][r] = v; mx = fmaxf(mx, v);
+                        cs[kb][r] = ok ? cs[kb][r] : NEG_INF;
                     }
             }
+            float mxa = NEG_INF, mxb = NEG_INF;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { mxa = att_max3(mxa, cs[0][r], cs[0][r + 1]); mxb = att_max3(mxb, cs[1][r], cs[1][r + 1]); }
+            float mx = fmaxf(mxa, mxb);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx * p.scale_log2);          // max over RAW scores (scale > 0 commutes with max)
             const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m - m_safe);
-            float rs = 0.f;
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t sc2 = {p.scale_log2, p.scale_log2}, nm2 = {-m_safe, -m_safe};
+            f32x2_t rs2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t x = {cs[kb][r], cs[kb][r + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, nm2);
 #if !(TR1_ABL & 1)
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[kb][r], p.scale_log2, -m_safe));
+                    const f32x2_t e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
 #else
-                    const float e = __builtin_fmaf(cs[kb][r], p.scale_log2, -m_safe);
+                    const f32x2_t e = x;
 #endif
-                    cs[kb][r] = e; rs += e;
+                    cs[kb][r] = e[0]; cs[kb][r + 1] = e[1];
+                    rs2 += e;
                 }
+            float rs = rs2[0] + rs2[1];
             rs += __shfl_xor(rs, 32, 64);
             l = l * alpha + rs; m = m_new;
             if (!__all(alpha == 1.0f)) {      // exact: the running maximum did not move for any row of the wave -> no rescale needed
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             FWD_STAMP(3);
             // O^T[feature][q] += V^T[feature][kv] P^T[kv][q], 16 keys per MFMA; V^T fragments are transposing reads of the V row tile
             const unsigned ya = kb_ + TILE + t_lane;
-            constexpr int TH = 2;
+            constexpr int TH = FWD_TH;
             bf16x8_t a[TH + 1];
 #define P2_LD(n) make_frag(LDS_TR16((ya ^ (((n) & 3) * 64)) + ((n) >> 2) * 4096), LDS_TR16((ya ^ (((n) & 3) * 64 + 32)) + ((n) >> 2) * 4096 + 2048))
 #pragma unroll
