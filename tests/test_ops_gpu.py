@@ -740,3 +740,47 @@ def test_down_projection_56_column_blocks_bit_identical(tmp_path):
         files.append(torch.load(f))
     for a, b in zip(*files):
         assert torch.equal(a, b)
+
+
+def test_decode_projections_x_through_lds_bit_identical(tmp_path):
+    """Round 3: the <= 16-row fused QKV kernel and the o projection take the activation rows through ONE DMA copy into LDS per block instead of per-wave
+    vector loads (TR1_QKV_XLDS / TR1_SKINNY_XLDS, default on), and the QKV weights can stream through LDS rings (TR1_QKV_LDS=1): same values, same
+    order of operations - q, the appended K / V^T cache rows and the projection output must be bit-identical in every form (7B and 2B widths, 16 / 5 rows)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import torch, sys
+        sys.path.insert(0, %r)
+        import time_r1_amd
+        from time_r1_amd.ops import HipOps
+        ops = HipOps("cuda:0")
+        g = torch.Generator().manual_seed(5)
+        outs = []
+        for K, nh, nkv in ((3584, 28, 4), (1536, 12, 2)):
+            hd = 128
+            for M in (16, 5):
+                x = torch.randn(M, K, generator=g).bfloat16().cuda()
+                lnw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
+                w = (torch.randn((nh + 2 * nkv) * hd, K, generator=g) * 0.02).bfloat16().cuda()
+                b = torch.randn((nh + 2 * nkv) * hd, generator=g).bfloat16().cuda()
+                cos, sin = torch.randn(M, hd // 2, generator=g).cuda(), torch.randn(M, hd // 2, generator=g).cuda()
+                kc = torch.zeros(256, nkv * hd, dtype=torch.bfloat16, device="cuda"); vt = torch.zeros(nkv * hd, 256, dtype=torch.bfloat16, device="cuda")
+                slots = (torch.arange(M, dtype=torch.int32) * 7 + 3).cuda()
+                q = ops.norm_gemm_qkv(x, lnw, 1e-6, w, b, cos, sin, kc, vt, slots, nh, nkv, hd)
+                wo = (torch.randn(K, K, generator=g) * 0.02).bfloat16().cuda()
+                res = torch.randn(M, K, generator=g).bfloat16().cuda()
+                o = ops.gemm_nt(x, wo, residual=res)
+                assert torch.isfinite(q.float()).all() and torch.isfinite(o.float()).all()
+                outs += [q.cpu(), kc.cpu(), vt.cpu(), o.cpu()]
+        torch.save(outs, sys.argv[1])
+        print("ok")
+    """) % root
+    res = []
+    for i, env in enumerate((dict(TR1_QKV_XLDS="0", TR1_SKINNY_XLDS="0", TR1_QKV_LDS="0"), dict(), dict(TR1_QKV_LDS="1"))):
+        f = str(tmp_path / ("proj_%d.pt" % i))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+        res.append(torch.load(f))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)

@@ -637,7 +637,9 @@ __device__ unsigned long long* tr1_probe = nullptr;
 // the L2 traffic for x drops from 1x to 1/NCOL of the weight stream (matters at M = 16, where x is as large as a block's W slab).
 // MG: 16-row groups of x (M <= 16*MG): every weight fragment fetched from HBM feeds MG MFMAs, so batching more rollout rows into one
 // decode step (G = 16, or several prompts of a gradient-accumulation window) keeps the single pass over the weights.
-template <int WAVES, int UNROLL, int NCOL, int MG>
+// XLDS (round 3; MG = 1, no cross-block split-K): x reaches the MFMA through ONE DMA copy into LDS per block instead of per-wave vector loads - see the
+// note at norm_gemm_skinny_kernel (the L1 tag pipe looks up 64 pieces per 1 KiB load in the operand layout; at NCOL = 1 half of the loads were x).
+template <int WAVES, int UNROLL, int NCOL, int MG, bool XLDS = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                  float* __restrict__ Cf32, const bf16_t* __restrict__ bias,
                                                                  const bf16_t* __restrict__ residual, int M, int64_t N, int64_t K, int64_t ldx,
@@ -645,6 +647,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
                                                                  int* __restrict__ fix_cnt) {
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ int s_ticket;
+    extern __shared__ __attribute__((aligned(1024))) char sk_xs[];             // XLDS: [K/64 segments][16 rows][128 bytes]
+    static_assert(!XLDS || MG == 1, "the LDS copy of x holds 16 rows");
     TR1_PROBE_AT(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
@@ -675,6 +679,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
     for (int c = 0; c < NCOL; ++c)
 #pragma unroll
         for (int mg = 0; mg < MG; ++mg) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    const unsigned xs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sk_xs;
+    if (XLDS) {       // inline asm: after the builtin hipcc would drain the weight stream (vmcnt(0)) in front of every LDS read
+        const int r8 = lane >> 3;
+        const int n_inst = (int)(K >> 5);                                     // 1 KiB per instruction
+        for (int i = __builtin_amdgcn_readfirstlane(wave); i < n_inst; i += WAVES) {
+            const int r = (i & 1) * 8 + r8;
+            const unsigned off = (unsigned)((r < M ? r : M - 1) * (int)ldx + (i >> 1) * 64 + (((lane & 7) ^ keyA(r)) << 3)) * 2u;
+            const unsigned dst = xs_base + (unsigned)i * 1024u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(X) : "memory", "m0");
+        }
+    }
+    const unsigned xs_lane = xs_base + (unsigned)(u * 128);
+    const int xs_key = keyA(u);
     // Rotating software pipeline over UNROLL k-step buffers: a buffer is refilled (next k-step, UNROLL ahead) right after its MFMAs are
     // issued.  Measured neutral against the batch form (issue UNROLL steps, drain, repeat): hipcc still drains the queue once per trip
     // (s_waitcnt vmcnt(1)/vmcnt(0) at the loop header), and the N sweep of tools/probe_skinny.hip shows the kernel already at
@@ -687,13 +704,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
             wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__);                               \
             wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__ + 32);                          \
         }                                                                                                \
-        _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                              \
+        if (!XLDS) { _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                 \
             xa[q][mg][0] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__);                             \
             xa[q][mg][1] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__ + 32);                        \
-        }                                                                                                \
+        } }                                                                                              \
     } while (0)
-#define SK_MFMA(q)                                                                                                            \
+#define SK_MFMA(q, st)                                                                                                        \
     do {                                                                                                                      \
+        if (XLDS) {                                                                                                           \
+            typedef const __attribute__((address_space(3))) bf16x8_t* xs_ptr_t;                                               \
+            const unsigned xa__ = xs_lane + (unsigned)(st) * 2048u;                                                           \
+            xa[q][0][0] = *(xs_ptr_t)(uintptr_t)(xa__ + (unsigned)(((0 + g) ^ xs_key) << 4));                                 \
+            xa[q][0][1] = *(xs_ptr_t)(uintptr_t)(xa__ + (unsigned)(((4 + g) ^ xs_key) << 4));                                 \
+        }                                                                                                                     \
         _Pragma("unroll") for (int c = 0; c < NCOL; ++c)                                                                      \
             _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                                               \
                 acc[c][mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], xa[q][mg][0], acc[c][mg][0], 0, 0, 0);   \
@@ -704,17 +727,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
 #pragma unroll
     for (int q = 0; q < UNROLL; ++q)
         if (s0 + q < s1) SK_LOAD(q, s0 + q);
+    if (XLDS) {       // the x copy has landed for this wave when only the UNROLL * 2 NCOL younger register loads are still in flight
+        static_assert(!XLDS || UNROLL * 2 * NCOL == 8, "vmcnt below is written for 8 register loads in the prologue");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     for (; s + 2 * UNROLL <= s1; s += UNROLL) {          // steady state: branch-free
 #pragma unroll
-        for (int q = 0; q < UNROLL; ++q) { SK_MFMA(q); SK_LOAD(q, s + q + UNROLL); }
+        for (int q = 0; q < UNROLL; ++q) { SK_MFMA(q, s + q); SK_LOAD(q, s + q + UNROLL); }
     }
 #pragma unroll
     for (int q = 0; q < UNROLL; ++q)
-        if (s + q < s1) { SK_MFMA(q); if (s + q + UNROLL < s1) SK_LOAD(q, s + q + UNROLL); }
+        if (s + q < s1) { SK_MFMA(q, s + q); if (s + q + UNROLL < s1) SK_LOAD(q, s + q + UNROLL); }
     s += UNROLL;
 #pragma unroll
     for (int q = 0; q < UNROLL; ++q)
-        if (s + q < s1) SK_MFMA(q);
+        if (s + q < s1) SK_MFMA(q, s + q);
 #undef SK_LOAD
 #undef SK_MFMA
     // D[row = n index (g*4+r)][col = m (u)]
@@ -802,17 +831,40 @@ TR1_DEV bf16x8_t scale_frag_sumsq(bf16x8_t x, bf16x8_t w, float& ss) {
     return __builtin_bit_cast(bf16x8_t, o);
 }
 
+#ifdef TR1_PROBE
+// block timeline of the fused QKV launch (tools/bench_qkv32.py PROBE=1 against tools/_probe_lib.so): s_memtime at entry / first loads issued / stream
+// consumed / partials reduced (after the barrier) / epilogue stored, for waves 0 and WAVES-1 of every block; written once, at the very end
+__device__ unsigned long long* tr1_qkv_probe = nullptr;
+extern "C" int probe_qkv_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_qkv_probe), &ptr, sizeof(ptr)); }
+#define QKV_STAMPS unsigned long long qs_[6] = {0, 0, 0, 0, 0, 0}
+#define QKV_STAMP(i) do { if (QKV) qs_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define QKV_DUMP() do { if (QKV && tr1_qkv_probe && lane == 0 && (wave == 0 || wave == WAVES - 1)) { \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) tr1_qkv_probe[((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + i_] = qs_[i_]; } } while (0)
+#else
+#define QKV_STAMPS do { } while (0)
+#define QKV_STAMP(i) do { } while (0)
+#define QKV_DUMP() do { } while (0)
+#endif
 // QKV: the block's two column groups are columns (d, d + hd/2) of one head and the epilogue is qkv_epilogue_store (RoPE + cache append).
-template <int WAVES, int UNROLL, int MG, bool GLU, int NCOL = 2, bool QKV = false>
+// XLDS (round 3, MG = 1): the activation rows do not travel through the vector-memory path at all.  In the MFMA operand layout a wave load touches 16
+// rows x 64 bytes = 64 separate (line, 16-byte) pieces, and the L1 tag pipe looks them up one per cycle: a 1 KiB load instruction costs ~64 cycles
+// (measured 38-54 GB/s per CU in this kernel, block timeline in DESIGN.md), and half of this kernel's load instructions were x and lnw.  With XLDS the
+// block copies x ONCE into LDS by DMA (8 rows x 128 bytes per instruction = 8 lines; 16 rows x K, swizzled on the source address like every other
+// tile here) and reads its fragments with ds_read_b128; only the weights stay on the register path.  Same values, same order of operations.
+template <int WAVES, int UNROLL, int MG, bool GLU, int NCOL = 2, bool QKV = false, bool XLDS = false>
 __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
                                                                       const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                       const bf16_t* __restrict__ bias, int M, int64_t N, int64_t K, int64_t ldx,
                                                                       int64_t ldw, int64_t ldc, float eps, int64_t up_off, QkvEpi qe = QkvEpi{}) {
     static_assert(!GLU || NCOL % 2 == 0, "GLU pairs NCOL/2 gate column groups with NCOL/2 up column groups");
     static_assert(!QKV || (NCOL == 2 && !GLU), "QKV pairs the two rotate-half column groups of a head");
+    static_assert(!XLDS || MG == 1, "the LDS copy of x holds 16 rows");
+    extern __shared__ __attribute__((aligned(1024))) char ng_xs[];             // XLDS: [K/64 segments][16 rows][128 bytes]
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ float ssred[WAVES][MG][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    QKV_STAMPS;
+    QKV_STAMP(0);
     const int u = lane & 15, g = lane >> 4;
     const int qkv_gph = QKV ? qe.hd >> 5 : 1;                                   // 16-column group pairs per head
     const int qkv_h = QKV ? (int)blockIdx.x / qkv_gph : 0, qkv_j = QKV ? (int)blockIdx.x % qkv_gph : 0;
@@ -843,6 +895,19 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) { acc[c][mg][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][mg][NA - 1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     }
+    const unsigned xs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ng_xs;
+    if (XLDS) {       // issued from inline asm: after the builtin hipcc would put vmcnt(0) in front of every LDS read, draining the weight stream
+        const int r8 = lane >> 3;
+        const int n_inst = (int)(K >> 5);                                     // 1 KiB per instruction
+        for (int i = __builtin_amdgcn_readfirstlane(wave); i < n_inst; i += WAVES) {
+            const int r = (i & 1) * 8 + r8;
+            const unsigned off = (unsigned)((r < M ? r : M - 1) * (int)ldx + (i >> 1) * 64 + (((lane & 7) ^ keyA(r)) << 3)) * 2u;
+            const unsigned dst = xs_base + (unsigned)i * 1024u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(X) : "memory", "m0");
+        }
+    }
+    const unsigned xs_lane = xs_base + (unsigned)(u * 128);
+    const int xs_key = keyA(u);
     // rotating software pipeline over UNROLL k-step buffers (see gemm_skinny_kernel)
     bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][MG][2], la[UNROLL][2];
 #define NG_LOAD(q, st)                                                                                   \
@@ -852,15 +917,21 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
             wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__);                               \
             wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__ + 32);                          \
         }                                                                                                \
-        _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                              \
+        if (!XLDS) { _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                 \
             xa[q][mg][0] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__);                             \
             xa[q][mg][1] = *reinterpret_cast<const bf16x8_t*>(xp[mg] + k__ + 32);                        \
-        }                                                                                                \
+        } }                                                                                              \
         la[q][0] = *reinterpret_cast<const bf16x8_t*>(lp + k__);                                         \
         la[q][1] = *reinterpret_cast<const bf16x8_t*>(lp + k__ + 32);                                    \
     } while (0)
-#define NG_MFMA(q)                                                                                                            \
+#define NG_MFMA(q, st)                                                                                                        \
     do {                                                                                                                      \
+        if (XLDS) {                                                                                                           \
+            typedef const __attribute__((address_space(3))) bf16x8_t* xs_ptr_t;                                               \
+            const unsigned xa__ = xs_lane + (unsigned)(st) * 2048u;                                                           \
+            xa[q][0][0] = *(xs_ptr_t)(uintptr_t)(xa__ + (unsigned)(((0 + g) ^ xs_key) << 4));                                 \
+            xa[q][0][1] = *(xs_ptr_t)(uintptr_t)(xa__ + (unsigned)(((4 + g) ^ xs_key) << 4));                                 \
+        }                                                                                                                     \
         _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) {                                                                   \
             const bf16x8_t x0__ = scale_frag_sumsq(xa[q][mg][0], la[q][0], ss[mg]);                                           \
             const bf16x8_t x1__ = scale_frag_sumsq(xa[q][mg][1], la[q][1], ss[mg]);                                           \
@@ -874,19 +945,27 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 #pragma unroll
     for (int q = 0; q < UNROLL; ++q)
         if (s0 + q < s1) NG_LOAD(q, s0 + q);
+    QKV_STAMP(1);
+    if (XLDS) {       // the x copy has landed for this wave when only the UNROLL * (2 NCOL + 2) younger register loads are still in flight
+        static_assert(!XLDS || UNROLL * (2 * NCOL + 2) == 12, "vmcnt below is written for 12 register loads in the prologue");
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     for (; s + 2 * UNROLL <= s1; s += UNROLL) {
 #pragma unroll
-        for (int q = 0; q < UNROLL; ++q) { NG_MFMA(q); NG_LOAD(q, s + q + UNROLL); }
+        for (int q = 0; q < UNROLL; ++q) { NG_MFMA(q, s + q); NG_LOAD(q, s + q + UNROLL); }
     }
 #pragma unroll
     for (int q = 0; q < UNROLL; ++q)
-        if (s + q < s1) { NG_MFMA(q); if (s + q + UNROLL < s1) NG_LOAD(q, s + q + UNROLL); }
+        if (s + q < s1) { NG_MFMA(q, s + q); if (s + q + UNROLL < s1) NG_LOAD(q, s + q + UNROLL); }
     s += UNROLL;
 #pragma unroll
     for (int q = 0; q < UNROLL; ++q)
-        if (s + q < s1) NG_MFMA(q);
+        if (s + q < s1) NG_MFMA(q, s + q);
 #undef NG_LOAD
 #undef NG_MFMA
+    QKV_STAMP(2);
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg) {     // lanes u, u+16, u+32, u+48 hold disjoint k chunks of row u
         float v = ss[mg];
@@ -899,6 +978,7 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
             for (int r = 0; r < 4; ++r) red[wave][c][mg][u][g * 4 + r] = NA == 2 ? acc[c][mg][0][r] + acc[c][mg][1][r] : acc[c][mg][0][r];
     }
     __syncthreads();
+    QKV_STAMP(3);
     const float inv_k = 1.f / (float)K;
     for (int i = threadIdx.x; i < OG * MG * 256; i += WAVES * 64) {   // (column group, row group, m, n)
         const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = (i >> 4) & 15, nn = i & 15;
@@ -924,6 +1004,8 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
             }
         }
     }
+    QKV_STAMP(4);
+    QKV_DUMP();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1074,10 +1156,16 @@ __global__ __launch_bounds__(256) void norm_qkv_split_kernel(const bf16_t* __res
 // LDS image of a stage: [gate 16 rows | up 16 rows] x 128 bytes (64 k); row r keeps its logical 16-byte chunk c at position c ^ keyA(r)
 // (applied on the SOURCE address of the DMA): the 16-row fragment reads are conflict-free.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NST, int R, int NRED = 2, int MG = 1>
+// QKV (round 3): the same stream for the fused rmsnorm + q/k/v projection + M-RoPE + KV append at <= 16 rows.  One block per column-group pair
+// (16 columns d of a head and their rotate-half partners d + hd/2: `up_off` = hd/2 weight rows), no persistence (144 pairs at 7B), epilogue and
+// rounding points of norm_gemm_skinny_kernel's QKV form - same k-slices per wave, same two accumulators per tile, same wave-order reduction, so the
+// result is bit-identical to it.  What changes is the path of the weights: full 128-byte row runs by DMA (8 tag look-ups per KiB) instead of
+// 64-byte pieces of 16 rows per wave load (64 look-ups per KiB: the L1 tag pipe held the register-fragment kernel at ~40 GB/s per CU).
+template <int NST, int R, int NRED = 2, int MG = 1, bool QKV = false>
 __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
-                                                           int64_t ldc, float eps, int64_t up_off) {
+                                                           int64_t ldc, float eps, int64_t up_off, const bf16_t* __restrict__ bias = nullptr,
+                                                           QkvEpi qe = QkvEpi{}) {
     constexpr int STAGE = 4096;                                            // bytes per stage: gate 2 KiB + up 2 KiB
     constexpr int REDW = MG * 2 * 16 * 17;                                 // floats of one wave's partial: MG row groups x (gate | up)
     // red[2][8][REDW] f32 | ssq[8][16] | [8 waves][R stages][4 KiB].  The rings come LAST: a DMA destination is passed as (slot - stage offset)
@@ -1088,8 +1176,11 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
     char* rings = glu_lds + (NRED * 8 * REDW + 8 * MG * 16) * sizeof(float);
     static_assert((NRED * 8 * REDW + 8 * MG * 16) * sizeof(float) >= 6 * 128 && ((NRED * 8 * REDW + 8 * MG * 16) * sizeof(float)) % 16 == 0, "ring base");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int64_t NP = (N + 15) / 16;
+    const int64_t NP = QKV ? (int64_t)gridDim.x : (N + 15) / 16;
     const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
+    const int qkv_gph = QKV ? qe.hd >> 5 : 1;                               // column-group pairs per head
+    const int qkv_h = QKV ? (int)blockIdx.x / qkv_gph : 0, qkv_j = QKV ? (int)blockIdx.x % qkv_gph : 0;
+    const int64_t row_base = QKV ? (int64_t)qkv_h * qe.hd + qkv_j * 16 : p0 * 16;      // first weight row of the block's first pair
     const int npair = (int)(p1 - p0);
     const int64_t kb = (int64_t)wave * (K / 8);
     // ---- DMA lane map: instruction j covers rows 8j .. 8j+7; lane -> row 8j + (lane >> 3), physical chunk lane & 7, logical chunk ^ keyA(row).
@@ -1101,7 +1192,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = 8 * j + (lane >> 3);
-        pg[j] = W + (p0 * 16 + r) * ldw + kb + (((lane & 7) ^ keyA(r)) << 3);
+        pg[j] = W + (row_base + r) * ldw + kb + (((lane & 7) ^ keyA(r)) << 3);
         pu[j] = pg[j] + up_off * ldw;
     }
     const int64_t pair_step = 16 * ldw;
@@ -1219,9 +1310,16 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
 #pragma unroll
             for (int w = 0; w < 8; ++w) { v += rb[w * REDW + mm * 17 + nn]; v2 += rb[w * REDW + 16 * 17 + mm * 17 + nn]; }
             v = __fmul_rn(v, rstd);
+            if (QKV) {      // rounding points of norm_gemm_skinny_kernel's QKV epilogue (projection -> bf16 -> RoPE / cache append)
+                const int64_t n = row_base + nn, nb = n + (qe.hd >> 1);
+                float vb = __fmul_rn(v2, rstd);
+                if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[nb])); }
+                if (mm < M && n < N) qkv_epilogue_store(qe, mm, qkv_h, qkv_j * 16 + nn, bf2f(f2bf(v)), bf2f(f2bf(vb)));
+            } else {
             const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
             const int64_t n = (p0 + pi) * 16 + nn;
             if (mgi * 16 + mm < M && n < N) C[(int64_t)(mgi * 16 + mm) * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
+            }
         }
         if (NRED == 1) TR1_BARRIER();                                   // single reduction buffer: everybody has read it before the next pair writes
     }
@@ -1309,7 +1407,36 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
 #define NGQ(WV, UN, MGR)                                                                                                              \
     hipLaunchKernelGGL((norm_gemm_skinny_kernel<WV, UN, MGR, false, 2, true>), grid, dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, \
                        (const bf16_t*)Wqkv, (bf16_t*)nullptr, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)0, qe)
-    if (M <= 16) NGQ(8, 2, 1); else if (M <= 32) { const int c = ng32_cfg(); if (c == 1) NGQ(8, 2, 2); else if (c == 2) NGQ(8, 1, 2); else if (c == 3) NGQ(4, 1, 2); else NGQ(4, 2, 2); } else NGQ(4, 2, 4);
+    // TR1_QKV_LDS=1: weights by DMA through per-wave LDS rings (norm_glu_lds_kernel, QKV mode).  Bit-identical and 12.99 us alone (register-fragment
+    // form with x in LDS: 12.69), but the decode step measured 3 547 us with it against 3 472 us - off by default.
+    static int qlds = -1;
+    if (qlds < 0) { const char* e = getenv("TR1_QKV_LDS"); qlds = e ? atoi(e) : 0; }
+    const int64_t nst = K / 512;
+    if (M <= 16 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
+        constexpr int RING = 4;
+        const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        static bool attr_q = false;
+        if (!attr_q) {
+#define QL_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
+            QL_ATTR(7); QL_ATTR(4); QL_ATTR(3);
+#undef QL_ATTR
+            attr_q = true;
+        }
+#define QL_LAUNCH(NSTV) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 1, 1, true>), grid, dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)Wqkv, \
+                                           (bf16_t*)nullptr, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)(head_dim / 2), (const bf16_t*)bias, qe)
+        if (nst == 7) QL_LAUNCH(7); else if (nst == 4) QL_LAUNCH(4); else QL_LAUNCH(3);
+#undef QL_LAUNCH
+        TR1_LAUNCH_CHECK();
+    }
+    static int xlds = -1;                            // TR1_QKV_XLDS=0: activation rows through the vector-memory path as well (A/B measurements)
+    if (xlds < 0) { const char* e = getenv("TR1_QKV_XLDS"); xlds = e ? atoi(e) : 1; }
+    if (M <= 16 && xlds && K / 64 / 8 >= 2 && K * 32 <= 120 * 1024 && (int64_t)M * ldx * 2 < 0x7fffffffLL) {
+        static bool attr_x = false;
+        if (!attr_x) { hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_gemm_skinny_kernel<8, 2, 1, false, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr_x = true; }
+        hipLaunchKernelGGL((norm_gemm_skinny_kernel<8, 2, 1, false, 2, true, true>), grid, dim3(512), (size_t)(K * 32), s, (const bf16_t*)x, (const bf16_t*)lnw,
+                           (const bf16_t*)Wqkv, (bf16_t*)nullptr, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)0, qe);
+    }
+    else if (M <= 16) NGQ(8, 2, 1); else if (M <= 32) { const int c = ng32_cfg(); if (c == 1) NGQ(8, 2, 2); else if (c == 2) NGQ(8, 1, 2); else if (c == 3) NGQ(4, 1, 2); else NGQ(4, 2, 2); } else NGQ(4, 2, 4);
 #undef NGQ
     TR1_LAUNCH_CHECK();
 }
@@ -1381,7 +1508,17 @@ static void launch_skinny(const void* A, const void* B, void* C, const void* bia
         if (longk) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2, 1); else SK(8, 4, 1, 1); }
         else if (ncol == 4) SK(4, 2, 4, 1);
         else if (ncol == 2) SK(4, 4, 2, 1);
-        else SK(4, 4, 1, 1);
+        else {
+            static int xlds = -1;                    // TR1_SKINNY_XLDS=0: activation rows through the vector-memory path (A/B measurements)
+            if (xlds < 0) { const char* e = getenv("TR1_SKINNY_XLDS"); xlds = e ? atoi(e) : 1; }
+            if (xlds && ksplit == 1 && K / 64 / 4 >= 4 && K * 32 <= 120 * 1024 && (int64_t)M * lda * 2 < 0x7fffffffLL) {
+                static bool attr_x = false;
+                if (!attr_x) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, 4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr_x = true; }
+                hipLaunchKernelGGL((gemm_skinny_kernel<4, 4, 1, 1, true>), dim3((unsigned)((N + 15) / 16), 1u), dim3(256), (size_t)(K * 32), s, (const bf16_t*)A,
+                                   (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C, out_f32 ? (float*)C : nullptr, (const bf16_t*)bias, (const bf16_t*)residual,
+                                   (int)M, N, K, lda, ldb, ldc, ldr, (float*)nullptr, (int*)nullptr);
+            } else SK(4, 4, 1, 1);
+        }
     } else if (M <= 32) {       // LDS reduce buffer: WAVES * NCOL * MG * 1088 B <= 64 KB
         if (longk) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2, 2); else SK(8, 2, 1, 2); }
         else if (ncol == 4) SK(4, 2, 4, 2);

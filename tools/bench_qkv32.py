@@ -34,3 +34,22 @@ def oproj():
     i[0] = (i[0] + 1) % NC
     return ops.gemm_nt(x, wo[i[0]], residual=res)
 print("cfg %s M=%d: fused qkv %6.2f us   o projection %6.2f us" % (os.environ.get("TR1_NG32_CFG", "0"), M, timeit(qkv), timeit(oproj)))
+
+if os.environ.get("PROBE"):      # TR1_HIP_LIB=tools/_probe_lib.so PROBE=1: block timeline of ONE fused QKV launch
+    import ctypes
+    from time_r1_amd import hip
+    buf = torch.zeros(160 * 2 * 8, dtype=torch.int64, device="cuda")
+    assert hip.lib().cdll.probe_qkv_set_ptr(ctypes.c_void_p(buf.data_ptr())) == 0
+    qkv(); torch.cuda.synchronize()
+    hip.lib().cdll.probe_qkv_set_ptr(ctypes.c_void_p(0))
+    st = buf.cpu().view(160, 2, 8).numpy()
+    nb = int((st[:, 0, 0] > 0).sum())
+    t0 = int(st[:nb, :, 0].min())
+    import numpy as np
+    rel = (st[:nb, :, :5] - t0).astype(np.float64)
+    names = ("entry", "first loads issued", "stream consumed", "partials reduced", "epilogue stored")
+    print("blocks", nb, "(s_memtime ticks; 100 ticks = 1 us at the 100 MHz reference clock)")
+    for w in (0, 1):
+        print(" wave %s:" % ("0" if w == 0 else "last"), "  ".join("%s min %.0f med %.0f max %.0f" % (names[i], rel[:, w, i].min(), np.median(rel[:, w, i]), rel[:, w, i].max()) for i in range(5)))
+    d = rel[:, 0, 1:] - rel[:, 0, :-1]
+    print(" wave 0 phase durations (median ticks):", "  ".join("%s %.0f" % (n, np.median(d[:, i])) for i, n in enumerate(("prologue", "stream", "reduce+barrier", "epilogue"))))
