@@ -1161,6 +1161,18 @@ __global__ __launch_bounds__(256) void norm_qkv_split_kernel(const bf16_t* __res
 // rounding points of norm_gemm_skinny_kernel's QKV form - same k-slices per wave, same two accumulators per tile, same wave-order reduction, so the
 // result is bit-identical to it.  What changes is the path of the weights: full 128-byte row runs by DMA (8 tag look-ups per KiB) instead of
 // 64-byte pieces of 16 rows per wave load (64 look-ups per KiB: the L1 tag pipe held the register-fragment kernel at ~40 GB/s per CU).
+#ifdef TR1_PROBE
+__device__ unsigned long long* tr1_glu_probe = nullptr;
+extern "C" int probe_glu_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_glu_probe), &ptr, sizeof(ptr)); }
+#define GLU_STAMPS unsigned long long gs_[6] = {0, 0, 0, 0, 0, 0}
+#define GLU_STAMP(i) do { gs_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GLU_DUMP() do { if (tr1_glu_probe && lane == 0 && (wave == 0 || wave == 7)) { \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) tr1_glu_probe[((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + i_] = gs_[i_]; } } while (0)
+#else
+#define GLU_STAMPS do { } while (0)
+#define GLU_STAMP(i) do { } while (0)
+#define GLU_DUMP() do { } while (0)
+#endif
 template <int NST, int R, int NRED = 2, int MG = 1, bool QKV = false>
 __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
@@ -1176,6 +1188,8 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
     char* rings = glu_lds + (NRED * 8 * REDW + 8 * MG * 16) * sizeof(float);
     static_assert((NRED * 8 * REDW + 8 * MG * 16) * sizeof(float) >= 6 * 128 && ((NRED * 8 * REDW + 8 * MG * 16) * sizeof(float)) % 16 == 0, "ring base");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    GLU_STAMPS;
+    GLU_STAMP(0);
     const int64_t NP = QKV ? (int64_t)gridDim.x : (N + 15) / 16;
     const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
     const int qkv_gph = QKV ? qe.hd >> 5 : 1;                               // column-group pairs per head
@@ -1209,16 +1223,57 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                                            case 4: GLU_ISSUE(4); break; case 5: GLU_ISSUE(5); break; default: GLU_ISSUE(6); break; } } while (0)
 #define GLU_NEXT_PAIR() do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { pg[j] += pair_step; pu[j] += pair_step; } } while (0)
     static_assert(NST <= 7, "stage offsets are enumerated up to 7");
-#pragma unroll
-    for (int i = 0; i < R - 1; ++i) {                    // prologue: items 0 .. R-2
-        if (i < total) {
-            if (i > 0 && i % NST == 0) GLU_NEXT_PAIR();
-            GLU_ISSUE_ST(i % NST);
-        }
-    }
+    constexpr bool XDMA = (MG == 1) && (2 * R + NRED >= NST);   // round 3: this wave's x slice goes through its own (still empty) ring first
+#define GLU_PROLOGUE() do {                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < R - 1; ++i) {      /* prologue: items 0 .. R-2 */                  \
+            if (i < total) {                                                                                     \
+                if (i > 0 && i % NST == 0) GLU_NEXT_PAIR();                                                      \
+                GLU_ISSUE_ST(i % NST);                                                                           \
+            }                                                                                                    \
+        } } while (0)
+    if (!XDMA) GLU_PROLOGUE();
+    GLU_STAMP(1);
     // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares - built AFTER the first weight stages were
     // issued, so the HBM stream starts at kernel entry instead of waiting for this L2 round trip
     bf16x8_t xr[MG][NST * 2];
+    if (XDMA) {
+        // The round-2 form loaded x and lnw with per-wave vector loads AFTER issuing the first weight stages: 28 loads per lane in four dependent
+        // batches, each load touching 16 rows x 64 bytes (64 L1 tag look-ups per KiB) - 15 400 of the launch's 98 000 cycles, with only two weight stages
+        // in flight meanwhile (block timeline).  Here the wave's x slice (16 rows x K/8 columns = NST stages of 2 KiB) is copied by DMA into
+        // its own ring (and, past 2R stages, its reduction slices - all unused so far), read back as fragments, and only then does the weight
+        // stream start: one L2 round trip instead of four, 8 tag look-ups per KiB.  Same fragments in the same order -> same sum of squares.
+        float ss = 0.f;
+        const bf16_t* lp = lnw + kb + g * 8;
+        bf16x8_t lv[NST * 2];
+#pragma unroll
+        for (int i = 0; i < NST * 2; ++i) lv[i] = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            char* dst = st < 2 * R ? ring + st * 2048 : reinterpret_cast<char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+                const int r = 8 * jx + (lane >> 3);
+                const bf16_t* src = X + (int64_t)(r < M ? r : M - 1) * ldx + kb + st * 64 + (((lane & 7) ^ keyA(r)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + jx * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NST * 2; ++i) {
+            const int st = i >> 1, ks = i & 1;
+            const char* sbx = st < 2 * R ? ring + st * 2048 : reinterpret_cast<const char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
+            const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(sbx + u * 128 + (((ks * 4 + g) ^ keyA(u)) << 4));
+            u32x4_t f = __builtin_bit_cast(u32x4_t, scale_frag_sumsq(xv, lv[i], ss));
+            asm volatile("" : "+v"(f));
+            xr[0][i] = __builtin_bit_cast(bf16x8_t, f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the ring is free again: start the weight stream
+        GLU_PROLOGUE();
+        float v = ss;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) ssq[wave * MG * 16 + u] = v;
+    } else
     {
         float ss[MG];
         const bf16_t* xp[MG];
@@ -1248,7 +1303,9 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             if (g == 0) ssq[(wave * MG + mg) * 16 + u] = v;
         }
     }
+    GLU_STAMP(2);
     TR1_BARRIER();                                       // the eight waves' sum-of-squares partials are in LDS (the prologue DMA is in flight)
+    GLU_STAMP(3);
     float rstd;
     {
         float sq = 0.f;
@@ -1322,7 +1379,10 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             }
         }
         if (NRED == 1) TR1_BARRIER();                                   // single reduction buffer: everybody has read it before the next pair writes
+        if (pi == 0) GLU_STAMP(4);
     }
+    GLU_STAMP(5);
+    GLU_DUMP();
 #undef GLU_ISSUE
 #undef GLU_ISSUE_ST
 #undef GLU_NEXT_PAIR

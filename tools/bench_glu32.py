@@ -27,3 +27,16 @@ for _ in range(200): run()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 5
 print("M=%d: %6.1f us  -> %5.0f GB/s of weights" % (M, us, 2 * I * K * 2 / us / 1e3))
+if os.environ.get("PROBE"):      # TR1_HIP_LIB=tools/_probe_lib.so PROBE=1: block timeline of ONE launch (within-block differences; XCD clocks are not aligned)
+    import ctypes
+    import numpy as np
+    from time_r1_amd import hip
+    buf = torch.zeros(256 * 2 * 8, dtype=torch.int64, device="cuda")
+    assert hip.lib().cdll.probe_glu_set_ptr(ctypes.c_void_p(buf.data_ptr())) == 0
+    run(); torch.cuda.synchronize()
+    hip.lib().cdll.probe_glu_set_ptr(ctypes.c_void_p(0))
+    st = buf.cpu().view(256, 2, 8).numpy().astype(np.float64)
+    names = ("prologue (pointers + first DMA)", "x' fragments built", "barrier (sum x^2)", "first column pair", "remaining pairs")
+    for w, wn in ((0, "wave 0"), (1, "wave 7")):
+        d = st[:, w, 1:6] - st[:, w, 0:5]
+        print(" %s, median cycles per phase: " % wn + "  ".join("%s %.0f" % (n, np.median(d[:, i])) for i, n in enumerate(names)), " total %.0f" % np.median(st[:, w, 5] - st[:, w, 0]))
