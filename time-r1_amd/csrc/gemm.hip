@@ -1173,11 +1173,14 @@ extern "C" int probe_glu_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_
 #define GLU_STAMP(i) do { } while (0)
 #define GLU_DUMP() do { } while (0)
 #endif
-template <int NST, int R, int NRED = 2, int MG = 1, bool QKV = false>
+// MODE 0: gate/up + SwiGLU.  MODE 1: fused QKV (above).  MODE 2 (round 3): plain projection C = rmsnorm(x) W^T for a wide N (the lm_head): the block's two
+// row groups are output columns n and n + N/2 (`up_off` = N/2 weight rows apart), both stored as they are.
+template <int NST, int R, int NRED = 2, int MG = 1, int MODE = 0>
 __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                                                            int64_t ldc, float eps, int64_t up_off, const bf16_t* __restrict__ bias = nullptr,
                                                            QkvEpi qe = QkvEpi{}) {
+    constexpr bool QKV = MODE == 1, PLAIN = MODE == 2;
     constexpr int STAGE = 4096;                                            // bytes per stage: gate 2 KiB + up 2 KiB
     constexpr int REDW = MG * 2 * 16 * 17;                                 // floats of one wave's partial: MG row groups x (gate | up)
     // red[2][8][REDW] f32 | ssq[8][16] | [8 waves][R stages][4 KiB].  The rings come LAST: a DMA destination is passed as (slot - stage offset)
@@ -1190,7 +1193,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
     GLU_STAMPS;
     GLU_STAMP(0);
-    const int64_t NP = QKV ? (int64_t)gridDim.x : (N + 15) / 16;
+    const int64_t NP = QKV ? (int64_t)gridDim.x : (PLAIN ? up_off / 16 : (N + 15) / 16);
     const int64_t p0 = NP * blockIdx.x / gridDim.x, p1 = NP * (blockIdx.x + 1) / gridDim.x;
     const int qkv_gph = QKV ? qe.hd >> 5 : 1;                               // column-group pairs per head
     const int qkv_h = QKV ? (int)blockIdx.x / qkv_gph : 0, qkv_j = QKV ? (int)blockIdx.x % qkv_gph : 0;
@@ -1372,6 +1375,11 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                 float vb = __fmul_rn(v2, rstd);
                 if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[nb])); }
                 if (mm < M && n < N) qkv_epilogue_store(qe, mm, qkv_h, qkv_j * 16 + nn, bf2f(f2bf(v)), bf2f(f2bf(vb)));
+            } else if (PLAIN) {
+                const int64_t n = (p0 + pi) * 16 + nn;
+                float vb = __fmul_rn(v2, rstd);
+                if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[n + up_off])); }
+                if (mm < M && n < up_off) { C[(int64_t)mm * ldc + n] = f2bf(v); if (n + up_off < N) C[(int64_t)mm * ldc + n + up_off] = f2bf(vb); }
             } else {
             const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
             const int64_t n = (p0 + pi) * 16 + nn;
@@ -1408,6 +1416,29 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     static int glu_lds = -1;                         // TR1_GLU_LDS=0 selects the register-fragment form (A/B measurements)
     if (glu_lds < 0) { const char* e = getenv("TR1_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
     const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
+    static int head_lds = -1;                        // TR1_HEAD_LDS=0: the lm_head stays on the register-fragment kernel (A/B measurements)
+    if (head_lds < 0) { const char* e = getenv("TR1_HEAD_LDS"); head_lds = e ? atoi(e) : 1; }
+    if (!glu && M <= 16 && head_lds && glu_lds && N >= 65536 && N % 32 == 0 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
+        // wide plain projection (the lm_head) through the LDS stream: 256 persistent blocks x 8 waves, column pairs (n, n + N/2)
+        constexpr int RING = 3;
+        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        static int n_cu_h = 0;
+        if (!n_cu_h) {
+            hipDeviceProp_t prop; int dev = 0;
+            hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
+            n_cu_h = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+#define HL_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 2, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
+            HL_ATTR(7); HL_ATTR(4); HL_ATTR(3);
+#undef HL_ATTR
+        }
+        const int64_t NPh = N / 32;
+        const unsigned gridh = (unsigned)(NPh < n_cu_h ? NPh : n_cu_h);
+#define HL_LAUNCH(NSTV) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 2, 1, 2>), dim3(gridh), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W, \
+                                           (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N / 2, (const bf16_t*)bias, QkvEpi{})
+        if (nst == 7) HL_LAUNCH(7); else if (nst == 4) HL_LAUNCH(4); else HL_LAUNCH(3);
+#undef HL_LAUNCH
+        TR1_LAUNCH_CHECK();
+    }
     if (glu && M <= 32 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3) && N % 16 == 0) {   // hidden 3584 / 2048 / 1536
         // <= 16 rows: ring of 3 + double reduction buffer (a ring of 4 with a single buffer and a second barrier per pair measured the same).
         // 17..32 rows (config 4 decodes 2 x 16 rollouts): two row groups per wave against the SAME LDS stage, ring of 3, single reduction
@@ -1477,12 +1508,12 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
         const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
         static bool attr_q = false;
         if (!attr_q) {
-#define QL_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
+#define QL_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
             QL_ATTR(7); QL_ATTR(4); QL_ATTR(3);
 #undef QL_ATTR
             attr_q = true;
         }
-#define QL_LAUNCH(NSTV) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 1, 1, true>), grid, dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)Wqkv, \
+#define QL_LAUNCH(NSTV) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 1, 1, 1>), grid, dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)Wqkv, \
                                            (bf16_t*)nullptr, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)(head_dim / 2), (const bf16_t*)bias, qe)
         if (nst == 7) QL_LAUNCH(7); else if (nst == 4) QL_LAUNCH(4); else QL_LAUNCH(3);
 #undef QL_LAUNCH
