@@ -782,8 +782,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
             const int m = mg * 16 + mm;
             const int64_t n = n0 + c * 16 + nn;
             float v = 0.f;
-            for (int ks = 0; ks < (int)gridDim.y; ++ks)
-                v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gridDim.y == 4) {       // unrolled: the four device-scope loads in flight together; same sum in the same order (see gemm_skinny_lds_fix_kernel)
+                float t[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    t[ks] = __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = ((t[0] + t[1]) + t[2]) + t[3];
+            } else {
+                for (int ks = 0; ks < (int)gridDim.y; ++ks)
+                    v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (m < M && n < N) {
                 if (bias) v += bf2f(bias[n]);
                 if (residual) v += bf2f(residual[(int64_t)m * ldr + n]);
@@ -1498,10 +1506,11 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
 #define NGQ(WV, UN, MGR)                                                                                                              \
     hipLaunchKernelGGL((norm_gemm_skinny_kernel<WV, UN, MGR, false, 2, true>), grid, dim3(WV * 64), 0, s, (const bf16_t*)x, (const bf16_t*)lnw, \
                        (const bf16_t*)Wqkv, (bf16_t*)nullptr, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)0, qe)
-    // TR1_QKV_LDS=1: weights by DMA through per-wave LDS rings (norm_glu_lds_kernel, QKV mode).  Bit-identical and 12.99 us alone (register-fragment
-    // form with x in LDS: 12.69), but the decode step measured 3 547 us with it against 3 472 us - off by default.
+    // TR1_QKV_LDS (default 1): weights by DMA through per-wave LDS rings (norm_glu_lds_kernel, QKV mode; bit-identical).  Before the x slice was staged
+    // by DMA as well the decode step measured 3 547 us with it against 3 472 us for the register-fragment form with x in LDS; with the staged x it is
+    // 3 277 against 3 325 us.  0 selects the register-fragment kernel (x through LDS unless TR1_QKV_XLDS=0).
     static int qlds = -1;
-    if (qlds < 0) { const char* e = getenv("TR1_QKV_LDS"); qlds = e ? atoi(e) : 0; }
+    if (qlds < 0) { const char* e = getenv("TR1_QKV_LDS"); qlds = e ? atoi(e) : 1; }
     const int64_t nst = K / 512;
     if (M <= 16 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         constexpr int RING = 4;
@@ -1847,6 +1856,18 @@ extern "C" int tr1_lmhead_lse_fwd(const void* hn, const void* W, const void* tar
 // NWI = weight DMA instructions (8 rows each) per stage: 8 = 64-column blocks; 7 = 56-column blocks (round 3): 3584 columns are then 64 groups, and
 // 64 x 4 K-slabs fill all 256 CUs (56 x 4 = 224 left 32 of them idle).  The MFMAs still run on four 16-row weight tiles - rows 56..63 of a stage are
 // never written and only feed the eight output columns that are not stored - so every stored value is the same sum in the same order as with NWI = 8.
+#ifdef TR1_PROBE
+__device__ unsigned long long* tr1_down_probe = nullptr;
+extern "C" int probe_down_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tr1_down_probe), &ptr, sizeof(ptr)); }
+#define DOWN_STAMPS unsigned long long ds_[6] = {0, 0, 0, 0, 0, 0}
+#define DOWN_STAMP(i) do { ds_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DOWN_DUMP() do { if (tr1_down_probe && threadIdx.x == 0) { \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) tr1_down_probe[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i_] = ds_[i_]; } } while (0)
+#else
+#define DOWN_STAMPS do { } while (0)
+#define DOWN_STAMP(i) do { } while (0)
+#define DOWN_DUMP() do { } while (0)
+#endif
 template <int WAVES, int MG = 1, int NWI = 8>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
                                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int M,
@@ -1857,6 +1878,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // [WAVES][2][STAGE]; afterwards red[WAVES][NC][MG][16][17] f32; ticket at the end
     int* s_ticket = reinterpret_cast<int*>(sk_lds + WAVES * 2 * STAGE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
+    DOWN_STAMPS;
+    DOWN_STAMP(0);
     constexpr int COLS = NWI * 8;                                           // output columns a block owns
     const int64_t n0 = (int64_t)blockIdx.x * COLS;
     const int64_t kslab = K / gridDim.y, k0 = (int64_t)blockIdx.y * kslab;
@@ -1912,7 +1935,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     }
 #undef SKL_ISSUE
 #undef SKL_CONSUME
-    TR1_BARRIER();                                                          // every wave is done with its ring: the space becomes the reduction buffer
+    DOWN_STAMP(1);
+    TR1_BARRIER();
+    DOWN_STAMP(2);                                                          // every wave is done with its ring: the space becomes the reduction buffer
     float* red = reinterpret_cast<float*>(sk_lds);                          // [WAVES][NC][MG][16][17]
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -1932,15 +1957,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DOWN_STAMP(3);
     if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(&fix_cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*s_ticket != (int)gridDim.y - 1) return;
+    DOWN_STAMP(4);
+    if (*s_ticket != (int)gridDim.y - 1) { DOWN_DUMP(); return; }
     for (int i = threadIdx.x; i < TILE; i += WAVES * 64) {
         const int c = i / (MG * 256), mg = (i >> 8) % MG, mm = mg * 16 + ((i >> 4) & 15), nn = i & 15;
         const int64_t n = n0 + c * 16 + nn;
         float v = 0.f;
-        for (int ks = 0; ks < (int)gridDim.y; ++ks)
-            v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gridDim.y == 4) {       // the usual case, unrolled: all four device-scope loads in flight together (as a loop each one waited for the one
+            float t[4];             // before it: 8 300 cycles for the last-arriving block, block timeline in DESIGN.md); same sum in the same order
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                t[ks] = __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = ((t[0] + t[1]) + t[2]) + t[3];
+        } else {
+            for (int ks = 0; ks < (int)gridDim.y; ++ks)
+                v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (mm < M && n < N && c * 16 + nn < COLS) {
             if (bias) v += bf2f(bias[n]);
             if (residual) v += bf2f(residual[(int64_t)mm * ldr + n]);
@@ -1948,6 +1983,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
         }
     }
     if (threadIdx.x == 0) fix_cnt[blockIdx.x] = 0;
+    DOWN_STAMP(5);
+    DOWN_DUMP();
 }
 
 // ---- narrow-N decode projections (o_proj, down_proj): cross-block split-K with in-kernel fixup -----------------------------------

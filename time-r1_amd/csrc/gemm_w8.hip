@@ -628,8 +628,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(cons
         const int c = i >> 8, mm = (i >> 4) & 15, nn = i & 15;
         const int64_t n = n0 + c * 16 + nn;
         float v = 0.f;
-        for (int ks = 0; ks < (int)gridDim.y; ++ks)
-            v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gridDim.y == 4) {       // unrolled: the four device-scope loads in flight together; same sum in the same order (see gemm_skinny_lds_fix_kernel)
+            float t[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                t[ks] = __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = ((t[0] + t[1]) + t[2]) + t[3];
+        } else {
+            for (int ks = 0; ks < (int)gridDim.y; ++ks)
+                v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (mm < M && n < N) {
             v *= wscale[n];
             if (bias) v += bf2f(bias[n]);

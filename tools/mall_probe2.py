@@ -30,3 +30,19 @@ for name, mk, call, mb in (
         call(ws[0])
     tc, tw = timeit(cold), timeit(warm)
     print("%-36s cold %6.1f us (%5.0f GB/s)   warm %6.1f us (%5.0f GB/s)" % (name, tc, mb / tc * 1e3, tw, mb / tw * 1e3), flush=True)
+if os.environ.get("PROBE"):      # TR1_HIP_LIB=tools/_probe_lib.so PROBE=1: block timeline of ONE down-projection launch (within-block differences)
+    import ctypes
+    import numpy as np
+    from time_r1_amd import hip
+    w = rnd(3584, 18944)
+    buf = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
+    ops.gemm_skinny_fixup(a, w, residual=h); torch.cuda.synchronize()
+    assert hip.lib().cdll.probe_down_set_ptr(ctypes.c_void_p(buf.data_ptr())) == 0
+    ops.gemm_skinny_fixup(a, w, residual=h); torch.cuda.synchronize()
+    hip.lib().cdll.probe_down_set_ptr(ctypes.c_void_p(0))
+    st = buf.cpu().view(256, 8).numpy().astype(np.float64)
+    last = st[:, 5] > 0
+    d = st[:, 1:5] - st[:, 0:4]
+    print("down projection, 256 blocks, median cycles: stream %.0f  barrier %.0f  reduce + park tile %.0f  ticket %.0f;  last-arriving blocks (%d): final sum + store %.0f;  block total %.0f / %.0f (last)"
+          % (np.median(d[:, 0]), np.median(d[:, 1]), np.median(d[:, 2]), np.median(d[:, 3]), int(last.sum()), np.median(st[last, 5] - st[last, 4]),
+             np.median(st[~last, 4] - st[~last, 0]), np.median(st[last, 5] - st[last, 0])))
