@@ -1254,10 +1254,14 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
         // its own ring (and, past 2R stages, its reduction slices - all unused so far), read back as fragments, and only then does the weight
         // stream start: one L2 round trip instead of four, 8 tag look-ups per KiB.  Same fragments in the same order -> same sum of squares.
         float ss = 0.f;
-        const bf16_t* lp = lnw + kb + g * 8;
-        bf16x8_t lv[NST * 2];
-#pragma unroll
-        for (int i = 0; i < NST * 2; ++i) lv[i] = *reinterpret_cast<const bf16x8_t*>(lp + i * 32);
+        // the wave's slice of the norm weight as well: ONE DMA instruction (1 KiB = 512 columns from kb on; lanes past the end of lnw re-read its
+        // last 16 bytes) into a private KiB behind the rings instead of 2 NST vector loads per lane
+        char* lnw_lds = rings + 8 * R * STAGE + wave * 1024;
+        {
+            int64_t col = kb + lane * 8;
+            if (col + 8 > K) col = K - 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)(lnw + col), (lptr_t)lnw_lds, 16, 0, 0);
+        }
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             char* dst = st < 2 * R ? ring + st * 2048 : reinterpret_cast<char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
@@ -1274,7 +1278,8 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             const int st = i >> 1, ks = i & 1;
             const char* sbx = st < 2 * R ? ring + st * 2048 : reinterpret_cast<const char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
             const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(sbx + u * 128 + (((ks * 4 + g) ^ keyA(u)) << 4));
-            u32x4_t f = __builtin_bit_cast(u32x4_t, scale_frag_sumsq(xv, lv[i], ss));
+            const bf16x8_t lvi = *reinterpret_cast<const bf16x8_t*>(lnw_lds + (i * 32 + g * 8) * 2);
+            u32x4_t f = __builtin_bit_cast(u32x4_t, scale_frag_sumsq(xv, lvi, ss));
             asm volatile("" : "+v"(f));
             xr[0][i] = __builtin_bit_cast(bf16x8_t, f);
         }
@@ -1429,7 +1434,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     if (!glu && M <= 16 && head_lds && glu_lds && N >= 65536 && N % 32 == 0 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         // wide plain projection (the lm_head) through the LDS stream: 256 persistent blocks x 8 waves, column pairs (n, n + N/2)
         constexpr int RING = 3;
-        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;
         static int n_cu_h = 0;
         if (!n_cu_h) {
             hipDeviceProp_t prop; int dev = 0;
@@ -1452,7 +1457,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
         // 17..32 rows (config 4 decodes 2 x 16 rollouts): two row groups per wave against the SAME LDS stage, ring of 3, single reduction
         // buffer (132 KB of LDS): 77.4 -> 52.8 us at 32 x 18944 x 3584 (5.1 TB/s of weights) over the register-fragment form.
         constexpr int RING = 3;
-        const size_t dyn1 = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        const size_t dyn1 = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;      // + the waves' norm-weight KiB
         const size_t dyn2 = 8 * RING * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float);
         static int n_cu = 0;
         if (!n_cu) {
@@ -1514,7 +1519,7 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
     const int64_t nst = K / 512;
     if (M <= 16 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         constexpr int RING = 4;
-        const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float);
+        const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;
         static bool attr_q = false;
         if (!attr_q) {
 #define QL_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
