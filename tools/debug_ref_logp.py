@@ -1,3 +1,5 @@
+"""Round 3 debugging aid: policy vs reference log-probs of one synthetic prompt through the engine (found the fused lm_head epilogue bug at V = 151936).
+   python tools/debug_ref_logp.py [qwen2-vl-2b|qwen2-vl-7b]"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
