@@ -1235,14 +1235,17 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
 #define GLU_NEXT_PAIR() do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { pg[j] += pair_step; pu[j] += pair_step; } } while (0)
     static_assert(NST <= 7, "stage offsets are enumerated up to 7");
     constexpr bool XDMA = (MG == 1) && (2 * R + NRED >= NST);   // round 3: this wave's x slice goes through its own (still empty) ring first
-#define GLU_PROLOGUE() do {                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < R - 1; ++i) {      /* prologue: items 0 .. R-2 */                  \
+#define GLU_PROLOGUE(I0, I1) do {                                                                                \
+        _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {    /* prologue: items 0 .. R-2 */                  \
             if (i < total) {                                                                                     \
                 if (i > 0 && i % NST == 0) GLU_NEXT_PAIR();                                                      \
                 GLU_ISSUE_ST(i % NST);                                                                           \
             }                                                                                                    \
         } } while (0)
-    if (!XDMA) GLU_PROLOGUE();
+    // x staging that leaves ring slot 0 to the FIRST weight stage (requested together with the x copy): slots 1 .. R-1, the reduction slices and one
+    // extra 2 KiB per wave behind the norm-weight area
+    constexpr bool XSLOT0 = XDMA && (2 * (R - 1) + NRED + 1 >= NST) && R >= 3;
+    if (!XDMA) GLU_PROLOGUE(0, R - 1);
     GLU_STAMP(1);
     // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares - built AFTER the first weight stages were
     // issued, so the HBM stream starts at kernel entry instead of waiting for this L2 round trip
@@ -1262,9 +1265,16 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             if (col + 8 > K) col = K - 8;
             __builtin_amdgcn_global_load_lds((gptr_t)(lnw + col), (lptr_t)lnw_lds, 16, 0, 0);
         }
+        char* const x_extra = rings + 8 * R * STAGE + 8 * 1024 + wave * 2048;
+        auto x_stage = [&](int st) -> char* {
+            if (!XSLOT0) return st < 2 * R ? ring + st * 2048 : reinterpret_cast<char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
+            if (st < 2 * (R - 1)) return ring + STAGE + st * 2048;
+            if (st - 2 * (R - 1) < NRED) return reinterpret_cast<char*>(red + ((st - 2 * (R - 1)) * 8 + wave) * REDW);
+            return x_extra;
+        };
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            char* dst = st < 2 * R ? ring + st * 2048 : reinterpret_cast<char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
+            char* dst = x_stage(st);
 #pragma unroll
             for (int jx = 0; jx < 2; ++jx) {
                 const int r = 8 * jx + (lane >> 3);
@@ -1272,19 +1282,24 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + jx * 1024), 16, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (XSLOT0) {
+            GLU_PROLOGUE(0, 1);                                           // the first weight stage travels while x' is built
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // everything but that stage's four DMA instructions has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < NST * 2; ++i) {
             const int st = i >> 1, ks = i & 1;
-            const char* sbx = st < 2 * R ? ring + st * 2048 : reinterpret_cast<const char*>(red + ((st - 2 * R) * 8 + wave) * REDW);
+            const char* sbx = x_stage(st);
             const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(sbx + u * 128 + (((ks * 4 + g) ^ keyA(u)) << 4));
             const bf16x8_t lvi = *reinterpret_cast<const bf16x8_t*>(lnw_lds + (i * 32 + g * 8) * 2);
             u32x4_t f = __builtin_bit_cast(u32x4_t, scale_frag_sumsq(xv, lvi, ss));
             asm volatile("" : "+v"(f));
             xr[0][i] = __builtin_bit_cast(bf16x8_t, f);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the ring is free again: start the weight stream
-        GLU_PROLOGUE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the ring is free again: start (continue) the weight stream
+        if (XSLOT0) GLU_PROLOGUE(1, R - 1); else GLU_PROLOGUE(0, R - 1);
         float v = ss;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
@@ -1434,7 +1449,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     if (!glu && M <= 16 && head_lds && glu_lds && N >= 65536 && N % 32 == 0 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         // wide plain projection (the lm_head) through the LDS stream: 256 persistent blocks x 8 waves, column pairs (n, n + N/2)
         constexpr int RING = 3;
-        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;
+        const size_t dyn = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192 + 16384;
         static int n_cu_h = 0;
         if (!n_cu_h) {
             hipDeviceProp_t prop; int dev = 0;
@@ -1457,7 +1472,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
         // 17..32 rows (config 4 decodes 2 x 16 rollouts): two row groups per wave against the SAME LDS stage, ring of 3, single reduction
         // buffer (132 KB of LDS): 77.4 -> 52.8 us at 32 x 18944 x 3584 (5.1 TB/s of weights) over the register-fragment form.
         constexpr int RING = 3;
-        const size_t dyn1 = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;      // + the waves' norm-weight KiB
+        const size_t dyn1 = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192 + 16384;      // + the waves' norm-weight KiB + one x stage each
         const size_t dyn2 = 8 * RING * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float);
         static int n_cu = 0;
         if (!n_cu) {
@@ -1519,7 +1534,7 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
     const int64_t nst = K / 512;
     if (M <= 16 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         constexpr int RING = 4;
-        const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;
+        const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;      // (ring of 4: the x staging fits without the extra stage area... see XSLOT0)
         static bool attr_q = false;
         if (!attr_q) {
 #define QL_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
