@@ -786,3 +786,40 @@ def test_decode_projections_x_through_lds_bit_identical(tmp_path):
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)
+
+
+def test_w8a8_decode_projections_x_through_lds_bit_identical(tmp_path):
+    """Round 3, fp8 sampling policy: the W8A8 register kernel with the activation rows / norm weight through one LDS copy per block (TR1_W8A8_XLDS, default
+    on) returns the bits of the vector-load form - norm + projection (qkv / lm_head shape), plain projection with residual (o), 7B and 2B widths, ragged rows."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import torch, sys
+        sys.path.insert(0, %r)
+        import time_r1_amd
+        from time_r1_amd.ops import HipOps
+        ops = HipOps("cuda:0")
+        g = torch.Generator().manual_seed(9)
+        outs = []
+        for K, N in ((3584, 4608), (1536, 2048), (3584, 3584)):
+            w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
+            q, sc = ops.quantize_fp8_rows(w)
+            for M in (16, 3):
+                x = torch.randn(M, K, generator=g).bfloat16().cuda()
+                lnw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
+                b = torch.randn(N, generator=g).bfloat16().cuda()
+                res = torch.randn(M, N, generator=g).bfloat16().cuda()
+                outs.append(ops.gemm_w8(x, q, sc, lnw=lnw, eps=1e-6, bias=b, a8=True).cpu())
+                outs.append(ops.gemm_w8(x, q, sc, residual=res, a8=True).cpu())
+        assert all(torch.isfinite(o.float()).all() for o in outs)
+        torch.save(outs, sys.argv[1])
+        print("ok")
+    """) % root
+    res = []
+    for i, env in enumerate((dict(TR1_W8A8_XLDS="0"), dict())):
+        f = str(tmp_path / ("w8_%d.pt" % i))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+        res.append(torch.load(f))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

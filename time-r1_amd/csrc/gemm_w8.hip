@@ -188,7 +188,10 @@ TR1_DEV void quant16_fp8(const float (&v)[16], float mul, int (&o)[4]) {
     }
 }
 
-template <int WAVES, int UNROLL, int NCOL, int MG, bool NORM, bool GLU>
+// XLDS (round 3, MG = 1): the bf16 activation rows and the norm weight - 8 of the 12 vector loads of a k-step at NCOL = 2, all in the MFMA operand
+// layout that costs 64 L1 tag look-ups per KiB (see gemm.hip) - reach the lanes through ONE DMA copy into LDS per block: x as [K/128 segments][16 rows]
+// [256 bytes] with chunk c of row r at c ^ r, lnw as it is.  Only the fp8 weights stay on the vector-memory path.  Same values, same order.
+template <int WAVES, int UNROLL, int NCOL, int MG, bool NORM, bool GLU, bool XLDS = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw,
                                                                       const unsigned char* __restrict__ W, const float* __restrict__ wscale,
                                                                       bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16
     constexpr int NOUT = GLU ? NCOL / 2 : NCOL;
     __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][MG][16][17];
     __shared__ float ssred[WAVES][MG][16];
+    extern __shared__ __attribute__((aligned(1024))) char w8_xs[];             // XLDS: x image (K * 32 bytes), then lnw (K * 2 bytes)
+    static_assert(!XLDS || MG == 1, "the LDS copy of x holds 16 rows");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane & 15, g = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 16 * NOUT;
@@ -228,6 +233,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16
     // the lane that holds the other 16 values of my blocks, and the lane whose block exponents I have to present to the MFMA
     const int partner = lane ^ 16;
     const int src_lane = u + 16 * (2 * (g & 1));             // first lane of the pair that holds block g (its half g / 2)
+    const unsigned xs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)w8_xs;
+    const unsigned ls_base = xs_base + (unsigned)(K * 32);
+    if (XLDS) {
+        const int n_x = (int)(K >> 5), n_l = NORM ? (int)((K * 2 + 1023) >> 10) : 0;      // 1 KiB per instruction: 4 rows x 256 bytes of x / 512 columns of lnw
+        const int w0 = __builtin_amdgcn_readfirstlane(wave);
+        for (int i = w0; i < n_x; i += WAVES) {
+            const int r = (i & 3) * 4 + (lane >> 4);
+            const unsigned off = (unsigned)((r < M ? r : M - 1) * (int)ldx + (i >> 2) * 128 + (((lane & 15) ^ r) << 3)) * 2u;
+            const unsigned dst = xs_base + (unsigned)i * 1024u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(X) : "memory", "m0");
+        }
+        for (int i = w0; i < n_l; i += WAVES) {
+            int64_t col = (int64_t)i * 512 + lane * 8;
+            if (col + 8 > K) col = K - 8;
+            const unsigned off = (unsigned)col * 2u, dst = ls_base + (unsigned)i * 1024u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(lnw) : "memory", "m0");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     for (int64_t s = s0; s < s1; s += UNROLL) {
         u32x4_t wq[UNROLL][NCOL][2];
         u32x4_t xa[UNROLL][MG][2][2], la[UNROLL][2][2];
@@ -239,6 +265,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int c = 0; c < NCOL; ++c) wq[q][c][h] = *reinterpret_cast<const u32x4_t*>(wp[c] + k + h * 64);
+                if (XLDS) {
+                    typedef const __attribute__((address_space(3))) u32x4_t* xs_ptr_t;
+                    const unsigned xrow = xs_base + (unsigned)st * 4096u + (unsigned)u * 256u;
+                    xa[q][0][h][0] = *(xs_ptr_t)(uintptr_t)(xrow + (unsigned)(((h * 8 + g * 2) ^ u) << 4));
+                    xa[q][0][h][1] = *(xs_ptr_t)(uintptr_t)(xrow + (unsigned)(((h * 8 + g * 2 + 1) ^ u) << 4));
+                    if (NORM) {
+                        const unsigned lrow = ls_base + (unsigned)(k + h * 64 + g * 16) * 2u;
+                        la[q][h][0] = *(xs_ptr_t)(uintptr_t)lrow;
+                        la[q][h][1] = *(xs_ptr_t)(uintptr_t)(lrow + 16u);
+                    }
+                } else {
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
                     xa[q][mg][h][0] = *reinterpret_cast<const u32x4_t*>(xp[mg] + k + h * 64);
@@ -247,6 +284,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16
                 if (NORM) {
                     la[q][h][0] = *reinterpret_cast<const u32x4_t*>(lp + k + h * 64);
                     la[q][h][1] = *reinterpret_cast<const u32x4_t*>(lp + k + h * 64 + 8);
+                }
                 }
             }
         }
@@ -392,29 +430,45 @@ __global__ __launch_bounds__(NW * 64) void norm_glu_lds_f8_kernel(const bf16_t* 
     } while (0)
 #define G8_ISSUE_ST(ST) do { switch (ST) { case 0: G8_ISSUE(0); break; case 1: G8_ISSUE(1); break; case 2: G8_ISSUE(2); break; default: G8_ISSUE(3); break; } } while (0)
 #define G8_NEXT_PAIR() do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { pg[j] += pair_step; pu[j] += pair_step; } } while (0)
+    // ---- block-quantised activation fragments of this wave's k-slice (once per block).  Round 3 (same finding as norm_glu_lds_kernel in gemm.hip:
+    // 32 vector loads per lane in the MFMA operand layout = 64 L1 tag look-ups per KiB, in dependent batches, while only R-1 weight stages were in
+    // flight): the wave's x slice (16 rows x 512 columns = NST stages of 16 rows x 256 bytes) and its norm-weight slice are copied by DMA - x into the
+    // wave's own still empty ring (+ one 4 KiB stage behind the rings when R < NST), lnw into a private KiB - and read back from LDS; the weight
+    // stream starts right after.  Same values in the same order.
+    static_assert(R + 1 >= NST, "x staging: ring + one extra stage");
+    char* const x_extra = rings + NW * R * STAGE + wave * STAGE;
+    char* const lnw_lds = rings + NW * R * STAGE + NW * STAGE + wave * 1024;
+    {
+        int64_t col = kb + lane * 8;
+        if (col + 8 > K) col = K - 8;
+        __builtin_amdgcn_global_load_lds((w8_gptr_t)(lnw + col), (w8_lptr_t)lnw_lds, 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < R - 1; ++i) {
-        if (i < total) {
-            if (i > 0 && i % NST == 0) G8_NEXT_PAIR();
-            G8_ISSUE_ST(i % NST);
+        for (int st = 0; st < NST; ++st) {
+            char* dst = st < R ? ring + st * STAGE : x_extra;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {                              // 4 rows x 256 bytes per instruction; row r keeps logical chunk c at c ^ r
+                const int r = 4 * i4 + (lane >> 4);
+                const bf16_t* src = X + (int64_t)(r < M ? r : M - 1) * ldx + kb + st * 128 + (((lane & 15) ^ r) << 3);
+                __builtin_amdgcn_global_load_lds((w8_gptr_t)src, (w8_lptr_t)(dst + i4 * 1024), 16, 0, 0);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // ---- block-quantised activation fragments of this wave's k-slice (once per block), built behind the first weight stages
     i32x8_t xq[NST]; int xs[NST];
     {
         float ss = 0.f;
         const int partner = lane ^ 16, src_lane = u + 16 * (2 * (g & 1));
-        const bf16_t* xp = X + (int64_t)(u < M ? u : M - 1) * ldx + kb + g * 16;
-        const bf16_t* lp = lnw + kb + g * 16;
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
+            const char* xst = (st < R ? ring + st * STAGE : x_extra) + u * 256;
             float v[2][16], am[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 am[h] = 0.f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xp + st * 128 + h * 64 + j * 8), lv = *reinterpret_cast<const u32x4_t*>(lp + st * 128 + h * 64 + j * 8);
+                    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(xst + (((h * 8 + g * 2 + j) ^ u) << 4));
+                    const u32x4_t lv = *reinterpret_cast<const u32x4_t*>(lnw_lds + (st * 128 + h * 64 + g * 16 + j * 8) * 2);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float a = bflo(xv[e]), b = bfhi(xv[e]);
@@ -444,6 +498,14 @@ __global__ __launch_bounds__(NW * 64) void norm_glu_lds_f8_kernel(const bf16_t* 
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         if (g == 0) ssq[wave * 16 + u] = ss;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the ring is free again: start the weight stream
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) {
+        if (i < total) {
+            if (i > 0 && i % NST == 0) G8_NEXT_PAIR();
+            G8_ISSUE_ST(i % NST);
+        }
     }
     W8_BARRIER();
     float rstd;
@@ -779,12 +841,12 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
         if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nw == 7 || nw == 4 || nw == 3) && N % 16 == 0) {
             constexpr int RING = 3;
             static int n_cu = 0;
-            const size_t dyn = (size_t)nw * RING * 4096 + (2 * nw * 2 * 16 * 17 + nw * 16) * sizeof(float);
+            const size_t dyn = (size_t)nw * RING * 4096 + (2 * nw * 2 * 16 * 17 + nw * 16) * sizeof(float) + (size_t)nw * (4096 + 1024);      // + one x stage and the norm-weight KiB per wave
             if (!n_cu) {
                 hipDeviceProp_t prop; int dev = 0;
                 hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
                 n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-                const int mx = 7 * RING * 4096 + (2 * 7 * 2 * 16 * 17 + 7 * 16) * (int)sizeof(float);
+                const int mx = 7 * RING * 4096 + (2 * 7 * 2 * 16 * 17 + 7 * 16) * (int)sizeof(float) + 7 * (4096 + 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_f8_kernel<7, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_f8_kernel<4, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_f8_kernel<3, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
@@ -800,9 +862,22 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
     }
     if (glu) { if (mg == 1) W8(4, 2, 4, 1, true, true); else if (mg == 2) W8(4, 2, 4, 2, true, true); else W8(4, 1, 2, 4, true, true); }
     else if (lnw && N >= 100000) { if (mg == 1) W8(4, 2, 4, 1, true, false); else if (mg == 2) W8(4, 2, 4, 2, true, false); else W8(4, 1, 2, 4, true, false); }
-    else if (lnw) W8_MG(4, 2, 2, true, false);
-    else if (K >= 8192) W8_MG(8, 2, 1, false, false);
-    else W8_MG(4, 2, 1, false, false);
+    else {
+        static int xlds = -1;                        // TR1_W8A8_XLDS=0: activation rows / norm weight through the vector-memory path (A/B measurements)
+        if (xlds < 0) { const char* e = getenv("TR1_W8A8_XLDS"); xlds = e ? atoi(e) : 1; }
+        const bool x_ok = xlds && mg == 1 && K < 8192 && K % 128 == 0 && K * 34 <= 128 * 1024 && (int64_t)M * ldx * 2 < 0x7fffffffLL;
+#define W8X(NC, NRM) do {                                                                                                                        \
+            static bool attr_ = false;                                                                                                           \
+            if (!attr_) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_w8a8_kernel<4, 2, NC, 1, NRM, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_ = true; } \
+            hipLaunchKernelGGL((gemm_skinny_w8a8_kernel<4, 2, NC, 1, NRM, false, true>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC))), dim3(256), (size_t)(K * 34), s, \
+                               (const bf16_t*)x, (const bf16_t*)lnw, (const unsigned char*)W_fp8, (const float*)wscale, (bf16_t*)out, (const bf16_t*)bias,  \
+                               (const bf16_t*)residual, (int)M, N, K, ldx, ldw, ldc, ldr, eps, N);                                              \
+        } while (0)
+        if (lnw) { if (x_ok) W8X(2, true); else W8_MG(4, 2, 2, true, false); }
+        else if (K >= 8192) W8_MG(8, 2, 1, false, false);
+        else { if (x_ok) W8X(1, false); else W8_MG(4, 2, 1, false, false); }
+#undef W8X
+    }
 #undef W8_MG
 #undef W8
     TR1_LAUNCH_CHECK();
