@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                                            case 4: GLU_ISSUE(4); break; case 5: GLU_ISSUE(5); break; default: GLU_ISSUE(6); break; } } while (0)
 #define GLU_NEXT_PAIR() do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { pg[j] += pair_step; pu[j] += pair_step; } } while (0)
     static_assert(NST <= 7, "stage offsets are enumerated up to 7");
-    constexpr bool XDMA = (MG == 1) && (2 * R + NRED >= NST);   // round 3: this wave's x slice goes through its own (still empty) ring first
+    constexpr bool XDMA = (MG <= 2) && (2 * R + NRED >= NST);   // round 3: this wave's x slice goes through its own (still empty) ring first (MG = 2: one 16-row group after the other)
 #define GLU_PROLOGUE(I0, I1) do {                                                                                \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {    /* prologue: items 0 .. R-2 */                  \
             if (i < total) {                                                                                     \
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
         } } while (0)
     // x staging that leaves ring slot 0 to the FIRST weight stage (requested together with the x copy): slots 1 .. R-1, the reduction slices and one
     // extra 2 KiB per wave behind the norm-weight area
-    constexpr bool XSLOT0 = XDMA && (2 * (R - 1) + NRED + 1 >= NST) && R >= 3;
+    constexpr bool XSLOT0 = XDMA && MG == 1 && (2 * (R - 1) + NRED + 1 >= NST) && R >= 3;
     if (!XDMA) GLU_PROLOGUE(0, R - 1);
     GLU_STAMP(1);
     // ---- x' fragments of this wave's k-slice (once per block) and the row sums of squares - built AFTER the first weight stages were
@@ -1256,7 +1256,6 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
         // in flight meanwhile (block timeline).  Here the wave's x slice (16 rows x K/8 columns = NST stages of 2 KiB) is copied by DMA into
         // its own ring (and, past 2R stages, its reduction slices - all unused so far), read back as fragments, and only then does the weight
         // stream start: one L2 round trip instead of four, 8 tag look-ups per KiB.  Same fragments in the same order -> same sum of squares.
-        float ss = 0.f;
         // the wave's slice of the norm weight as well: ONE DMA instruction (1 KiB = 512 columns from kb on; lanes past the end of lnw re-read its
         // last 16 bytes) into a private KiB behind the rings instead of 2 NST vector loads per lane
         char* lnw_lds = rings + 8 * R * STAGE + wave * 1024;
@@ -1273,12 +1272,15 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             return x_extra;
         };
 #pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+        float ss = 0.f;
+#pragma unroll
         for (int st = 0; st < NST; ++st) {
             char* dst = x_stage(st);
 #pragma unroll
             for (int jx = 0; jx < 2; ++jx) {
-                const int r = 8 * jx + (lane >> 3);
-                const bf16_t* src = X + (int64_t)(r < M ? r : M - 1) * ldx + kb + st * 64 + (((lane & 7) ^ keyA(r)) << 3);
+                const int r = mg * 16 + 8 * jx + (lane >> 3);
+                const bf16_t* src = X + (int64_t)(r < M ? r : M - 1) * ldx + kb + st * 64 + (((lane & 7) ^ keyA(r & 15)) << 3);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + jx * 1024), 16, 0, 0);
             }
         }
@@ -1296,14 +1298,15 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             const bf16x8_t lvi = *reinterpret_cast<const bf16x8_t*>(lnw_lds + (i * 32 + g * 8) * 2);
             u32x4_t f = __builtin_bit_cast(u32x4_t, scale_frag_sumsq(xv, lvi, ss));
             asm volatile("" : "+v"(f));
-            xr[0][i] = __builtin_bit_cast(bf16x8_t, f);
+            xr[mg][i] = __builtin_bit_cast(bf16x8_t, f);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the ring is free again: start (continue) the weight stream
-        if (XSLOT0) GLU_PROLOGUE(1, R - 1); else GLU_PROLOGUE(0, R - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the ring is free again: next row group / start (continue) the weight stream
         float v = ss;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (g == 0) ssq[wave * MG * 16 + u] = v;
+        if (g == 0) ssq[(wave * MG + mg) * 16 + u] = v;
+        }
+        if (XSLOT0) GLU_PROLOGUE(1, R - 1); else GLU_PROLOGUE(0, R - 1);
     } else
     {
         float ss[MG];
@@ -1402,7 +1405,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                 const int64_t n = row_base + nn, nb = n + (qe.hd >> 1);
                 float vb = __fmul_rn(v2, rstd);
                 if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[nb])); }
-                if (mm < M && n < N) qkv_epilogue_store(qe, mm, qkv_h, qkv_j * 16 + nn, bf2f(f2bf(v)), bf2f(f2bf(vb)));
+                if (mgi * 16 + mm < M && n < N) qkv_epilogue_store(qe, mgi * 16 + mm, qkv_h, qkv_j * 16 + nn, bf2f(f2bf(v)), bf2f(f2bf(vb)));
             } else if (PLAIN) {
                 const int64_t n = (p0 + pi) * 16 + nn;
                 float vb = __fmul_rn(v2, rstd);
@@ -1473,7 +1476,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
         // buffer (132 KB of LDS): 77.4 -> 52.8 us at 32 x 18944 x 3584 (5.1 TB/s of weights) over the register-fragment form.
         constexpr int RING = 3;
         const size_t dyn1 = 8 * RING * 4096 + (2 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192 + 16384;      // + the waves' norm-weight KiB + one x stage each
-        const size_t dyn2 = 8 * RING * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float);
+        const size_t dyn2 = 8 * RING * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float) + 8192;
         static int n_cu = 0;
         if (!n_cu) {
             hipDeviceProp_t prop; int dev = 0;
@@ -1532,6 +1535,22 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
     static int qlds = -1;
     if (qlds < 0) { const char* e = getenv("TR1_QKV_LDS"); qlds = e ? atoi(e) : 1; }
     const int64_t nst = K / 512;
+    if (M > 16 && M <= 32 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {      // 17 .. 32 rows (config 4): two row groups per wave, ring of 3
+        constexpr int RING2 = 3;
+        const size_t dyn = 8 * RING2 * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float) + 8192;
+        static bool attr_q2 = false;
+        if (!attr_q2) {
+#define QL2_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING2, 1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
+            QL2_ATTR(7); QL2_ATTR(4); QL2_ATTR(3);
+#undef QL2_ATTR
+            attr_q2 = true;
+        }
+#define QL2_LAUNCH(NSTV) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING2, 1, 2, 1>), grid, dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)Wqkv, \
+                                            (bf16_t*)nullptr, (int)M, N, K, ldx, ldw, (int64_t)0, eps, (int64_t)(head_dim / 2), (const bf16_t*)bias, qe)
+        if (nst == 7) QL2_LAUNCH(7); else if (nst == 4) QL2_LAUNCH(4); else QL2_LAUNCH(3);
+#undef QL2_LAUNCH
+        TR1_LAUNCH_CHECK();
+    }
     if (M <= 16 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         constexpr int RING = 4;
         const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 16 * 17 + 8 * 16) * sizeof(float) + 8192;      // (ring of 4: the x staging fits without the extra stage area... see XSLOT0)
