@@ -250,21 +250,46 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_w8a8_kernel(const bf16
             const unsigned off = (unsigned)col * 2u, dst = ls_base + (unsigned)i * 1024u;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(off), "s"(lnw) : "memory", "m0");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // XLDS: the weight loads of a trip are requested one trip ahead (wn), the first ones BEFORE the wait for the x copy - only they may still be in
+    // flight when the copy has landed (counted vmcnt), so the weight stream starts at kernel entry
+    u32x4_t wn[UNROLL][NCOL][2];
+#define W8_LOADW(dst, s_)                                                                                         \
+    do { _Pragma("unroll") for (int q = 0; q < UNROLL; ++q) {                                                     \
+        const int64_t k__ = ((s_) + q < s1 ? (s_) + q : s1 - 1) * 128;                                            \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                             \
+        _Pragma("unroll") for (int c = 0; c < NCOL; ++c) dst[q][c][h] = *reinterpret_cast<const u32x4_t*>(wp[c] + k__ + h * 64); } } while (0)
+    if (XLDS) {
+        static_assert(!XLDS || (UNROLL * NCOL * 2 == 4 || UNROLL * NCOL * 2 == 8), "counted wait below");
+        if (s0 < s1) {
+            W8_LOADW(wn, s0);
+            if (UNROLL * NCOL * 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     for (int64_t s = s0; s < s1; s += UNROLL) {
         u32x4_t wq[UNROLL][NCOL][2];
         u32x4_t xa[UNROLL][MG][2][2], la[UNROLL][2][2];
+        if (XLDS) {
+#pragma unroll
+            for (int q = 0; q < UNROLL; ++q)
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) { wq[q][c][0] = wn[q][c][0]; wq[q][c][1] = wn[q][c][1]; }
+            if (s + UNROLL < s1) W8_LOADW(wn, s + UNROLL);
+        }
 #pragma unroll
         for (int q = 0; q < UNROLL; ++q) {
             const int64_t st = s + q < s1 ? s + q : s1 - 1;
             const int64_t k = st * 128;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if (!XLDS) {
 #pragma unroll
                 for (int c = 0; c < NCOL; ++c) wq[q][c][h] = *reinterpret_cast<const u32x4_t*>(wp[c] + k + h * 64);
+                }
                 if (XLDS) {
                     typedef const __attribute__((address_space(3))) u32x4_t* xs_ptr_t;
                     const unsigned xrow = xs_base + (unsigned)st * 4096u + (unsigned)u * 256u;
