@@ -540,7 +540,7 @@ def test_video_preprocess_matches_hf_processor_golden(hip_ops):
                                        # 17 .. 32 rows: the two-fragment LDS-streamed form (config 4: two prompts x G = 16 rows per decode step)
                                        (32, 18944, 3584, True), (17, 4112, 3584, True), (20, 11008, 2048, True), (29, 48, 1536, True),
                                        # round 3: wide plain projection (the lm_head) through the LDS stream - column pairs (n, n + N/2), with bias, ragged rows, both vocabularies
-                                       (16, 152064, 3584, False), (7, 151936, 1536, False), (1, 65536, 2048, False)])
+                                       (16, 152064, 3584, False), (7, 151936, 1536, False), (1, 65536, 2048, False), (32, 152064, 3584, False), (19, 65536, 1536, False)])
 def test_norm_gemm_fused(hip_ops, ref_ops, M, N, K, glu):
     """rmsnorm folded into the decode GEMM (and SwiGLU into its epilogue) vs the unfused oracle composition."""
     x, lnw = rnd(M, K, seed=1, scale=2.0), (1.0 + 0.1 * rnd(K, seed=2).float()).to(BF16)

@@ -1410,7 +1410,8 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
                 const int64_t n = (p0 + pi) * 16 + nn;
                 float vb = __fmul_rn(v2, rstd);
                 if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[n + up_off])); }
-                if (mm < M && n < up_off) { C[(int64_t)mm * ldc + n] = f2bf(v); if (n + up_off < N) C[(int64_t)mm * ldc + n + up_off] = f2bf(vb); }
+                const int mrow = mgi * 16 + mm;
+                if (mrow < M && n < up_off) { C[(int64_t)mrow * ldc + n] = f2bf(v); if (n + up_off < N) C[(int64_t)mrow * ldc + n + up_off] = f2bf(vb); }
             } else {
             const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
             const int64_t n = (p0 + pi) * 16 + nn;
@@ -1449,6 +1450,27 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
     const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
     static int head_lds = -1;                        // TR1_HEAD_LDS=0: the lm_head stays on the register-fragment kernel (A/B measurements)
     if (head_lds < 0) { const char* e = getenv("TR1_HEAD_LDS"); head_lds = e ? atoi(e) : 1; }
+    if (!glu && M > 16 && M <= 32 && head_lds && glu_lds && N >= 65536 && N % 32 == 0 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
+        // 17 .. 32 rows (config 4): two row groups per wave against the same LDS stage, single reduction buffer
+        constexpr int RING = 3;
+        const size_t dyn = 8 * RING * 4096 + (1 * 8 * 2 * 2 * 16 * 17 + 8 * 2 * 16) * sizeof(float) + 8192;
+        static int n_cu_h2 = 0;
+        if (!n_cu_h2) {
+            hipDeviceProp_t prop; int dev = 0;
+            hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
+            n_cu_h2 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+#define HL2_ATTR(NSTV) hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_glu_lds_kernel<NSTV, RING, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)
+            HL2_ATTR(7); HL2_ATTR(4); HL2_ATTR(3);
+#undef HL2_ATTR
+        }
+        const int64_t NPh = N / 32;
+        const unsigned gridh = (unsigned)(NPh < n_cu_h2 ? NPh : n_cu_h2);
+#define HL2_LAUNCH(NSTV) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 1, 2, 2>), dim3(gridh), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)lnw, (const bf16_t*)W, \
+                                            (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N / 2, (const bf16_t*)bias, QkvEpi{})
+        if (nst == 7) HL2_LAUNCH(7); else if (nst == 4) HL2_LAUNCH(4); else HL2_LAUNCH(3);
+#undef HL2_LAUNCH
+        TR1_LAUNCH_CHECK();
+    }
     if (!glu && M <= 16 && head_lds && glu_lds && N >= 65536 && N % 32 == 0 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         // wide plain projection (the lm_head) through the LDS stream: 256 persistent blocks x 8 waves, column pairs (n, n + N/2)
         constexpr int RING = 3;
