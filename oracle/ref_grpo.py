@@ -57,3 +57,22 @@ def grpo_step(W, W_ref, cfg, prompt_ids, pixel_values, grid_thw, completion_ids,
         metrics["kl"] = ((kl * mask).sum(1) / mask.sum(1)).mean().item()                                 # :762-768
     metrics["generation_entropy"] = ((ent * mask).sum(1) / mask.sum(1).clamp(min=1)).mean().item()       # :769-777
     return dict(loss=loss, logp=logp, entropy=ent, ref_logp=ref_logp, advantages=adv, mask=mask, metrics=metrics, rewards=rewards)
+
+
+def ft_extra_metrics(logp, advantages, mask, completions, metric_funcs, metric_kwargs, eps_low=0.2, eps_high=0.2):
+    """What `TimeR1_Trainer_ft.compute_loss` logs on top of the base trainer (reference timer1_trainer_ft.py, single process so every
+    `gather_for_metrics` is the identity): `metrics/<fn>` = mean over the G completions of each metric callback (:670-691, :789-794) and
+    the clip ratios of the PPO-clip branch (:820-842; `coef_1 = exp(logp - logp.detach())` is identically 1, so they are 0 by construction)."""
+    out = {}
+    for fn in metric_funcs:
+        vals = torch.tensor(fn(prompts=None, completions=completions, **metric_kwargs), dtype=torch.float32)       # :685-691
+        out["metrics/" + fn.__name__] = vals.mean().item()                                                          # :789-794
+    coef_1 = torch.exp(logp - logp.detach())                                                                        # :756
+    adv = advantages[:, None]
+    low = (coef_1 < 1 - eps_low) & (adv < 0)                                                                        # :821
+    high = (coef_1 > 1 + eps_high) & (adv > 0)                                                                      # :822-824
+    tot = mask.sum()
+    low_r, high_r, reg_r = (low * mask).sum() / tot, (high * mask).sum() / tot, ((low | high) * mask).sum() / tot   # :827-829
+    out.update({"clip_ratio/low_mean": low_r.item(), "clip_ratio/low_min": low_r.item(), "clip_ratio/high_mean": high_r.item(),     # :831-842
+                "clip_ratio/high_max": high_r.item(), "clip_ratio/region_mean": reg_r.item()})
+    return out

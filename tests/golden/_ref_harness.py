@@ -79,6 +79,15 @@ def load_ref_main():
     return mod
 
 
+def load_ref_finetune():
+    """finetune.py (config 4's entry point): its own copies of the reward / metric registries (finetune.py:716-727)."""
+    install_stubs()
+    spec = importlib.util.spec_from_file_location("ref_finetune", REF + "/finetune.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load_ref_vision_process():
     install_stubs()
     spec = importlib.util.spec_from_file_location("ref_vision_process", REF + "/src/utils/vision_process.py")

@@ -190,6 +190,83 @@ def run_case(name, use_grpo, beta, force_eos, seed, G=4, C=8, model="qwen2_vl", 
     print(name, "loss", float(loss), "metrics", {k: round(v[0], 5) for k, v in tr._metrics.items()}, os.path.getsize(out), "bytes")
 
 
+def run_case_ft(name, force_eos, seed, G=4, C=8, frames_shape=(6, 3, 56, 140), prompt_type="v2"):
+    """One micro-step of the UNMODIFIED `TimeR1_Trainer_ft.compute_loss` (/root/reference/src/time_r1/rl/timer1_trainer_ft.py:536-852) the way
+    `finetune.py:693-713` configures it for config 4: Qwen2.5-VL, PPO-clip loss (`--use_grpo false`), beta = 0 (no reference model), the dataset
+    row carrying pre-decoded frames (`video_inputs` / `video_kwargs`, finetune.py:594-623), `metric_funcs` = finetune.py's registry.  Besides what
+    run_case stores, the fixture keeps the chat conversation `make_conversation_video` produced (prompt template v2/v3 exist only in `_ft`) and every
+    `metrics/<fn>` / `clip_ratio/*` value.  (`use_grpo=True` cannot be captured from `_ft`: :821 reads `coef_1`, which only the clip branch defines.)"""
+    from _ref_harness import load_ref_finetune
+    ref_ft = load_ref_finetune()
+    _, t2 = load_ref_trainers()
+    from transformers import GenerationConfig
+    cfg = tiny_test_25()
+    ops = RefOps()
+    params = ModelParams(cfg, ops, seed=0)
+    hf = hf_tiny(cfg)
+    hf.load_state_dict({k: v.float() for k, v in params.export_hf_state_dict().items()}, strict=True)
+    frames = torch.randint(0, 256, frames_shape, generator=torch.Generator().manual_seed(7), dtype=torch.uint8).float()
+    row = {"problem": "person opens the door", "video_path": "x.mp4", "video_start": None, "video_end": None, "solution": (2.0, 12.0), "durations": 30.0,
+           "video_inputs": [frames], "video_kwargs": {"fps": [2.0]}}
+    tr = object.__new__(t2.TimeR1_Trainer_ft)
+    acc = types.SimpleNamespace(device=torch.device("cpu"), gather_for_metrics=lambda x: x, unwrap_model=lambda m: m)
+    seen = {}
+
+    class Proc(FakeProc):
+        def apply_chat_template(self, conv, tokenize=False, add_generation_prompt=True):
+            seen["conversation"] = copy.deepcopy(conv)
+            return "PROMPT"
+
+        def __call__(self, text=None, images=None, videos=None, fps=None, **kw):
+            seen["fps"] = list(fps)
+            return super().__call__(text=text, images=images, videos=videos, fps=fps, **kw)
+
+    def tok(*idx):
+        return [26 * 2 + i for i in idx]
+    force_rows = {0: tok(0, 22, 1, 2, 8, 4, 14, 3), 1: tok(0, 18, 1, 2, 6, 4, 7, 3), 3: tok(2, 7, 4, 6, 7, 3, 16, 16)}
+    policy = Shim(hf, cfg.video_token_id, force_eos=force_eos, force_rows=force_rows)
+    reward_funcs = [ref_ft.reward_funcs_registry["iou_v2"], ref_ft.reward_funcs_registry["format"]]
+    metric_funcs = list(ref_ft.metric_funcs_registry.values())
+    tr.__dict__.update(processing_class=Proc(cfg), accelerator=acc, num_generations=G, beta=0.0, use_grpo=False, epsilon_low=0.2, epsilon_high=0.2,
+                       epsilon=0.2, reward_funcs=reward_funcs, reward_processing_classes=[None, None], metric_funcs=metric_funcs,
+                       _metrics=collections.defaultdict(list), ref_model=None, prompt_type=prompt_type, is_deepspeed_enabled=False,
+                       _past=None, args=types.SimpleNamespace(device=torch.device("cpu"), past_index=-1),
+                       generation_config=GenerationConfig(max_new_tokens=C, do_sample=True, temperature=1.0, num_return_sequences=G, pad_token_id=0))
+    cap = {"calls": []}
+    orig = t2.TimeR1_Trainer_ft._get_per_token_logps
+
+    def spy(self, model, input_ids, attention_mask, pixel_values_videos, video_grid_thw):
+        lp, en = orig(self, model, input_ids, attention_mask, pixel_values_videos, video_grid_thw)
+        cap["calls"].append(dict(ids=input_ids.clone(), logp=lp.detach().clone(), ent=en.detach().clone()))
+        return lp, en
+    tr._get_per_token_logps = types.MethodType(spy, tr)
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = tr.compute_loss(policy, [row])
+        loss.backward()
+    ids = cap["calls"][0]["ids"]
+    P = ids.shape[1] - C
+    comp = ids[:, P:]
+    fx = {
+        "case": name, "trainer": "TimeR1_Trainer_ft", "use_grpo": False, "beta": 0.0, "G": G, "C": C, "seed": seed, "param_seed": 0, "dtype": "float32", "like": None,
+        "frames_seed": 7, "frames_shape": tuple(frames_shape), "model": "qwen2_5_vl", "prompt_type": prompt_type,
+        "row": {k: v for k, v in row.items() if k not in ("video_inputs",)}, "conversation": seen["conversation"], "fps_seen": seen["fps"],
+        "prompt_ids": ids[0, :P].tolist(), "completion_ids": comp.clone(), "completions": tr.processing_class.batch_decode(comp),
+        "logp": cap["calls"][0]["logp"][:, P - 1:].float(), "entropy": cap["calls"][0]["ent"][:, P - 1:].float(), "ref_logp": None,
+        "n_logp_calls": len(cap["calls"]), "loss": loss.detach().float().clone(), "metrics": {k: list(v) for k, v in tr._metrics.items()},
+        "reward_func_names": [f.__name__ for f in reward_funcs], "metric_func_names": [f.__name__ for f in metric_funcs], "ref_noise_seed": 99,
+        "grads": {k: p.grad.detach().float().clone() for k, p in hf.named_parameters() if p.grad is not None and
+                  any(s in k for s in ("lm_head", "layers.0.self_attn.q_proj", "layers.1.mlp.down_proj", "merger.mlp.2", "merger.ln_q", "norm.weight", "layers.0.self_attn.v_proj.bias"))},
+        "grad_norms": {k: float(p.grad.norm()) for k, p in hf.named_parameters() if p.grad is not None},
+        "embed_grad_rows": {int(i): hf.model.language_model.embed_tokens.weight.grad[int(i)].float().clone() for i in set(comp.reshape(-1).tolist()[:6] + [5, 10])},
+    }
+    out = os.path.join(HERE, "grpo_step_%s.pt" % name)
+    torch.save(fx, out)
+    print(name, "loss", float(loss), "metrics", {k: round(v[0], 5) for k, v in tr._metrics.items()}, os.path.getsize(out), "bytes")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["qwen2_vl", "qwen2_5_vl"]
     if "qwen2_vl" in which:
@@ -203,3 +280,6 @@ if __name__ == "__main__":
         run_case("q25_grpo_beta", True, 0.04, None, 223, model="qwen2_5_vl", frames_shape=(4, 3, 84, 112))
         run_case("q25_clip_beta_ragged", False, 0.04, {0: 3, 2: 5}, 224, model="qwen2_5_vl", frames_shape=(6, 3, 56, 140))
         run_case("q25_grpo_beta_bf16", True, 0.04, None, 223, model="qwen2_5_vl", frames_shape=(4, 3, 84, 112), dtype=torch.bfloat16, like="q25_grpo_beta")
+    if "ft" in which or not sys.argv[1:]:
+        # TimeR1_Trainer_ft (config 4's class): clip branch, beta 0, ragged EOS, template v2, pre-decoded frames in the row, metric funcs
+        run_case_ft("ft_clip_nobeta_ragged_v2", {0: 3, 2: 5}, 324)

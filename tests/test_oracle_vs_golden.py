@@ -43,6 +43,40 @@ def test_oracle_reproduces_reference_step(case):
         assert torch.allclose(W["embed"].grad[tok], g, atol=1e-6 + 1e-5 * g.abs().max().item(), rtol=1e-4), tok
 
 
+def test_oracle_reproduces_reference_ft_step():
+    """The step captured from the UNMODIFIED `TimeR1_Trainer_ft.compute_loss` (timer1_trainer_ft.py:536-852; finetune.py:693-713 settings:
+    Qwen2.5-VL, PPO-clip, beta 0, ragged EOS, template v2, pre-decoded frames in the row, finetune.py's metric registry): every logged value."""
+    from time_r1_amd import rewards as R
+    fx = load_case("ft_clip_nobeta_ragged_v2")
+    assert fx["trainer"] == "TimeR1_Trainer_ft" and fx["n_logp_calls"] == 1 and fx["ref_logp"] is None      # beta 0: no reference forward
+    cfg, pol, _ = golden_params(RefOps(), fx)
+    W = RM.weights_from_params(pol, requires_grad=True)
+    pv, grid = golden_inputs(fx)
+    assert [fake_decode(r.tolist(), skip=(1, 0)) for r in fx["completion_ids"]] == fx["completions"]
+    rew, fns = golden_rewards(fx)
+    assert [f.__name__ for f in fns] == fx["reward_func_names"]
+    out = RG.grpo_step(W, None, cfg, fx["prompt_ids"], pv, grid, fx["completion_ids"], rew, 0.0, False, rope_mode="hf5")
+    m = out["mask"].bool()
+    assert torch.allclose(out["logp"][m], fx["logp"][m], atol=1e-5, rtol=1e-5)
+    assert torch.allclose(out["entropy"][m], fx["entropy"][m], atol=1e-5, rtol=1e-5)
+    assert abs(out["loss"].item() - fx["loss"].item()) < 1e-6
+    G = fx["G"]
+    metric_fns = [R.metric_funcs_registry[n] for n in fx["metric_func_names"]]
+    kw = {k: [v] * G for k, v in fx["row"].items()}
+    mets = dict(out["metrics"])
+    for j, fn in enumerate(fns):
+        mets["rewards/" + fn.__name__] = rew[:, j].mean().item()
+    mets.update(RG.ft_extra_metrics(out["logp"], out["advantages"], out["mask"], fx["completions"], metric_fns, kw))
+    assert set(mets) == set(fx["metrics"])
+    for k, v in mets.items():
+        assert abs(v - fx["metrics"][k][0]) < 2e-5, (k, v, fx["metrics"][k])
+    out["loss"].backward()
+    for hk, g in fx["grads"].items():
+        if hk in HF_GRAD_KEYS:
+            mine = pick_grad(cfg, lambda n: W[n].grad, hk)
+            assert torch.allclose(mine, g, atol=1e-6 + 1e-5 * g.abs().max().item(), rtol=1e-4), hk
+
+
 @pytest.mark.parametrize("case", ["grpo_beta", "q25_grpo_beta", "q25_clip_beta_ragged"])
 def test_oracle_model_matches_transformers_logits(case):
     """Independent of the reference: oracle forward vs transformers' Qwen2VL / Qwen2_5_VL ForConditionalGeneration on the same weights."""

@@ -46,6 +46,28 @@ def test_hip_trainer_vs_reference_golden(hip_ops, case):
             assert rel < 0.06, (hk, float(rel))
 
 
+def test_hip_ft_trainer_vs_reference_ft_golden(hip_ops):
+    """`TimeR1_Trainer_ft` on the HIP path against the step captured from the unmodified reference `_ft.compute_loss`
+    (timer1_trainer_ft.py:536-852): EVERY metric value (shaping metrics and clip ratios included), loss, decoded strings, gradients."""
+    from test_trainer_host_logic import make_ft_trainer
+    fx = load_case("ft_clip_nobeta_ragged_v2")
+    cfg, tr, proc, row = make_ft_trainer(fx, hip_ops)
+    loss = tr.compute_loss(tr.model, [row])
+    assert proc.seen_conv == fx["conversation"] and proc.seen_fps == fx["fps_seen"]
+    assert abs(float(loss) - float(fx["loss"])) < 5e-3
+    assert set(tr._metrics) == set(fx["metrics"])
+    for k, v in fx["metrics"].items():
+        tol = 0.05 if k == "generation_entropy" else 1e-6
+        assert abs(tr._metrics[k][0] - v[0]) <= tol, (k, tr._metrics[k], v)
+    assert tr.last_completions == fx["completions"]
+    g = tr.params.train
+    for hk, gold in fx["grads"].items():
+        if hk in HF_GRAD_KEYS:
+            mine = pick_grad(cfg, g.g, hk).float().cpu()
+            rel = (mine - gold).norm() / gold.norm().clamp(min=1e-12)
+            assert rel < 0.06, (hk, float(rel))
+
+
 def test_hip_full_step_with_rollout_and_optimizer(hip_ops):
     """Sampling + update end to end on the GPU: tokens valid, metrics finite, weights move, grads zeroed; two identical seeds agree."""
     fx = load_case("grpo_beta")

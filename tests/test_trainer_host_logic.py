@@ -68,6 +68,50 @@ def test_ft_variant_metric_keys_and_video_inputs():
     assert set(tr._metrics) == want
 
 
+class _RecordingProcessor(FakeProcessor):
+    def apply_chat_template(self, conv, tokenize=False, add_generation_prompt=True):
+        self.seen_conv = conv
+        return super().apply_chat_template(conv, tokenize=tokenize, add_generation_prompt=add_generation_prompt)
+
+    def __call__(self, text=None, images=None, videos=None, fps=None, **kw):
+        self.seen_fps = list(fps)
+        return super().__call__(text=text, images=images, videos=videos, fps=fps, **kw)
+
+
+def make_ft_trainer(fx, ops):
+    """`TimeR1_Trainer_ft` as finetune.py:693-713 builds it, on the fixture's settings."""
+    cfg, pol, _ = golden_params(ops, fx)
+    args = GRPOConfig(output_dir="/tmp/tr1_test_ft", num_generations=fx["G"], max_completion_length=fx["C"], beta=fx["beta"], use_grpo=fx["use_grpo"],
+                      rope_index_mode="hf5", temperature=1.0, logging_steps=1, save_strategy="no", prompt_type=fx["prompt_type"])
+    proc = _RecordingProcessor(cfg)
+    tr = TimeR1_Trainer_ft(pol, [R.reward_funcs_registry["iou_v2"], R.reward_funcs_registry["format"]], [R.metric_funcs_registry[n] for n in fx["metric_func_names"]],
+                           args=args, train_dataset=None, processing_class=proc, ops=ops)
+    row = dict(fx["row"])
+    row["video_inputs"] = [frames_for(fx)]            # finetune.py:594-623: pre-decoded float frames + their kwargs ride in the dataset row
+    row["_forced_completion_ids"] = fx["completion_ids"].numpy()
+    return cfg, tr, proc, row
+
+
+def test_ft_trainer_matches_reference_ft_golden():
+    """Every value the UNMODIFIED `TimeR1_Trainer_ft.compute_loss` logged for this step (timer1_trainer_ft.py:536-852), not only the key set:
+    template v2 through make_conversation_video, the `video_inputs` / `video_kwargs` row path, `metrics/<fn>`, `clip_ratio/*`, loss and gradients."""
+    fx = load_case("ft_clip_nobeta_ragged_v2")
+    cfg, tr, proc, row = make_ft_trainer(fx, RefOps())
+    assert tr.ref_model is None                       # beta == 0: the reference creates no reference policy (:340-352)
+    loss = tr.compute_loss(tr.model, [row])
+    assert proc.seen_conv == fx["conversation"] and proc.seen_fps == fx["fps_seen"]
+    assert abs(float(loss) - float(fx["loss"])) < 2e-5
+    assert set(tr._metrics) == set(fx["metrics"])
+    for k, v in fx["metrics"].items():
+        assert abs(tr._metrics[k][0] - v[0]) < 5e-5, (k, tr._metrics[k], v)
+    assert tr.last_completions == fx["completions"]
+    g = tr.params.train
+    for hk, gold in fx["grads"].items():
+        if hk in HF_GRAD_KEYS:
+            mine = pick_grad(cfg, g.g, hk)
+            assert torch.allclose(mine, gold, atol=2e-5 * max(1.0, gold.abs().max().item()), rtol=2e-3), hk
+
+
 def test_errors_match_reference_contract():
     fx = load_case("clip_nobeta")
     cfg, tr = make_trainer(fx)
