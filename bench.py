@@ -436,9 +436,9 @@ def parse_args(argv=None):
     ap.add_argument("--engine-path", action="store_true", help="time the bare engine loop (GRPOCore + AdamWFlat, no TimeR1_Trainer) instead of the trainer class")
     ap.add_argument("--no-engine-leg", action="store_true", help="skip the short bare-engine-loop cross-check that follows the timed region")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
-    ap.add_argument("--shard-optimizer", action="store_true", help="N > 1: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
-                    "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json).  This is the DEFAULT for N in {2, 4, 8}: same "
-                    "wire bytes as the all-reduce, 1/N of the AdamW + grad-norm streams per rank")
+    ap.add_argument("--shard-optimizer", action="store_true", help="DEPRECATED, no effect: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
+                    "shard of master/m/v, all-gather bf16 weights; reference scripts/zero3.json) has been the DEFAULT for N in {2, 4, 8} since round 3; "
+                    "--replicated-optimizer opts out")
     ap.add_argument("--replicated-optimizer", action="store_true", help="N > 1: keep master / m / v whole on every rank and all-reduce the gradient")
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.ga < 1:

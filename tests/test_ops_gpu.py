@@ -245,6 +245,15 @@ def test_attention_fwd_bwd(hip_ops, ref_ops, name, nh, nkv, hd, m):
     o_s, lse_s = hip_ops.attn_fwd(q.cuda(), k.cuda(), vt_h, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, scale, nsplit=3)
     close(o_s, o_r, 0.02, what=name + " O split")
     close(lse_s, lse_r, 2e-3, rtol=1e-3, what=name + " lse split")
+    if hd == 128:
+        # the DEFAULT training / prefill / reference-forward kernel for head dim 128 (attn_fwd32_kernel, K and V read row-major): same op with
+        # v_rows instead of V^T, against the oracle and against the 16x16-MFMA kernel above
+        assert hip_ops.attn_fwd_rows_ok(hd)
+        o_w, lse_w = hip_ops.attn_fwd(q.cuda(), k.cuda(), None, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, scale, v_rows=v.cuda())
+        close(o_w, o_r, 0.02, what=name + " O (row-major V kernel)")
+        close(lse_w, lse_r, 2e-3, rtol=1e-3, what=name + " lse (row-major V kernel)")
+        close(o_w, o_h.float().cpu(), 0.02, what=name + " O rows vs V^T kernel")
+        close(lse_w, lse_h.float().cpu(), 2e-3, rtol=1e-3, what=name + " lse rows vs V^T kernel")
     # backward (uses the oracle's O / lse so that only the backward kernels are under test)
     dq_h, dk_h, dv_h = hip_ops.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o_r.to(BF16).cuda(), do.cuda(), lse_r.cuda(), pre.cuda(), lo.cuda(),
                                         hi.cuda(), nh, nkv, S, hd, scale)
@@ -252,6 +261,46 @@ def test_attention_fwd_bwd(hip_ops, ref_ops, name, nh, nkv, hd, m):
     close(dq_h, dq_r, 0.03, rtol=3e-2, what=name + " dQ")
     close(dk_h, dk_r, 0.03 * math.sqrt(nh // nkv) + 0.02, rtol=3e-2, what=name + " dK")
     close(dv_h, dv_r, 0.03 * math.sqrt(nh // nkv) + 0.02, rtol=3e-2, what=name + " dV")
+
+
+ROWS_CASES = [
+    # name, n_heads, n_kv, P, G, C, continuation (q = completion rows only, T < n_slots)
+    ("g7-kv4-packed", 28, 4, 210, 4, 33, False),          # Qwen2-VL-7B head layout; 342 * 7 packed rows: not a multiple of 256
+    ("g7-kv4-continuation", 28, 4, 210, 4, 33, True),
+    ("g6-kv2-continuation", 12, 2, 333, 8, 25, True),     # Qwen2-VL-2B head layout
+    ("g1-continuation-tiny", 2, 2, 5, 2, 3, True),
+]
+
+
+@pytest.mark.parametrize("name,nh,nkv,P,G,C,cont", ROWS_CASES, ids=[c[0] for c in ROWS_CASES])
+def test_attention_fwd_rows_strided_views_and_continuation(hip_ops, ref_ops, name, nh, nkv, P, G, C, cont):
+    """tr1_attn_fwd_rows as model.llm_fwd calls it - K and V are COLUMN VIEWS of the fused [S, q|k|v] projection buffer (row stride =
+    qkv width), the output is a view of a wider buffer, and the continuation forward passes only the completion rows as queries (T < n_slots)
+    while K / V span the prompt + completion slots."""
+    hd = 128
+    qd, kvd = nh * hd, nkv * hd
+    S = P + G * C
+    pre, lo, hi = masks_prefix_shared(P, G, C)
+    qkv = rnd(S, qd + 2 * kvd, seed=11).cuda()
+    q_all, k_view, v_view = qkv[:, :qd], qkv[:, qd:qd + kvd], qkv[:, qd + kvd:]
+    assert not k_view.is_contiguous() and not v_view.is_contiguous()
+    r0 = P if cont else 0
+    q = q_all[r0:]
+    T = S - r0
+    obuf = torch.zeros(S, qd + 64, dtype=BF16, device="cuda:0")
+    o_view = obuf[r0:, :qd]
+    o_w, lse_w = hip_ops.attn_fwd(q, k_view, None, pre[r0:].cuda(), lo[r0:].cuda(), hi[r0:].cuda(), nh, nkv, S, hd, hd ** -0.5, v_rows=v_view, out=o_view)
+    assert o_w.data_ptr() == o_view.data_ptr()
+    k32, v32 = k_view.float().cpu(), v_view.float().cpu()
+    o_r, lse_r = ref_ops.attn_fwd(q.float().cpu(), k32, ref_ops.pack_transpose(v32, nkv, nkv, hd), pre[r0:], lo[r0:], hi[r0:], nh, nkv, S, hd, hd ** -0.5)
+    close(o_w, o_r, 0.02, what=name + " O")
+    close(lse_w, lse_r, 2e-3, rtol=1e-3, what=name + " lse")
+    assert float(obuf[:, qd:].abs().max()) == 0.0 and (r0 == 0 or float(obuf[:r0].abs().max()) == 0.0), "writes outside the output view"
+    # and against the V^T kernel (the path taken without v_rows / with TR1_FWD32=0) on contiguous copies of the same operands
+    vt = hip_ops.pack_transpose(v_view.contiguous(), nkv, nkv, hd)
+    o_t, lse_t = hip_ops.attn_fwd(q.contiguous(), k_view.contiguous(), vt, pre[r0:].cuda(), lo[r0:].cuda(), hi[r0:].cuda(), nh, nkv, S, hd, hd ** -0.5)
+    close(o_w, o_t.float().cpu(), 0.02, what=name + " O rows vs V^T kernel")
+    close(lse_w, lse_t.float().cpu(), 2e-3, rtol=1e-3, what=name + " lse rows vs V^T kernel")
 
 
 def test_attention_decode_over_cache(hip_ops, ref_ops):

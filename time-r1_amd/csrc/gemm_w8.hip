@@ -888,13 +888,15 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
     if (glu) { if (mg == 1) W8(4, 2, 4, 1, true, true); else if (mg == 2) W8(4, 2, 4, 2, true, true); else W8(4, 1, 2, 4, true, true); }
     else if (lnw && N >= 100000) { if (mg == 1) W8(4, 2, 4, 1, true, false); else if (mg == 2) W8(4, 2, 4, 2, true, false); else W8(4, 1, 2, 4, true, false); }
     else {
+// x image (32 bytes per k: 16 rows of bf16) + the norm weight, which arrives in whole 1 KiB DMA instructions (the last one may run past K * 2 bytes)
+#define W8X_LDS(K_) ((int64_t)(K_) * 32 + (((int64_t)(K_) * 2 + 1023) / 1024) * 1024)
         static int xlds = -1;                        // TR1_W8A8_XLDS=0: activation rows / norm weight through the vector-memory path (A/B measurements)
         if (xlds < 0) { const char* e = getenv("TR1_W8A8_XLDS"); xlds = e ? atoi(e) : 1; }
-        const bool x_ok = xlds && mg == 1 && K < 8192 && K % 128 == 0 && K * 34 <= 128 * 1024 && (int64_t)M * ldx * 2 < 0x7fffffffLL;
+        const bool x_ok = xlds && mg == 1 && K < 8192 && K % 128 == 0 && W8X_LDS(K) <= 128 * 1024 && (int64_t)M * ldx * 2 < 0x7fffffffLL;
 #define W8X(NC, NRM) do {                                                                                                                        \
             static bool attr_ = false;                                                                                                           \
             if (!attr_) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_w8a8_kernel<4, 2, NC, 1, NRM, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_ = true; } \
-            hipLaunchKernelGGL((gemm_skinny_w8a8_kernel<4, 2, NC, 1, NRM, false, true>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC))), dim3(256), (size_t)(K * 34), s, \
+            hipLaunchKernelGGL((gemm_skinny_w8a8_kernel<4, 2, NC, 1, NRM, false, true>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC))), dim3(256), (size_t)W8X_LDS(K), s, \
                                (const bf16_t*)x, (const bf16_t*)lnw, (const unsigned char*)W_fp8, (const float*)wscale, (bf16_t*)out, (const bf16_t*)bias,  \
                                (const bf16_t*)residual, (int)M, N, K, ldx, ldw, ldc, ldr, eps, N);                                              \
         } while (0)

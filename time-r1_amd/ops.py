@@ -473,12 +473,14 @@ class HipOps:
         T = rows // n_batch
         o = out if out is not None else self.empty(rows, n_heads * head_dim)
         lse = self.empty(n_batch * n_heads, T, dtype=F32) if need_lse else None
-        if v_rows is not None and self.attn_fwd_rows_ok(head_dim, nsplit, n_batch):
+        if v_rows is not None and self.attn_fwd_rows_ok(head_dim, nsplit, n_batch, n_slots=n_slots, ld=max(_ld(k), _ld(v_rows))):
             self._chk(q, k, v_rows)
             assert k.shape[0] >= n_slots and v_rows.shape[0] >= n_slots
             self.L.call("tr1_attn_fwd_rows", _p(q), _ld(q), _p(k), _ld(k), _p(v_rows), _ld(v_rows), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
                         n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
             return o, lse
+        if vt is None and v_rows is not None:      # the row-major kernel does not take this launch (head dim, split-KV, > 4 GiB operands): V^T copy
+            vt = self.pack_transpose(v_rows, n_kv, n_kv, head_dim)
         assert vt is not None, "attention: this shape needs the V^T operand"
         self._chk(q, k, vt)
         ws, nws = None, 0
@@ -494,9 +496,10 @@ class HipOps:
                     n_heads, n_kv, n_slots, head_dim, float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, self._s())
         return o, lse
 
-    def attn_fwd_rows_ok(self, head_dim, nsplit=1, n_batch=1):
-        """True when attn_fwd(v_rows=...) would take the row-major K / V kernel (callers can then skip building V^T)."""
-        return self.FWD32 and head_dim == 128 and nsplit == 1 and n_batch == 1
+    def attn_fwd_rows_ok(self, head_dim, nsplit=1, n_batch=1, n_slots=0, ld=0):
+        """True when attn_fwd(v_rows=...) would take the row-major K / V kernel (callers can then skip building V^T).  The kernel addresses
+        K / V with 32-bit DMA offsets: operands of n_slots rows x ld elements must stay below 4 GiB (csrc/attn_fwd32.hip, tr1_attn_fwd_rows)."""
+        return self.FWD32 and head_dim == 128 and nsplit == 1 and n_batch == 1 and n_slots * ld * 2 < 0xffffffff
 
     def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):
         """-> dq [T, n_heads*hd], dk, dv [n_slots, n_kv*hd]. Builds the transposed operand copies it needs."""

@@ -87,7 +87,7 @@ class AdamWFlat:
     def load_state_dict(self, sd):
         a = self.params.train
         if sd.get("shard") != a.shard:
-            raise ValueError("optimizer state was saved with shard %s but this run uses %s (resume with the same world size / --shard-optimizer setting)"
+            raise ValueError("optimizer state was saved with shard %s but this run uses %s (resume with the same world size and optimizer layout: GRPOConfig.shard_optimizer=False / bench.py --replicated-optimizer selects the replicated form that checkpoints written before round 3 used by default)"
                              % (sd.get("shard"), a.shard))
         self.step_count = int(sd["step"])
         a.master.copy_(sd["master"]); a.m.copy_(sd["m"]); a.v.copy_(sd["v"])

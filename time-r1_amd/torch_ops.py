@@ -415,13 +415,14 @@ def hf_attention_forward(module, query, key, value, attention_mask=None, dropout
     if S < T:
         raise NotImplementedError("timer1_hip attention: fewer keys (%d) than queries (%d)" % (S, T))
     causal = is_causal if is_causal is not None else bool(getattr(module, "is_causal", True))
-    if attention_mask is not None and attention_mask.dtype == torch.bool:
-        full = bool(attention_mask.all())
-    elif attention_mask is not None:
-        # an additive float mask: transformers builds the plain causal triangle for sdpa-like backends; anything else (left padding,
-        # sliding windows, packed documents) cannot be expressed by one (pre, lo, hi) interval per query here
+    if attention_mask is not None:
+        # transformers builds the plain causal triangle for sdpa-like backends, as an additive float mask (0 = keep) or as a bool mask
+        # (True = keep); anything else (left padding, sliding windows, packed documents) cannot be expressed by one (pre, lo, hi) interval per
+        # query here.  An all-keep mask is trivial for either setting of `causal`.
+        keep = attention_mask if attention_mask.dtype == torch.bool else (attention_mask == 0)
+        keep = keep.expand(B, -1, T, S).reshape(-1, T, S) if keep.dim() == 4 else keep.reshape(-1, T, S)
         tri = torch.ones(T, S, dtype=torch.bool, device=query.device).tril(S - T) if causal else torch.ones(T, S, dtype=torch.bool, device=query.device)
-        full = bool(((attention_mask.reshape(-1, T, S) == 0) == tri).all())
+        full = bool((keep == tri).all()) or bool(keep.all())
     else:
         full = True
     if not full:

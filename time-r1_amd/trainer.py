@@ -536,7 +536,16 @@ class TimeR1_Trainer:
     @property
     def _metrics(self):
         """The reference's `self._metrics` (defaultdict of per-micro-step lists, timer1_trainer.py:739-777).  Reading it resolves the micro-steps
-        whose device-side values are still pending (one packed device-to-host copy, one all-gather under data parallelism)."""
+        whose device-side values are still pending with one packed device-to-host copy.  Under data parallelism resolving them is a COLLECTIVE
+        (the reference gathers every metric over the ranks), so a plain attribute read never does it - a rank-0-only callback or debug print
+        reading `trainer._metrics` would otherwise enter an all-gather alone and hang until the process-group timeout.  There the pending
+        micro-steps are resolved by `log()` (every rank calls it at the same optimizer step) or an explicit `flush_metrics()` on ALL ranks."""
+        if not self.dp.enabled:
+            self._flush_metrics()
+        return self._metrics_store
+
+    def flush_metrics(self):
+        """Resolve the pending micro-steps' metrics now.  Collective under data parallelism: every rank must call it."""
         self._flush_metrics()
         return self._metrics_store
 
@@ -794,7 +803,7 @@ class TimeR1_Trainer:
         """The reference's keys (timer1_trainer.py:784-793: means of the per-micro-step metric lists, then cleared) plus the throughput keys
         SURVEY 5.5 asks this build to emit beside them: `samples_per_sec` / `rollout_tokens_per_sec` (whole job) and the two roofline
         fractions of the step's dominant kernel families (`perf/*`, from HIP-event phase times and the algorithmic work of the shapes run)."""
-        metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}     # reference :784-793
+        metrics = {k: sum(v) / len(v) for k, v in self.flush_metrics().items()}     # reference :784-793 (all ranks are here: see _metrics)
         logs = {**logs, **metrics, **self._throughput_keys()}
         if self.state.epoch is not None:
             logs["epoch"] = round(self.state.epoch, 4)
