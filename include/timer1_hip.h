@@ -38,6 +38,17 @@ int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, co
 /* C[M,N] = A[M,K] * B[K,N], B K-major ("NN").  The dgrad of a Linear (dX = dY * W; reference: autograd of F.linear under accelerator.backward,
  * TF trainer.py:1952-1961) reads the weight as stored instead of a transposed copy.  Needs M >= 512, N >= 256, K % 64 == 0; bf16 in / out. */
 int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+/* Fused-epilogue training GEMMs ("fuse SiLU*up", "M-RoPE fused into QKV epilogue"): each is bit-identical to the GEMM followed by the elementwise
+ * kernel it absorbs (the GEMM output is rounded to bf16 exactly where the unfused path stores it).
+ * tr1_gemm_glu_bf16: a[M, I] = silu(x Wg^T) * (x Wu^T), Wgu = [2I, K] gate rows then up rows (TF:459-466 Qwen2MLP, reached from
+ *   src/time_r1/rl/timer1_trainer.py:452-457); gu_out (NULL = not needed) receives the projection [M, 2I] the backward reads. */
+int tr1_gemm_glu_bf16(const void* x, const void* Wgu, void* a_out, void* gu_out, int64_t M, int64_t I, int64_t K, int64_t ldx, int64_t ldw, int64_t lda, int64_t ldgu, void* stream);
+/* tr1_gemm_qkv_rope_bf16: fused q|k|v projection + bias + multimodal rotary embedding for head dim 128 (TF:501-504 q/k/v_proj, TF:212-222
+ *   apply_multimodal_rotary_pos_emb): q_out / k_out rotated with cos / sin fp32 [M, 64], v_out plain; k_out may point into the KV cache rows. */
+int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ldq, void* k_out, int64_t ldk, void* v_out, int64_t ldv, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, void* stream);
+/* tr1_gemm_nn_glubwd_bf16: dgu[M, 2I] = SwiGLU backward of da = dh[M, H] Wd[H, I] (the down projection as stored) with the saved gu[M, 2I]; da is never
+ *   written (autograd of TF:459-466 under accelerator.backward, src/time_r1/rl/timer1_trainer.py:709-737). */
+int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void* dgu, int64_t M, int64_t I, int64_t H, int64_t lda, int64_t ldb, int64_t ldgu, int64_t lddgu, void* stream);
 /* Weight gradient without the X^T copy: C[M,N] fp32 (+)= A[M,K] B[K,N], B K-major with only its first b_rows rows valid (A = dY^T zero-padded to
  * K = tokens rounded up to 64, B = the saved activation as stored).  ref: autograd of nn.Linear inside HF Trainer.training_step (TF trainer.py:1892-1961). */
 int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int64_t b_rows, void* stream);
@@ -64,6 +75,9 @@ int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, const void* bia
 int64_t tr1_gemm_skinny_fixup_workspace_floats(int64_t M, int64_t N, int64_t K);
 /* out[c, r] = in[r, c]; columns [R, ld_out) of out are zero-filled (feeds the NT GEMM for dgrad / wgrad). */
 int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* stream);
+/* The same transpose with colsum_f32[c] += sum_r in[r, c]: the bias gradient of a Linear (reference: autograd of F.linear, q/k/v_proj bias TF:501-504) taken
+ * from the pass that builds dY^T for its weight gradient. */
+int tr1_transpose_colsum_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* colsum_f32, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------------- */
 /* ref: Qwen2RMSNorm TF:96-110 (fp32 math, cast to bf16 BEFORE the weight multiply).  If residual != NULL the kernel first forms
@@ -131,6 +145,9 @@ int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_b
  * delta: fp32 [2*n_heads, T] scratch (delta, then the log2-scaled LSE); qmeta_ws: int32 [8*ceil(T*group/64)] scratch; ws_f32: tr1_attn_bwd_workspace_floats() floats (fp32 dK/dV
  * partials of the query-split dK/dV kernel).  Writes dQ [T, n_heads*hd], dK, dV [slots, n_kv*hd]. */
 int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT, int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld, const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld, void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32, int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
+/* The same backward with the M-RoPE backward (TF:212-222 transposed) folded in: dQ / dK come back with respect to the UN-rotated projections, rotated in
+ * the dQ kernel's epilogue and in the dK / dV partial-sum kernel (head dim 128; other shapes run tr1_rope_apply in place).  cos / sin fp32 [T, d/2], n_slots == T. */
+int tr1_attn_bwd_rope(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT, int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld, const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld, void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32, int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, const void* rope_cos, const void* rope_sin, void* stream);
 int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim);
 /* out[(kvh*hd + d) * ld_out + col] = in[t*ld_in + (kvh*group + hq)*hd + d], col = t*group + hq (or slots[t] when slots != NULL, group 1);
  * without slots, columns [T*group, zero_cols) are zero-filled */

@@ -84,8 +84,10 @@ class RefOps:
             return out
         return c if out_f32 else self._a(c)
 
-    def transpose(self, x, pad_to=64, out=None):
+    def transpose(self, x, pad_to=64, out=None, colsum=None):
         R, C = x.shape
+        if colsum is not None:
+            colsum += x.float().sum(0)
         Rp = (R + pad_to - 1) // pad_to * pad_to
         if out is None:
             out = torch.zeros(C, Rp, dtype=x.dtype)
@@ -197,6 +199,25 @@ class RefOps:
         xn, _, _ = self.rmsnorm_fwd(x, lnw, eps, need_rstd=False)
         y = self.gemm_nt(xn, w, bias=bias)
         return self.swiglu_fwd(y) if glu else y
+
+    # ---- fused-epilogue training GEMMs: by definition the compositions they replace (csrc/gemm.hip EPI 2 / 3 / 4)
+    def gemm_glu(self, x, w_gu, a_out=None, gu_out=None, save_gu=True):
+        gu = self.gemm_nt(x, w_gu, out=gu_out)
+        return self.swiglu_fwd(gu, out=a_out), (gu if save_gu else None)
+
+    def gemm_qkv_rope(self, x, w_qkv, bias, cos, sin, n_heads, n_kv, head_dim, q_out=None, k_out=None, v_out=None):
+        qd, kvd = n_heads * head_dim, n_kv * head_dim
+        qkv = self.gemm_nt(x, w_qkv, bias=bias)
+        q = self.rope_apply(qkv[:, :qd], n_heads, head_dim, cos, sin, out=q_out)
+        k = self.rope_apply(qkv[:, qd:qd + kvd], n_kv, head_dim, cos, sin, out=k_out)
+        v = qkv[:, qd + kvd:]
+        if v_out is not None:
+            v_out.copy_(v)
+            v = v_out
+        return q, k, v
+
+    def dgrad_glu_bwd(self, dh, w_down, gu):
+        return self.swiglu_bwd(self.gemm_nn(dh, w_down), gu)
 
     def swiglu_fwd(self, gu, out=None):
         i = gu.shape[1] // 2
@@ -362,17 +383,24 @@ class RefOps:
             return out, (lse if need_lse else None)
         return self._a(o), (lse if need_lse else None)
 
-    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):
+    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None, dq_out=None, dk_out=None, rope=None):
         with torch.enable_grad():
             qf = q.float().detach().requires_grad_(True)
             kf = k[:n_slots].float().detach().requires_grad_(True)
             vf = v[:n_slots].float().detach().requires_grad_(True)
             of, _ = self._dense_attn(qf, kf, vf, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale)
             dq, dk, dv = torch.autograd.grad(of, (qf, kf, vf), do.float())
-        if dv_out is not None:
-            dv_out.copy_(self._a(dv))
-            return self._a(dq), self._a(dk), dv_out
-        return self._a(dq), self._a(dk), self._a(dv)
+        dq, dk, dv = self._a(dq), self._a(dk), self._a(dv)
+        if rope is not None:        # gradients of the un-rotated projections: the transposed rotation, as the separate rope_apply(backward=True) calls
+            dq = self.rope_apply(dq, n_heads, head_dim, rope[0], rope[1], backward=True)
+            dk = self.rope_apply(dk, n_kv, head_dim, rope[0], rope[1], backward=True)
+        outs = []
+        for val, dst in ((dq, dq_out), (dk, dk_out), (dv, dv_out)):
+            if dst is not None:
+                dst.copy_(val)
+                val = dst
+            outs.append(val)
+        return tuple(outs)
 
     # ---- video preprocessing (ref: vision_process.py:467-472 + HF video processor patchify)
     def video_preprocess(self, frames_u8, out_hw, k_pad, patch=14, temporal=2, merge=2, mean=None, std=None):

@@ -179,6 +179,76 @@ def test_gather_scatter_embed(hip_ops, ref_ops):
     close(dt_h, dt_r, 1e-5, rtol=1e-5, what="embed bwd")
 
 
+# ------------------------------------------------------------------------------------------- fused-epilogue training GEMMs
+class _unfused:
+    """The same HipOps with the fused epilogues switched off (GEMM + separate elementwise kernels: the round-3 path)."""
+
+    def __init__(self, ops):
+        self.ops = ops
+
+    def __enter__(self):
+        self.ops.FUSE_EPI = False
+        return self.ops
+
+    def __exit__(self, *a):
+        del self.ops.FUSE_EPI            # back to the class default
+
+
+@pytest.mark.parametrize("M,I,K,save", [(300, 640, 256, True), (1111, 1032, 512, True), (700, 200, 128, False), (5074, 2048, 256, True), (65, 8, 64, True)])
+def test_gemm_glu_fused_epilogue(hip_ops, ref_ops, M, I, K, save):
+    """gate/up GEMM with SwiGLU in the epilogue (csrc/gemm.hip EPI 2): bit-identical to GEMM + swiglu_fwd, close to the oracle; I % 128 != 0 and
+    output views included."""
+    x, w = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.1)
+    abuf = torch.zeros(M + 3, I + 16, dtype=BF16, device="cuda:0")
+    gbuf = torch.zeros(M, 2 * I, dtype=BF16, device="cuda:0")
+    a, gu = hip_ops.gemm_glu(x.cuda(), w.cuda(), a_out=abuf[3:, :I], gu_out=gbuf if save else None, save_gu=save)
+    with _unfused(hip_ops) as o:
+        a0, gu0 = o.gemm_glu(x.cuda(), w.cuda(), save_gu=True)
+    assert torch.equal(a, a0), "fused SwiGLU epilogue differs from GEMM + swiglu_fwd"
+    assert float(abuf[:3].abs().max()) == 0.0 and float(abuf[:, I:].abs().max()) == 0.0
+    if save:
+        assert gu.data_ptr() == gbuf.data_ptr() and torch.equal(gu, gu0)
+    else:
+        assert gu is None
+    ar, gur = ref_ops.gemm_glu(x.float(), w.float())
+    close(a, ar, 0.02 * math.sqrt(K) * 0.1 + 0.02, rtol=3e-2, what="glu a")
+
+
+@pytest.mark.parametrize("M,nh,nkv,K,row0", [(300, 4, 2, 256, 0), (1000, 28, 4, 512, 0), (333, 12, 2, 192, 77), (5074, 2, 2, 64, 0)])
+def test_gemm_qkv_rope_fused_epilogue(hip_ops, ref_ops, M, nh, nkv, K, row0):
+    """q|k|v projection + bias + M-RoPE in the GEMM epilogue (EPI 4): q / k / v bit-identical to GEMM + rope_apply; k written into rows
+    [row0, row0 + M) of a wider cache buffer, v into a column view."""
+    hd = 128
+    qd, kvd = nh * hd, nkv * hd
+    x, w, b = rnd(M, K, seed=1), rnd(qd + 2 * kvd, K, seed=2, scale=0.1), rnd(qd + 2 * kvd, seed=3)
+    g = torch.Generator().manual_seed(5)
+    ang = torch.rand(M, hd // 2, generator=g) * 6.28
+    cos, sin = torch.cos(ang).to(BF16).float(), torch.sin(ang).to(BF16).float()
+    kc = torch.zeros(row0 + M + 5, kvd, dtype=BF16, device="cuda:0")
+    vb = torch.zeros(M, kvd + 8, dtype=BF16, device="cuda:0")
+    q, k, v = hip_ops.gemm_qkv_rope(x.cuda(), w.cuda(), b.cuda(), cos.cuda(), sin.cuda(), nh, nkv, hd, k_out=kc[row0:row0 + M], v_out=vb[:, :kvd])
+    with _unfused(hip_ops) as o:
+        q0, k0, v0 = o.gemm_qkv_rope(x.cuda(), w.cuda(), b.cuda(), cos.cuda(), sin.cuda(), nh, nkv, hd)
+    assert torch.equal(q, q0) and torch.equal(k, k0) and torch.equal(v, v0)
+    assert k.data_ptr() == kc[row0:].data_ptr() and float(kc[:row0].abs().max() if row0 else 0.0) == 0.0 and float(kc[row0 + M:].abs().max()) == 0.0
+    assert float(vb[:, kvd:].abs().max()) == 0.0
+    qr, kr, vr = ref_ops.gemm_qkv_rope(x.float(), w.float(), b.float(), cos, sin, nh, nkv, hd)
+    atol = 0.02 * math.sqrt(K) * 0.1 + 0.03
+    close(q, qr, atol, rtol=3e-2, what="q rope"); close(k, kr, atol, rtol=3e-2, what="k rope"); close(v, vr, atol, rtol=3e-2, what="v")
+
+
+@pytest.mark.parametrize("M,I,H", [(2048, 6400, 256), (1600, 8192, 128), (5074, 4096, 64)])
+def test_dgrad_glu_bwd_fused_epilogue(hip_ops, ref_ops, M, I, H):
+    """Down-projection dgrad (weight as stored) with the SwiGLU backward in its epilogue (EPI 3): bit-identical to gemm_nn + swiglu_bwd."""
+    dh, w, gu = rnd(M, H, seed=1), rnd(H, I, seed=2, scale=0.1), rnd(M, 2 * I, seed=3)
+    d = hip_ops.dgrad_glu_bwd(dh.cuda(), w.cuda(), gu.cuda())
+    with _unfused(hip_ops) as o:
+        d0 = o.dgrad_glu_bwd(dh.cuda(), w.cuda(), gu.cuda())
+    assert torch.equal(d, d0), "fused SwiGLU-backward epilogue differs from gemm_nn + swiglu_bwd"
+    if M <= 2048:
+        close(d, ref_ops.dgrad_glu_bwd(dh.float(), w.float(), gu.float()), 0.02 * math.sqrt(H) * 0.1 + 0.03, rtol=4e-2, what="dgu")
+
+
 # ------------------------------------------------------------------------------------------------------------- attention
 def masks_causal(T):
     t = torch.arange(T, dtype=torch.int32)
@@ -301,6 +371,39 @@ def test_attention_fwd_rows_strided_views_and_continuation(hip_ops, ref_ops, nam
     o_t, lse_t = hip_ops.attn_fwd(q.contiguous(), k_view.contiguous(), vt, pre[r0:].cuda(), lo[r0:].cuda(), hi[r0:].cuda(), nh, nkv, S, hd, hd ** -0.5)
     close(o_w, o_t.float().cpu(), 0.02, what=name + " O rows vs V^T kernel")
     close(lse_w, lse_t.float().cpu(), 2e-3, rtol=1e-3, what=name + " lse rows vs V^T kernel")
+
+
+@pytest.mark.parametrize("name,nh,nkv,hd,m", [c for c in ATT_CASES if c[0] in ("causal", "prefix-shared-128", "prefix-shared-128-g7", "prefix-shared", "tiny-128")] +
+                         [("prefix-shared-big", 28, 4, 128, masks_prefix_shared(700, 8, 60))], ids=lambda v: v if isinstance(v, str) else None)
+def test_attention_bwd_with_rope_backward_folded_in(hip_ops, ref_ops, name, nh, nkv, hd, m):
+    """tr1_attn_bwd_rope: dQ / dK rotated by the transposed M-RoPE matrix inside the dQ kernel's epilogue and the dK / dV partial-sum kernel (head dim 128),
+    written into column views of one [T, q|k|v] buffer - bit-identical to tr1_attn_bwd followed by rope_apply(backward=True), and close to the oracle."""
+    pre, lo, hi = m
+    T = pre.numel()
+    scale = hd ** -0.5
+    q, k, v, do = rnd(T, nh * hd, seed=1), rnd(T, nkv * hd, seed=2), rnd(T, nkv * hd, seed=3), rnd(T, nh * hd, seed=4)
+    ang = torch.rand(T, hd // 2, generator=torch.Generator().manual_seed(9)) * 6.28
+    cos, sin = torch.cos(ang).to(BF16).float(), torch.sin(ang).to(BF16).float()
+    o_r, lse_r = ref_ops.attn_fwd(q.float(), k.float(), ref_ops.pack_transpose(v.float(), nkv, nkv, hd), pre, lo, hi, nh, nkv, T, hd, scale)
+    qd, kvd = nh * hd, nkv * hd
+    buf = torch.zeros(T, qd + 2 * kvd, dtype=BF16, device="cuda:0")
+    args = (q.cuda(), k.cuda(), v.cuda(), o_r.to(BF16).cuda(), do.cuda(), lse_r.cuda(), pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, T, hd, scale)
+    hip_ops.attn_bwd(*args, dq_out=buf[:, :qd], dk_out=buf[:, qd:qd + kvd], dv_out=buf[:, qd + kvd:], rope=(cos.cuda(), sin.cuda()))
+    with _unfused(hip_ops) as o:
+        dq0, dk0, dv0 = o.attn_bwd(*args, rope=(cos.cuda(), sin.cuda()))
+    assert torch.equal(buf[:, :qd], dq0) and torch.equal(buf[:, qd:qd + kvd], dk0) and torch.equal(buf[:, qd + kvd:], dv0)
+    dq_r, dk_r, dv_r = ref_ops.attn_bwd(q.float(), k.float(), v.float(), o_r, do.float(), lse_r, pre, lo, hi, nh, nkv, T, hd, scale, rope=(cos, sin))
+    close(buf[:, :qd], dq_r, 0.04, rtol=4e-2, what=name + " dQ (rope bwd)")
+    close(buf[:, qd:qd + kvd], dk_r, 0.04 * math.sqrt(nh // nkv) + 0.03, rtol=4e-2, what=name + " dK (rope bwd)")
+
+
+@pytest.mark.parametrize("R,C", [(5074, 4608), (100, 72), (64, 64), (333, 200)])
+def test_transpose_with_column_sums(hip_ops, ref_ops, R, C):
+    x = rnd(R, C, seed=1)
+    cs = torch.full((C,), 0.25, device="cuda:0")
+    t = hip_ops.transpose(x.cuda(), colsum=cs)
+    assert torch.equal(t, hip_ops.transpose(x.cuda())), "the transpose itself must not change"
+    close(cs, x.float().sum(0) + 0.25, 1e-3 * math.sqrt(R), rtol=1e-4, what="column sums")
 
 
 def test_attention_decode_over_cache(hip_ops, ref_ops):

@@ -1368,6 +1368,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
         att_split_row(p, e_R, t2, hq2);
         const float scale = p.scale_log2 * 0.6931471805599453f;
         bf16_t* row = p.dQ + (int64_t)t2 * p.dq_ld + (int64_t)(kvh * p.group + hq2) * D;
+        if (p.rope_cos) {
+            // M-RoPE backward in the epilogue: feature f < 64 and its rotate-half partner f + 64 (db + 2) sit in the SAME lane.  As the separate
+            // kernels did: dQ is rounded to bf16 first, then da' = da c + db s, db' = db c - da s in fp32, rounded once more.
+            const float* cr = p.rope_cos + (int64_t)t2 * 64;
+            const float* sr = p.rope_sin + (int64_t)t2 * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = db * 32 + 8 * i + 4 * e_h;
+                    const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cr + f), s4 = *reinterpret_cast<const f32x4_t*>(sr + f);
+                    float oa[4], ob[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = bf2f(f2bf(acc[db][4 * i + j] * scale)), b = bf2f(f2bf(acc[db + 2][4 * i + j] * scale));
+                        const float sn = -s4[j];                     // rope_apply_kernel's sgn = -1
+                        oa[j] = a * c4[j] - b * sn; ob[j] = b * c4[j] + a * sn;
+                    }
+                    const u32x2_t wa = {pack2bf(oa[0], oa[1]), pack2bf(oa[2], oa[3])}, wb = {pack2bf(ob[0], ob[1]), pack2bf(ob[2], ob[3])};
+                    *reinterpret_cast<u32x2_t*>(row + f) = wa;
+                    *reinterpret_cast<u32x2_t*>(row + f + 64) = wb;
+                }
+        } else {
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -1375,14 +1398,45 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
                 const u32x2_t w = {pack2bf(acc[db][4 * i] * scale, acc[db][4 * i + 1] * scale), pack2bf(acc[db][4 * i + 2] * scale, acc[db][4 * i + 3] * scale)};
                 *reinterpret_cast<u32x2_t*>(row + db * 32 + 8 * i + 4 * e_h) = w;
             }
+        }
     }
 }
 
-// dK = scale * sum_z part_k[z], dV = sum_z part_v[z]  -> bf16
+// dK = scale * sum_z part_k[z], dV = sum_z part_v[z]  -> bf16.  ROPE (head dim 128): a thread owns 4 features f < 64 of a head AND their rotate-half partners
+// f + 64, and dK leaves rotated by the transposed rotary matrix of its slot (rounded to bf16 before and after, as the separate rope kernel did).
+template <bool ROPE>
 __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const float* __restrict__ part_v, bf16_t* __restrict__ dK, int64_t dk_ld,
-                                       bf16_t* __restrict__ dV, int64_t dv_ld, int n_slots, int kvd, int QS, float scale) {
-    const int64_t nch = (int64_t)n_slots * (kvd / 4);
+                                       bf16_t* __restrict__ dV, int64_t dv_ld, int n_slots, int kvd, int QS, float scale,
+                                       const float* __restrict__ cosb, const float* __restrict__ sinb) {
     const int64_t stride = (int64_t)n_slots * kvd;
+    if (ROPE) {
+        const int64_t nch = (int64_t)n_slots * (kvd / 8);
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nch; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t slot = i / (kvd / 8); const int cc = (int)(i - slot * (kvd / 8));
+            const int f = (cc & 15) * 4, c = (cc >> 4) * 128 + f;
+            f32x4_t ka = {0.f, 0.f, 0.f, 0.f}, kb = ka, va = ka, vb = ka;
+            for (int z = 0; z < QS; ++z) {
+                const float* pk = part_k + z * stride + slot * kvd + c;
+                const float* pv = part_v + z * stride + slot * kvd + c;
+                ka += *reinterpret_cast<const f32x4_t*>(pk); kb += *reinterpret_cast<const f32x4_t*>(pk + 64);
+                va += *reinterpret_cast<const f32x4_t*>(pv); vb += *reinterpret_cast<const f32x4_t*>(pv + 64);
+            }
+            const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(cosb + slot * 64 + f), s4 = *reinterpret_cast<const f32x4_t*>(sinb + slot * 64 + f);
+            float oa[4], ob[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf2f(f2bf(ka[j] * scale)), b = bf2f(f2bf(kb[j] * scale));
+                const float sn = -s4[j];
+                oa[j] = a * c4[j] - b * sn; ob[j] = b * c4[j] + a * sn;
+            }
+            *reinterpret_cast<u32x2_t*>(dK + slot * dk_ld + c) = (u32x2_t){pack2bf(oa[0], oa[1]), pack2bf(oa[2], oa[3])};
+            *reinterpret_cast<u32x2_t*>(dK + slot * dk_ld + c + 64) = (u32x2_t){pack2bf(ob[0], ob[1]), pack2bf(ob[2], ob[3])};
+            *reinterpret_cast<u32x2_t*>(dV + slot * dv_ld + c) = (u32x2_t){pack2bf(va[0], va[1]), pack2bf(va[2], va[3])};
+            *reinterpret_cast<u32x2_t*>(dV + slot * dv_ld + c + 64) = (u32x2_t){pack2bf(vb[0], vb[1]), pack2bf(vb[2], vb[3])};
+        }
+        return;
+    }
+    const int64_t nch = (int64_t)n_slots * (kvd / 4);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nch; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = i / (kvd / 4); const int c = (int)(i - slot * (kvd / 4)) * 4;
         f32x4_t ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
@@ -1396,6 +1450,9 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const f
         *reinterpret_cast<u32x2_t*>(dV + slot * dv_ld + c) = wv;
     }
 }
+
+extern "C" int tr1_rope_apply(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* cosb, const void* sinb, int64_t T, int64_t n_heads,
+                              int64_t head_dim, int backward, void* stream);
 
 // wave pairs per block of the 32x32x16 kernel (TR1_DKDV32_NP = 4 | 6): 6 pairs = 12 waves = 3 per SIMD, 192 keys per block
 static int dkdv32_pairs() {
@@ -1498,10 +1555,23 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     else if (use_dma) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(256), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
     else if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
+    const bool rope = p.rope_cos != nullptr;
+    bool dk_rotated = false;
     if (QS > 1) {
         const float scale = p.scale_log2 * 0.6931471805599453f;
-        hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(tr1_grid_1d(p.n_slots * kvd / 4, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
-                           p.n_slots, (int)kvd, QS, scale);
+        if (rope && p.d_real == 128) {
+            hipLaunchKernelGGL(attn_bwd_reduce_kernel<true>, dim3(tr1_grid_1d(p.n_slots * kvd / 8, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
+                               p.n_slots, (int)kvd, QS, scale, p.rope_cos, p.rope_sin);
+            dk_rotated = true;
+        } else
+        hipLaunchKernelGGL(attn_bwd_reduce_kernel<false>, dim3(tr1_grid_1d(p.n_slots * kvd / 4, 256, 2048)), dim3(256), 0, s, pk, pv, p.dK, p.dk_ld, p.dV, p.dv_ld,
+                           p.n_slots, (int)kvd, QS, scale, (const float*)nullptr, (const float*)nullptr);
+    }
+    if (rope) {      // forms without the fused rotation: the separate kernel, in place (a thread reads its pair before writing it)
+        int rc = 0;
+        if (!use_dq32) rc = tr1_rope_apply(p.dQ, p.dq_ld, p.dQ, p.dq_ld, p.rope_cos, p.rope_sin, p.T, (int64_t)p.n_kv * p.group, p.d_real, 1, s);
+        if (!rc && !dk_rotated) rc = tr1_rope_apply(p.dK, p.dk_ld, p.dK, p.dk_ld, p.rope_cos, p.rope_sin, p.n_slots, p.n_kv, p.d_real, 1, s);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -1520,13 +1590,15 @@ extern "C" int64_t tr1_attn_bwd_workspace_floats(int64_t T, int64_t n_heads, int
 }
 
 // Scratch: qmeta_ws int32 [8*ceil(T*group/64)], delta fp32 [2*n_heads*T] (delta | log2-scaled LSE), ws_f32 of tr1_attn_bwd_workspace_floats() floats.
-extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
+static int attn_bwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
                             int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
                             const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,
                             void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32,
                             int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale,
-                            void* stream) {
+                            const void* rope_cos, const void* rope_sin, void* stream) {
     AttnParams p; memset(&p, 0, sizeof(p));
+    p.rope_cos = (const float*)rope_cos; p.rope_sin = (const float*)rope_sin;
+    TR1_CHECK_ARG(!rope_cos || (rope_sin && n_slots == T && head_dim % 16 == 0), "attention bwd: rope tables need sin, n_slots == T and head_dim % 16 == 0");
     TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention bwd: n_heads must be a multiple of n_kv");
     p.Q = (const bf16_t*)Q; p.q_ld = q_ld; p.K = (const bf16_t*)K; p.k_ld = k_ld; p.V = (const bf16_t*)V; p.v_ld = v_ld;
     p.KT = (const bf16_t*)KT; p.kt_ld = kt_ld; p.QT = (const bf16_t*)QT; p.qt_ld = qt_ld; p.dOT = (const bf16_t*)dOT; p.dot_ld = dot_ld;
@@ -1562,4 +1634,28 @@ extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t 
     }
     if (rc) return rc;
     TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_attn_bwd(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
+                            int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
+                            const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,
+                            void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32,
+                            int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale,
+                            void* stream) {
+    return attn_bwd_impl(Q, q_ld, K, k_ld, V, v_ld, KT, kt_ld, QT, qt_ld, dOT, dot_ld, O, o_ld, dO, do_ld, lse, delta, dQ, dq_ld, dK, dk_ld, dV, dv_ld, pre, lo,
+                         hi, qmeta_ws, ws_f32, ws_floats, T, n_heads, n_kv, n_slots, head_dim, scale, nullptr, nullptr, stream);
+}
+
+// The same backward with the M-RoPE backward folded in: dQ and dK are returned with respect to the UN-rotated q / k (what the q|k|v projection produced),
+// i.e. multiplied by the transposed rotary matrix of their row (cos / sin fp32 [T, head_dim / 2]; n_slots == T).  Head dim 128 rotates in the dQ kernel's
+// epilogue and in the partial-sum kernel of dK / dV; other shapes run the rotation kernel in place.  Bit-identical to tr1_attn_bwd + tr1_rope_apply(backward).
+extern "C" int tr1_attn_bwd_rope(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, const void* KT,
+                                 int64_t kt_ld, const void* QT, int64_t qt_ld, const void* dOT, int64_t dot_ld, const void* O, int64_t o_ld,
+                                 const void* dO, int64_t do_ld, const void* lse, void* delta, void* dQ, int64_t dq_ld, void* dK, int64_t dk_ld,
+                                 void* dV, int64_t dv_ld, const void* pre, const void* lo, const void* hi, void* qmeta_ws, void* ws_f32,
+                                 int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale,
+                                 const void* rope_cos, const void* rope_sin, void* stream) {
+    TR1_CHECK_ARG(rope_cos && rope_sin, "attention bwd (rope): cos / sin tables required");
+    return attn_bwd_impl(Q, q_ld, K, k_ld, V, v_ld, KT, kt_ld, QT, qt_ld, dOT, dot_ld, O, o_ld, dO, do_ld, lse, delta, dQ, dq_ld, dK, dk_ld, dV, dv_ld, pre, lo,
+                         hi, qmeta_ws, ws_f32, ws_floats, T, n_heads, n_kv, n_slots, head_dim, scale, rope_cos, rope_sin, stream);
 }

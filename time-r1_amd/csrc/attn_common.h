@@ -49,6 +49,9 @@ struct AttnParams {
     // each of the 8 XCDs (blocks are dealt to them round-robin) walks chunks of 8 CONSECUTIVE blocks of it: the query tiles that share a segment's / a
     // head's K and V tiles then meet in one L2 instead of fetching them from HBM once per XCD.  grid_x / grid_y = the logical grid.
     int grid_x, grid_y, xcd_pad;
+    // backward only: when set, dQ and dK leave the kernels already multiplied by the TRANSPOSED rotary matrix (the backward of M-RoPE, TF:212-222):
+    // fp32 cos / sin tables [T, d / 2]; row t of dQ and slot t of dK use row t
+    const float* rope_cos; const float* rope_sin;
 };
 
 #define ATT_KV 64          // keys per tile

@@ -221,9 +221,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // out[c, r] = in[r, c] for r < R, c < C; out has leading dimension ld_out >= R and columns [R, ld_out) are zero-filled.
 // 64 x 64 tile through LDS with 16-byte global accesses on both sides: rows are read 8 elements per lane, the transposed tile is written
 // 8 elements per lane (the 2-byte-per-lane form this replaces ran at ~1 TB/s and was 4.6 % of the 7B step's kernel time).
+// COLSUM: the tile's column sums are added to colsum[c] (fp32 atomics, one per column and block) - the bias gradient of a Linear taken from the pass that
+// builds dY^T for its weight gradient instead of a second read of dY (tr1_colsum_accum).
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
-                                                        int64_t ld_out, int64_t R, int64_t C) {
+                                                        int64_t ld_out, int64_t R, int64_t C, float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];           // 144-byte rows: 16-byte aligned, conflict-free column reads
+    __shared__ float csum[COLSUM ? 8 : 1][64];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const bool vec_in = (ld_in % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
 #pragma unroll
@@ -250,16 +254,32 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         const int idx = threadIdx.x + i * 256;                             // 64 output rows (c) x 8 chunks of 8 source rows
         const int cc = idx & 63, rr = (idx >> 6) * 8;
         const int64_t c = c0 + cc, r = r0 + rr;
+        if (COLSUM) csum[idx >> 6][cc] = 0.f;
         if (c >= C || r >= ld_out) continue;
         bf16_t t[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = tile[rr + e][cc];               // rows >= R were zero-filled on load: they are the padding
+        if (COLSUM) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += bf2f(t[e]);
+            csum[idx >> 6][cc] = a;
+        }
         if (vec_out && r + 8 <= ld_out) {
             const u32x4_t v = {t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16), t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16)};
             *reinterpret_cast<u32x4_t*>(out + c * ld_out + r) = v;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (r + e < ld_out) out[c * ld_out + r + e] = t[e];
+        }
+    }
+    if (COLSUM) {
+        __syncthreads();
+        if (threadIdx.x < 64 && c0 + threadIdx.x < C && r0 < R) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += csum[j][threadIdx.x];
+            atomicAdd(&colsum[c0 + threadIdx.x], a);
         }
     }
 }
@@ -375,7 +395,15 @@ extern "C" int tr1_transpose_bf16(const void* in, int64_t ld_in, void* out, int6
     TR1_CHECK_ARG(ld_out >= R && ld_in >= C, "transpose: bad leading dimensions");
     if (R == 0 || C == 0) return 0;
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ld_out + 63) / 64));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C, (float*)nullptr);
+    TR1_LAUNCH_CHECK();
+}
+// The same transpose, and colsum_f32[c] += sum_r in[r, c] (the bias gradient rides on the pass that builds dY^T)
+extern "C" int tr1_transpose_colsum_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, void* colsum_f32, void* stream) {
+    TR1_CHECK_ARG(ld_out >= R && ld_in >= C && colsum_f32, "transpose_colsum: bad leading dimensions / missing colsum");
+    if (R == 0 || C == 0) return 0;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ld_out + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C, (float*)colsum_f32);
     TR1_LAUNCH_CHECK();
 }
 

@@ -324,6 +324,8 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
     }
 }
 
+TR1_DEV float epi_silu(float x) { return x / (1.f + __expf(-x)); }
+
 template <bool IS_B, int ROWS>
 TR1_DEV void stage_tile2(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_tile,
                          int wave, int lane) {
@@ -457,24 +459,214 @@ TR1_DEV void stage_round_km(const bf16_t* __restrict__ g, int64_t ld, int64_t n0
     __builtin_amdgcn_global_load_lds((gptr_t)(g + kr * ld + col), (lptr_t)(lds_region + inst * 1024), 16, 0, 0);
 }
 
-template <bool IS_B, int REGION_ROWS>
+// Fused-epilogue forms of the phased NT kernel (EPI template argument of gemm_nt8p_kernel); extra operands travel in GemmEpi.
+//   EPI 2 "gate/up + SwiGLU" (training / prefill / reference forward; TF:459-466 act_fn(gate_proj(x)) * up_proj(x)): B = [2I, K] (gate rows then up
+//         rows).  A block's 256 B-tile rows are 4 x (32 gate rows | the 32 up rows of the SAME intermediate columns), so every wave holds both
+//         halves of 32 columns and the epilogue writes a = silu(g) * u [M, I] (C) and, when the backward needs it, gu (ep.p0) from the same tile.
+//   EPI 3 "down-projection dgrad + SwiGLU backward" (K-major form): C = dgu [M, 2I] = [da * u * silu'(g) | da * silu(g)] with gu read in the epilogue.
+//   EPI 4 "q/k/v projection + bias + M-RoPE" (TF:501-504, :212-222): rotating tiles (q and k heads of 128) hold per wave 32 columns d and their
+//         rotate-half partners d + 64; q goes to C, k to ep.p0 (the K cache rows), v (plain tiles) to ep.p1.
+// All three round exactly where the unfused path rounds (GEMM output to bf16 first), so results are bit-identical to GEMM + elementwise kernel.
+struct GemmEpi {
+    void* p0; void* p1; const float* f0; const float* f1;
+    int64_t ld0, ld1;
+    int i0, i1;
+};
+
+// B-tile row (0..255) -> row of the stored weight for the fused forms; -1 = past the operand (clamped by the caller)
+template <int EPI>
+TR1_DEV int64_t epi_brow(int row, int64_t n0, int64_t N, const GemmEpi& ep) {
+    if (EPI == 2) {
+        const int64_t col = (n0 >> 1) + (row >> 6) * 32 + (row & 31);        // intermediate column
+        const int64_t I = ep.i0;
+        return ((row >> 5) & 1) * I + (col < I ? col : I - 1);
+    }
+    if (EPI == 4) {
+        if (n0 < (int64_t)ep.i0 + ep.i1) return n0 + (row >> 7) * 128 + ((row >> 6) & 1) * 32 + ((row >> 5) & 1) * 64 + (row & 31);
+        const int64_t r = n0 + row;
+        return r < N ? r : N - 1;
+    }
+    const int64_t r = n0 + row;
+    return r < N ? r : N - 1;
+}
+
+template <bool IS_B, int REGION_ROWS, int EPI = 0>
 TR1_DEV void stage_round(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t rows_valid, int64_t k0, char* lds_region,
-                         char* junk, int round, int wave, int lane) {
+                         char* junk, int round, int wave, int lane, const GemmEpi* ep = nullptr) {
     const int inst = round * 8 + wave;                                   // 8 rows (1 KiB) per wave-instruction
     int row = inst * 8 + (lane >> 3);
     char* dst = lds_region + inst * 1024;
     if (REGION_ROWS % 64 != 0 && inst * 8 >= REGION_ROWS) { dst = junk + (wave & 3) * 1024; row = REGION_ROWS - 8 + (lane >> 3); }   // wave-uniform
     const int logical = (lane & 7) ^ (IS_B ? keyB(row) : keyA(row));
-    int64_t grow = row0 + row;
-    if (grow >= rows_valid) grow = rows_valid - 1;
+    int64_t grow;
+    if (IS_B && (EPI == 2 || EPI == 4)) grow = epi_brow<EPI>(row, row0, rows_valid, *ep);
+    else { grow = row0 + row; if (grow >= rows_valid) grow = rows_valid - 1; }
     __builtin_amdgcn_global_load_lds((gptr_t)(g + grow * ld + k0 + logical * 8), (lptr_t)dst, 16, 0, 0);
+}
+
+
+template <int RT, int EPI>
+TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ wave_lds, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+                                int64_t M, int64_t N, int64_t ldc, int64_t mrow0, int64_t n0, int wn, int lane, const GemmEpi& ep) {
+    constexpr int CH = (RT % 2 == 0) ? 4 : 3;
+    const int u = lane & 15, g = lane >> 4;
+    const int c4 = lane & 3, q = (lane >> 2) & 3;
+    const int rr16 = (q & 1) + (q >> 1) * 8 + 2 * (lane >> 4);
+    // column bookkeeping of this lane's 8 pair columns
+    int64_t col_a;              // EPI 2: intermediate column; EPI 4: column inside q (or k) of the "a" half (d < 64)
+    bf16_t *dst_a, *dst_b, *dst_ga = nullptr, *dst_gb = nullptr;
+    int64_t ld_o, ld_g = 0;
+    bool col_ok;
+    u32x4_t ba = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
+    int dcs = 0;                // EPI 4: index of the lane's first column into a row of the cos / sin tables
+    if (EPI == 2) {
+        const int64_t I = ep.i0;
+        col_a = (n0 >> 1) + wn * 32 + c4 * 8;
+        col_ok = col_a + 8 <= I;
+        dst_a = reinterpret_cast<bf16_t*>(Cv) + col_a; dst_b = nullptr; ld_o = ldc;
+        if (ep.p0) { dst_ga = reinterpret_cast<bf16_t*>(ep.p0) + col_a; dst_gb = dst_ga + I; ld_g = ep.ld0; }
+    } else {
+        const int d = (wn & 1) * 32 + c4 * 8;
+        const int64_t ncol = n0 + (wn >> 1) * 128 + d;                  // column of the fused q|k|v projection
+        col_ok = true;
+        dcs = d;
+        if (bias) { ba = *reinterpret_cast<const u32x4_t*>(bias + ncol); bb = *reinterpret_cast<const u32x4_t*>(bias + ncol + 64); }
+        if (n0 < ep.i0) { dst_a = reinterpret_cast<bf16_t*>(Cv) + ncol; ld_o = ldc; }
+        else { dst_a = reinterpret_cast<bf16_t*>(ep.p0) + (ncol - ep.i0); ld_o = ep.ld0; }
+        dst_b = dst_a + 64;
+        col_a = ncol;
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < RT; i0 += CH) {
+        const int cnt = RT - i0 < CH ? RT - i0 : CH;
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+            if (ii < cnt) {
+                const int row = ii * 16 + u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(wave_lds + row * 256 + (((g * 4 + j) ^ u) << 4)) = acc[i0 + ii][j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r16 = 0; r16 < CH; ++r16) {
+            if (r16 < cnt) {
+                const int rr = r16 * 16 + rr16;
+                const char* rowp = wave_lds + rr * 256;
+                const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(rowp + (((2 * c4) ^ rr16) << 4));
+                const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(rowp + (((2 * c4 + 1) ^ rr16) << 4));
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(rowp + (((8 + 2 * c4) ^ rr16) << 4));
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(rowp + (((9 + 2 * c4) ^ rr16) << 4));
+                float va[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                float vb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const int64_t m = mrow0 + i0 * 16 + rr;
+                if (m < M && col_ok) {
+                    u32x4_t oa, ob;
+                    if (EPI == 2) {
+                        u32x4_t pg, pu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pg[e] = pack2bf(va[2 * e], va[2 * e + 1]); pu[e] = pack2bf(vb[2 * e], vb[2 * e + 1]); }
+                        if (dst_ga) {
+                            *reinterpret_cast<u32x4_t*>(dst_ga + m * ld_g) = pg;
+                            *reinterpret_cast<u32x4_t*>(dst_gb + m * ld_g) = pu;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {        // as swiglu_fwd_kernel: on the bf16-rounded gate / up, silu rounded to bf16 before the product
+                            const float x0 = bf2f(f2bf(epi_silu(bflo(pg[e])))) * bflo(pu[e]);
+                            const float x1 = bf2f(f2bf(epi_silu(bfhi(pg[e])))) * bfhi(pu[e]);
+                            oa[e] = pack2bf(x0, x1);
+                        }
+                        *reinterpret_cast<u32x4_t*>(dst_a + m * ld_o) = oa;
+                    } else {
+                        const float* cp = ep.f0 + m * 64 + dcs;
+                        const float* sp = ep.f1 + m * 64 + dcs;
+                        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cp), c1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
+                        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sp), s1 = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                        const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                        const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            va[2 * e] += bflo(ba[e]); va[2 * e + 1] += bfhi(ba[e]); vb[2 * e] += bflo(bb[e]); vb[2 * e + 1] += bfhi(bb[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { va[e] = bf2f(f2bf(va[e])); vb[e] = bf2f(f2bf(vb[e])); }      // the projection output as the unfused path stores it
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {        // as rope_apply_kernel (forward)
+                            oa[e] = pack2bf(va[2 * e] * cc[2 * e] - vb[2 * e] * ss[2 * e], va[2 * e + 1] * cc[2 * e + 1] - vb[2 * e + 1] * ss[2 * e + 1]);
+                            ob[e] = pack2bf(vb[2 * e] * cc[2 * e] + va[2 * e] * ss[2 * e], vb[2 * e + 1] * cc[2 * e + 1] + va[2 * e + 1] * ss[2 * e + 1]);
+                        }
+                        *reinterpret_cast<u32x4_t*>(dst_a + m * ld_o) = oa;
+                        *reinterpret_cast<u32x4_t*>(dst_b + m * ld_o) = ob;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// EPI 3: the wave's 64 columns of da (K-major dgrad of the down projection) -> dgu columns n (gate half) and I + n (up half), as swiglu_bwd_kernel
+template <int RT>
+TR1_DEV void store_acc256_glubwd(const f32x4_t (&acc)[RT][4], char* __restrict__ wave_lds, void* __restrict__ Cv, int64_t M, int64_t N, int64_t ldc,
+                                 int64_t mrow0, int64_t ncol0, int lane, const GemmEpi& ep) {
+    constexpr int CH = (RT % 2 == 0) ? 4 : 3;
+    const int u = lane & 15, g = lane >> 4;
+    const int c8 = lane & 7;
+    const int64_t n = ncol0 + c8 * 8, I = ep.i0;
+    const bf16_t* gu = reinterpret_cast<const bf16_t*>(ep.p0);
+#pragma unroll
+    for (int i0 = 0; i0 < RT; i0 += CH) {
+        const int cnt = RT - i0 < CH ? RT - i0 : CH;
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+            if (ii < cnt) {
+                const int row = ii * 16 + u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(wave_lds + row * 256 + (((g * 4 + j) ^ u) << 4)) = acc[i0 + ii][j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r8 = 0; r8 < CH * 2; ++r8) {
+            if (r8 < cnt * 2) {
+                const int rr = r8 * 8 + (lane >> 3);
+                const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8) ^ (rr & 15)) << 4));
+                const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8 + 1) ^ (rr & 15)) << 4));
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int64_t m = mrow0 + i0 * 16 + rr;
+                if (m < M && n + 8 <= N) {
+                    const u32x4_t gg = *reinterpret_cast<const u32x4_t*>(gu + m * ep.ld0 + n);
+                    const u32x4_t uu = *reinterpret_cast<const u32x4_t*>(gu + m * ep.ld0 + I + n);
+                    u32x4_t og, ou;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gv[2] = {bflo(gg[e]), bfhi(gg[e])}, uv[2] = {bflo(uu[e]), bfhi(uu[e])};
+                        const float dv[2] = {bf2f(f2bf(v[2 * e])), bf2f(f2bf(v[2 * e + 1]))};      // da as the unfused dgrad stores it
+                        float rg[2], ru[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float sg = 1.f / (1.f + __expf(-gv[k]));
+                            const float si = gv[k] * sg;
+                            rg[k] = dv[k] * uv[k] * (sg * (1.f + gv[k] * (1.f - sg)));
+                            ru[k] = dv[k] * si;
+                        }
+                        og[e] = pack2bf(rg[0], rg[1]); ou[e] = pack2bf(ru[0], ru[1]);
+                    }
+                    bf16_t* cp = reinterpret_cast<bf16_t*>(Cv) + m * ldc + n;
+                    *reinterpret_cast<u32x4_t*>(cp) = og;
+                    *reinterpret_cast<u32x4_t*>(cp + I) = ou;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 }
 
 template <bool OUT_F32, bool ACCUM, int RT, bool BKM = false, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
                                                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                                                        int64_t ldr, int tiles_m, int tiles_n) {
+                                                        int64_t ldr, int tiles_m, int tiles_n, const GemmEpi ep) {
     constexpr int BMX = RT * 32;
     constexpr int A_BYTES = BMX * BK * 2, BUF_BYTES = A_BYTES + TILE2_BYTES;
     constexpr int AR = (BMX + 63) / 64;                // A rounds per K-tile; phases 0 / 1 issue AR0 / AR1 of them
@@ -519,7 +711,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 
 #define STAGE_A(t, r) stage_round<false, BMX>(A, lda, m0, M, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES, junk, (r), wave, lane)
 #define STAGE_B(t, r) do { if (BKM) stage_round_km(B, ldb, n0, N, (int64_t)(t) * BK, bkm_kvalid, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, (r), wave, lane); \
-                           else stage_round<true, BN2>(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, junk, (r), wave, lane); } while (0)
+                           else stage_round<true, BN2, EPI>(B, ldb, n0, N, (int64_t)(t) * BK, smem2 + ((t) & 1) * BUF_BYTES + A_BYTES, junk, (r), wave, lane, &ep); } while (0)
     // prologue: tile 0 complete, B of tile 1 in flight
 #pragma unroll
     for (int r = 0; r < 4; ++r) STAGE_B(0, r);
@@ -609,6 +801,14 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 #undef STAGE_B
 #if TR1_EPI_LDS
     // every wave is past its last LDS read (the realignment barrier above): the operand buffers become 8 private staging slices
+    if (EPI == 2 || (EPI == 4 && n0 < (int64_t)ep.i0 + ep.i1))
+        store_acc256_pairs<RT, EPI>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, M, N, ldc, m0 + wm * (RT * 16), n0, wn, lane, ep);
+    else if (EPI == 4)       // V tile: bias only, into its own buffer
+        store_acc256_lds<false, false, RT, 0>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), ep.p1, bias + ep.i0 + ep.i1, nullptr, M, N - ep.i0 - ep.i1,
+                                              ep.ld1, 0, m0 + wm * (RT * 16), n0 - ep.i0 - ep.i1 + wn * 64, lane);
+    else if (EPI == 3)
+        store_acc256_glubwd<RT>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, M, N, ldc, m0 + wm * (RT * 16), n0 + wn * 64, lane, ep);
+    else
     store_acc256_lds<OUT_F32, ACCUM, RT, EPI>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, residual, M, N, ldc, ldr,
                                               m0 + wm * (RT * 16), n0 + wn * 64, lane);
 #else
@@ -1748,7 +1948,7 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
             dim3 grid2((unsigned)(t2m * t2n));
 #define LAUNCH2(OF, AC, R)                                                                                                            \
     do { if (phased) hipLaunchKernelGGL((gemm_nt8p_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
-                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n);                                     \
+                       (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n, GemmEpi{});                          \
     else hipLaunchKernelGGL((gemm_nt256_kernel<OF, AC, R>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
                        (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t2m, (int)t2n); } while (0)
 #define LAUNCH2R(R) do { if (out_f32) { if (accumulate) LAUNCH2(true, true, R); else LAUNCH2(true, false, R); } else LAUNCH2(false, false, R); } while (0)
@@ -1798,7 +1998,7 @@ extern "C" int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
     }
     dim3 grid2((unsigned)(t2m * t2n));
 #define LAUNCHNN(R) hipLaunchKernelGGL((gemm_nt8p_kernel<false, false, R, true>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, \
-                                       (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, (int64_t)0, (int)t2m, (int)t2n)
+                                       (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, (int64_t)0, (int)t2m, (int)t2n, GemmEpi{})
     if (rt == 7) LAUNCHNN(7); else if (rt == 9) LAUNCHNN(9); else if (rt == 10) LAUNCHNN(10); else LAUNCHNN(8);
 #undef LAUNCHNN
     TR1_LAUNCH_CHECK();
@@ -1834,11 +2034,102 @@ extern "C" int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C, int64_
     }
     dim3 grid2((unsigned)(t2m * t2n));
 #define LAUNCHNA(AC, R) hipLaunchKernelGGL((gemm_nt8p_kernel<true, AC, R, true>), grid2, dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, \
-                                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, b_rows, (int)t2m, (int)t2n)
+                                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, b_rows, (int)t2m, (int)t2n, GemmEpi{})
 #define LAUNCHNAR(R) do { if (accumulate) LAUNCHNA(true, R); else LAUNCHNA(false, R); } while (0)
     if (rt == 7) LAUNCHNAR(7); else if (rt == 9) LAUNCHNAR(9); else if (rt == 10) LAUNCHNAR(10); else LAUNCHNAR(8);
 #undef LAUNCHNAR
 #undef LAUNCHNA
+    TR1_LAUNCH_CHECK();
+}
+
+// ---- fused-epilogue training GEMMs (EPI 2 / 3 / 4 of gemm_nt8p_kernel) ----------------------------------------------------------------
+static int epi_pick_rt(int64_t M, int64_t Ntiles) {
+    auto cost = [&](int64_t bm, double eff) {
+        const int64_t t = ((M + bm - 1) / bm) * Ntiles;
+        return (double)((t + 255) / 256) * 256.0 * (double)(bm * BN2) / eff;
+    };
+    static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
+    int rt = 8; double best = cost(256, 1.0);
+    for (int r = 7; r <= 10; ++r) { const double c = cost(r * 32, eff[r - 7]); if (c < best) { best = c; rt = r; } }
+    return rt;
+}
+#define EPI_LAUNCH(KERN_ARGS, RTV, ...)                                                                                                   \
+    do { if (RTV == 7) { hipLaunchKernelGGL((gemm_nt8p_kernel<KERN_ARGS(7)>), __VA_ARGS__); }                                             \
+         else if (RTV == 9) { hipLaunchKernelGGL((gemm_nt8p_kernel<KERN_ARGS(9)>), __VA_ARGS__); }                                        \
+         else if (RTV == 10) { hipLaunchKernelGGL((gemm_nt8p_kernel<KERN_ARGS(10)>), __VA_ARGS__); }                                      \
+         else { hipLaunchKernelGGL((gemm_nt8p_kernel<KERN_ARGS(8)>), __VA_ARGS__); } } while (0)
+#define EPI_SETATTR(KERN_ARGS)                                                                                                             \
+    do { static bool set_ = false; if (!set_) { const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES)) + 4096;                             \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<KERN_ARGS(7)>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<KERN_ARGS(8)>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<KERN_ARGS(9)>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<KERN_ARGS(10)>), hipFuncAttributeMaxDynamicSharedMemorySize, mx); \
+        set_ = true; } } while (0)
+
+// a[M, I] = silu(x Wg^T) * (x Wu^T) with Wgu = [2I, K] (gate rows, then up rows); gu_out (optional) receives the projection itself [M, 2I] for the backward.
+// Bit-identical to tr1_gemm_nt_bf16 + tr1_swiglu_fwd.
+extern "C" int tr1_gemm_glu_bf16(const void* x, const void* Wgu, void* a_out, void* gu_out, int64_t M, int64_t I, int64_t K, int64_t ldx, int64_t ldw,
+                                 int64_t lda, int64_t ldgu, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && I % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && lda % 8 == 0 && (!gu_out || ldgu % 8 == 0), "gemm_glu: K%64, I%8, ld%8 required");
+    TR1_CHECK_ARG(I < (1 << 30), "gemm_glu: I too large");
+    if (M == 0 || I == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t2n = (I + 127) / 128;
+    const int rt = epi_pick_rt(M, t2n);
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+#define KA_GLU(R) false, false, R, false, 2
+    EPI_SETATTR(KA_GLU);
+    GemmEpi ep{}; ep.p0 = gu_out; ep.ld0 = ldgu; ep.i0 = (int)I;
+    EPI_LAUNCH(KA_GLU, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)Wgu, a_out, (const bf16_t*)nullptr,
+               (const bf16_t*)nullptr, M, 2 * I, K, ldx, ldw, lda, (int64_t)0, (int)t2m, (int)t2n, ep);
+#undef KA_GLU
+    TR1_LAUNCH_CHECK();
+}
+
+// Fused q|k|v projection + bias + M-RoPE for head dim 128: q_out[M, n_heads*128] and k_out[M, n_kv*128] rotated (cos / sin fp32 [M, 64]), v_out[M, n_kv*128]
+// plain.  Bit-identical to tr1_gemm_nt_bf16 (bias) + tr1_rope_apply on the q and k columns.  n_heads and n_kv must be even (whole 256-column tiles).
+extern "C" int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ldq,
+                                      void* k_out, int64_t ldk, void* v_out, int64_t ldv, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim,
+                                      int64_t K, int64_t ldx, int64_t ldw, void* stream) {
+    TR1_CHECK_ARG(head_dim == 128 && n_heads % 2 == 0 && n_kv % 2 == 0, "gemm_qkv_rope: head_dim 128 and even head counts required");
+    TR1_CHECK_ARG(K % BK == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "gemm_qkv_rope: K%64, ld%8 required");
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t N = (n_heads + 2 * n_kv) * 128, t2n = N / 256;
+    const int rt = epi_pick_rt(M, t2n);
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+#define KA_QKV(R) false, false, R, false, 4
+    EPI_SETATTR(KA_QKV);
+    GemmEpi ep{}; ep.p0 = k_out; ep.ld0 = ldk; ep.p1 = v_out; ep.ld1 = ldv; ep.f0 = (const float*)cosb; ep.f1 = (const float*)sinb;
+    ep.i0 = (int)(n_heads * 128); ep.i1 = (int)(n_kv * 128);
+    EPI_LAUNCH(KA_QKV, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)Wqkv, q_out, (const bf16_t*)bias,
+               (const bf16_t*)nullptr, M, N, K, ldx, ldw, ldq, (int64_t)0, (int)t2m, (int)t2n, ep);
+#undef KA_QKV
+    TR1_LAUNCH_CHECK();
+}
+
+// dgu[M, 2I] = SwiGLU backward of da = dh[M, H] * Wd[H, I] (Wd = the down projection as stored, K-major operand), with gu[M, 2I] the saved projection.
+// Bit-identical to tr1_gemm_nn_bf16 + tr1_swiglu_bwd; da never exists in HBM.
+extern "C" int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void* dgu, int64_t M, int64_t I, int64_t H, int64_t lda, int64_t ldb,
+                                       int64_t ldgu, int64_t lddgu, void* stream) {
+    TR1_CHECK_ARG(H % BK == 0 && I % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0, "gemm_nn_glubwd: H%64, I%8, ld%8 required");
+    TR1_CHECK_ARG(M >= 512 && I >= 256, "gemm_nn_glubwd: M >= 512 and I >= 256 required");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t2n = (I + BN2 - 1) / BN2;
+    const int rt = epi_pick_rt(M, t2n);
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+#define KA_GB(R) false, false, R, true, 3
+    EPI_SETATTR(KA_GB);
+    GemmEpi ep{}; ep.p0 = const_cast<void*>(gu); ep.ld0 = ldgu; ep.i0 = (int)I;
+    EPI_LAUNCH(KA_GB, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)dh, (const bf16_t*)Wd, dgu, (const bf16_t*)nullptr,
+               (const bf16_t*)nullptr, M, I, H, lda, ldb, lddgu, (int64_t)0, (int)t2m, (int)t2n, ep);
+#undef KA_GB
     TR1_LAUNCH_CHECK();
 }
 
@@ -1900,7 +2191,7 @@ extern "C" int tr1_lmhead_lse_fwd(const void* hn, const void* W, const void* tar
     }
     dim3 grid2((unsigned)(t2m * t2n));
 #define LAUNCHL(R) hipLaunchKernelGGL((gemm_nt8p_kernel<false, false, R, false, 1>), grid2, dim3(512), dyn, s, (const bf16_t*)hn, (const bf16_t*)W, part_ws, \
-                                      (const bf16_t*)targets, (const bf16_t*)nullptr, M, N, K, lda, ldb, ncb + 1, (int64_t)0, (int)t2m, (int)t2n)
+                                      (const bf16_t*)targets, (const bf16_t*)nullptr, M, N, K, lda, ldb, ncb + 1, (int64_t)0, (int)t2m, (int)t2n, GemmEpi{})
     if (rt == 7) LAUNCHL(7); else if (rt == 9) LAUNCHL(9); else if (rt == 10) LAUNCHL(10); else LAUNCHL(8);
 #undef LAUNCHL
     hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)M), dim3(256), 0, s, (const f32x4_t*)part_ws, ncb, (float*)logp, (float*)ent, (float*)lse);

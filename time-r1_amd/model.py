@@ -40,7 +40,7 @@ class Engine:
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
-    def _wgrad(self, dy, x, gw, key=None):
+    def _wgrad(self, dy, x, gw, key=None, bias_g=None):
         """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K].  key (decoder-layer weights): the FIRST weight gradient after an optimizer step (the arena's
         version changed) overwrites gw instead of accumulating - AdamW left it at zero, so the result is identical and the GEMM epilogue skips
         reading 4 bytes per parameter (33 GB per accumulation window at 7B)."""
@@ -56,8 +56,11 @@ class Engine:
         # cost 7 ms of the 154 ms backward (measured with stale non-zero copies), so the backward came out 6 ms SLOWER.
         tn = getattr(ops, "wgrad_tn", None)
         if tn is not None and self.wgrad_tn and tn(dy, x, gw, acc):
+            if bias_g is not None:
+                ops.colsum_accum(dy, bias_g)
             return
-        dyt = ops.transpose(dy)          # [N, Mp], zero-padded columns
+        # bias_g: the Linear's bias gradient (column sums of dy) rides on the pass that builds dy^T
+        dyt = ops.transpose(dy, colsum=bias_g) if bias_g is not None else ops.transpose(dy)          # [N, Mp], zero-padded columns
         # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out).
         # Its transposing LDS reads cost 8-17 % of the GEMM rate (tools/bench_wgrad.py: 1060 against 1244 TFLOP/s at the down-projection
         # shape), so it only pays where the saved transpose is the larger piece: x at least twice as wide as dy (the down projection,
@@ -77,13 +80,13 @@ class Engine:
             self._side = torch.cuda.Stream(device=self.ops.device)
         return self._side
 
-    def _wgrad_async(self, dy, x, gw, side, key=None):
+    def _wgrad_async(self, dy, x, gw, side, key=None, bias_g=None):
         if side is None:
-            return self._wgrad(dy, x, gw, key)
+            return self._wgrad(dy, x, gw, key, bias_g)
         main = torch.cuda.current_stream(self.ops.device)
         side.wait_stream(main)                         # dy (and every earlier write of gw) is ordered before the side work
         with torch.cuda.stream(side):
-            self._wgrad(dy, x, gw, key)
+            self._wgrad(dy, x, gw, key, bias_g)
         dy.record_stream(side)                         # keep the caching allocator from recycling them under the side stream
         x.record_stream(side)
 
@@ -205,7 +208,7 @@ class Engine:
             self.ops.scatter_rows(vid_embeds, vid_rows, h)
         return h
 
-    SAVED = ("h", "xn", "qkv", "q", "o", "h2", "xn2", "gu", "a")
+    SAVED = ("h", "xn", "v", "q", "o", "h2", "xn2", "gu", "a")
 
     # A full set of saved-activation buffers above this size is kept ONCE: further prompts of the accumulation window stash only their
     # prompt rows (written by the rollout prefill) and move them into the one full set when their update starts (unstash_ctx).
@@ -213,7 +216,7 @@ class Engine:
 
     def ctx_bytes(self, rows):
         t = self.cfg.text
-        return rows * t.n_layers * (2 * (4 * t.hidden + t.qkv_dim + 2 * t.q_dim + 3 * t.intermediate) + 8)
+        return rows * t.n_layers * (2 * (4 * t.hidden + t.kv_dim + 2 * t.q_dim + 3 * t.intermediate) + 8)
 
     def alloc_ctx_bufs(self, total_rows, slot=0, prefill_rows=None):
         """Saved-activation buffers for a packed sequence of `total_rows` rows that is run in two pieces (prompt rows during the rollout
@@ -232,7 +235,7 @@ class Engine:
         if ent is None or ent[0] < rows:
             pool[key] = None          # release the smaller set before allocating the larger one
             cap = (rows + 255) // 256 * 256
-            cols = dict(h=t.hidden, xn=t.hidden, qkv=t.qkv_dim, q=t.q_dim, o=t.q_dim, h2=t.hidden, xn2=t.hidden, gu=2 * t.intermediate, a=t.intermediate)
+            cols = dict(h=t.hidden, xn=t.hidden, v=t.kv_dim, q=t.q_dim, o=t.q_dim, h2=t.hidden, xn2=t.hidden, gu=2 * t.intermediate, a=t.intermediate)
             full = []
             for _ in range(t.n_layers):
                 L = {k: ops.empty(cap, c) for k, c in cols.items()}
@@ -279,38 +282,39 @@ class Engine:
         for i in range(t.n_layers):
             p = "l%d." % i
             xn, rstd1, _ = ops.rmsnorm_fwd(h, arena.w(p + "ln1"), t.rms_eps, need_rstd=save, out=dst(i, "xn"), rstd_out=dst(i, "rstd1"))
-            qkv = ops.gemm_nt(xn, arena.w(p + "qkv.w"), bias=arena.w(p + "qkv.b"), out=dst(i, "qkv"))
-            q = ops.rope_apply(qkv[:, :qd], t.n_heads, hd, cos, sin, out=dst(i, "q"))
-            # head dim 128: the forward kernel reads V row-major (it transposes in its LDS reads); V^T is then only built where a later decode
-            # needs it in the cache (rollout prefill / continuation), not for the reference-policy and plain training forwards
-            rows_ok = getattr(ops, "attn_fwd_rows_ok", lambda *a: False)(hd)
-            v_rows = None
+            # q|k|v projection + bias + M-RoPE in one launch (the GEMM epilogue rotates q and k; k lands in the KV cache rows when there is one).
+            # The un-rotated q / k are never stored: nothing reads them again (the backward needs q, k rotated and v).
+            rows_ok = getattr(ops, "attn_fwd_rows_ok", lambda *a, **kw: False)(hd)
+            kc = vtc = None
             if kv_cache is not None:
                 kc, vtc = kv_cache[i]
-                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin, out=kc[row0:S])
+            q, k, v = ops.gemm_qkv_rope(xn, arena.w(p + "qkv.w"), arena.w(p + "qkv.b"), cos, sin, t.n_heads, t.n_kv_heads, hd, q_out=dst(i, "q"),
+                                        k_out=kc[row0:S] if kc is not None else None, v_out=dst(i, "v"))
+            # head dim 128: the forward kernel reads V row-major (it transposes in its LDS reads); V^T is then only built where a later decode
+            # needs it in the cache (rollout prefill / continuation), not for the reference-policy and plain training forwards
+            v_rows = None
+            if kv_cache is not None:
                 if row0 == 0:
-                    vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc)
-                    v_rows = qkv[:, qd + kvd:] if rows_ok else None
+                    vt = ops.pack_transpose(v, t.n_kv_heads, t.n_kv_heads, hd, out=vtc)
+                    v_rows = v if rows_ok else None
                 else:
-                    vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd, out=vtc[:, row0:], zero_pad=False)
+                    vt = ops.pack_transpose(v, t.n_kv_heads, t.n_kv_heads, hd, out=vtc[:, row0:], zero_pad=False)
                     vt = vtc
                     if rows_ok and inplace:      # the prefix rows' V sits in the shared activation buffers (written by the prefill)
-                        v_rows = bufs[i]["qkv"][:S, qd + kvd:]
+                        v_rows = bufs[i]["v"][:S]
                 k_all = kc
             else:
-                k = ops.rope_apply(qkv[:, qd:qd + kvd], t.n_kv_heads, hd, cos, sin)
-                v_rows = qkv[:, qd + kvd:] if rows_ok else None
-                vt = ops.pack_transpose(qkv[:, qd + kvd:], t.n_kv_heads, t.n_kv_heads, hd) if v_rows is None else None
+                v_rows = v if rows_ok else None
+                vt = ops.pack_transpose(v, t.n_kv_heads, t.n_kv_heads, hd) if v_rows is None else None
                 k_all = k
             o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save, out=dst(i, "o"),
                                   **({"v_rows": v_rows} if v_rows is not None else {}))
             h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h, out=dst(i, "h2"))
             xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save, out=dst(i, "xn2"), rstd_out=dst(i, "rstd2"))
-            gu = ops.gemm_nt(xn2, arena.w(p + "gu.w"), out=dst(i, "gu"))
-            a = ops.swiglu_fwd(gu, out=dst(i, "a"))
+            a, gu = ops.gemm_glu(xn2, arena.w(p + "gu.w"), a_out=dst(i, "a"), gu_out=dst(i, "gu"), save_gu=save)     # SwiGLU in the GEMM epilogue
             h_out = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2, out=dst(i + 1, "h") if inplace and i + 1 < t.n_layers else None)
             if save:
-                layers.append(dict(h=h, rstd1=rstd1, xn=xn, qkv=qkv, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
+                layers.append(dict(h=h, rstd1=rstd1, xn=xn, v=v, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
             h = h_out
         ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin, h_last=h, bufs=bufs if inplace else None) if save else None
         return h, ctx
@@ -324,7 +328,7 @@ class Engine:
         shared = ctx_a.get("bufs") is not None and ctx_a.get("bufs") is ctx_b.get("bufs")
         for i, (a, b) in enumerate(zip(ctx_a["layers"], ctx_b["layers"])):
             L = {}
-            for key in ("h", "xn", "qkv", "q", "o", "h2", "xn2", "gu", "a", "rstd1", "rstd2"):
+            for key in ("h", "xn", "v", "q", "o", "h2", "xn2", "gu", "a", "rstd1", "rstd2"):
                 L[key] = ctx_a["bufs"][i][key][:M] if shared else torch.cat([a[key], b[key]], 0)
             L["lse"] = torch.cat([a["lse"], b["lse"]], 1).contiguous()
             L["k"] = kv_cache[i][0][:M]
@@ -349,8 +353,7 @@ class Engine:
             # h_out = a @ Wd^T + h2
             _sync = self.wgrad_on_main
             self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side, key=p + "down.w")
-            da = self._dgrad(dh, tr.w(p + "down.w"), key=p + "down.w")
-            dgu = ops.swiglu_bwd(da, L["gu"])
+            dgu = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"])       # down-projection dgrad with the SwiGLU backward in its epilogue
             self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side, key=p + "gu.w")
             dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"), key=p + "gu.w")
             dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))
@@ -358,13 +361,11 @@ class Engine:
             self._wgrad_async(dh2, L["o"], tr.g(p + "o.w"), None if "o" in _sync else side, key=p + "o.w")
             do = self._dgrad(dh2, tr.w(p + "o.w"), key=p + "o.w")
             dqkv = ops.empty(M, t.qkv_dim)
-            v = L["qkv"][:, qd + kvd:]
-            dq, dk, _ = ops.attn_bwd(L["q"], L["k"], v, L["o"], do, L["lse"], pre, lo, hi, t.n_heads, t.n_kv_heads, M, hd, scale,
-                                     dv_out=dqkv[:, qd + kvd:])
-            ops.rope_apply(dq, t.n_heads, hd, cos, sin, backward=True, out=dqkv[:, :qd])
-            ops.rope_apply(dk, t.n_kv_heads, hd, cos, sin, backward=True, out=dqkv[:, qd:qd + kvd])
-            ops.colsum_accum(dqkv, tr.g(p + "qkv.b"))
-            self._wgrad_async(dqkv, L["xn"], tr.g(p + "qkv.w"), None if "q" in _sync else side, key=p + "qkv.w")
+            # attention backward writes dq | dk | dv straight into the columns of dqkv, dq and dk already rotated back (M-RoPE backward in the
+            # kernels' epilogues); the bias gradient is summed by the transpose that feeds the weight gradient
+            ops.attn_bwd(L["q"], L["k"], L["v"], L["o"], do, L["lse"], pre, lo, hi, t.n_heads, t.n_kv_heads, M, hd, scale,
+                         dq_out=dqkv[:, :qd], dk_out=dqkv[:, qd:qd + kvd], dv_out=dqkv[:, qd + kvd:], rope=(cos, sin))
+            self._wgrad_async(dqkv, L["xn"], tr.g(p + "qkv.w"), None if "q" in _sync else side, key=p + "qkv.w", bias_g=tr.g(p + "qkv.b"))
             dxn = self._dgrad(dqkv, tr.w(p + "qkv.w"), key=p + "qkv.w")
             dh = ops.rmsnorm_bwd(dxn, L["h"], tr.w(p + "ln1"), L["rstd1"], dres=dh2, dw=tr.g(p + "ln1"))
             ctx["layers"][i] = None  # release this layer's activations

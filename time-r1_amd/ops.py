@@ -152,6 +152,57 @@ class HipOps:
                     _ld(residual) if residual is not None else 0, int(out_f32), int(accumulate), self._s())
         return out
 
+    # ---- fused-epilogue training GEMMs (bit-identical to the compositions in their `else` branches) ---------------------
+    FUSE_EPI = os.environ.get("TR1_FUSE_EPI", "1") != "0"          # A/B switch: 0 = GEMM + separate elementwise kernels (the round-3 path)
+
+    def gemm_glu(self, x, w_gu, a_out=None, gu_out=None, save_gu=True):
+        """(a, gu): a[M, I] = silu(x Wg^T) * (x Wu^T); gu = the projection [M, 2I] (None unless save_gu)."""
+        self._chk(x, w_gu, a_out, gu_out)
+        M, K = x.shape
+        I = w_gu.shape[0] // 2
+        if self.FUSE_EPI and M > 64 and K % 64 == 0 and I % 8 == 0 and x.stride(1) == 1 and w_gu.stride(1) == 1:
+            a = a_out if a_out is not None else self.empty(M, I)
+            gu = (gu_out if gu_out is not None else self.empty(M, 2 * I)) if save_gu else None
+            self.L.call("tr1_gemm_glu_bf16", _p(x), _p(w_gu), _p(a), _p(gu), M, I, K, _ld(x), _ld(w_gu), _ld(a), _ld(gu) if gu is not None else 0, self._s())
+            return a, gu
+        gu = self.gemm_nt(x, w_gu, out=gu_out)
+        return self.swiglu_fwd(gu, out=a_out), (gu if save_gu else None)
+
+    def gemm_qkv_rope(self, x, w_qkv, bias, cos, sin, n_heads, n_kv, head_dim, q_out=None, k_out=None, v_out=None):
+        """(q, k, v) of the fused projection with bias, q and k rotated (M-RoPE tables cos / sin fp32 [M, head_dim / 2]); outputs may be views."""
+        self._chk(x, w_qkv, bias, q_out, k_out, v_out)
+        M, K = x.shape
+        qd, kvd = n_heads * head_dim, n_kv * head_dim
+        if (self.FUSE_EPI and M > 64 and head_dim == 128 and n_heads % 2 == 0 and n_kv % 2 == 0 and K % 64 == 0 and x.stride(1) == 1 and w_qkv.stride(1) == 1
+                and bias is not None):
+            assert cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (M, 64)
+            q = q_out if q_out is not None else self.empty(M, qd)
+            k = k_out if k_out is not None else self.empty(M, kvd)
+            v = v_out if v_out is not None else self.empty(M, kvd)
+            self.L.call("tr1_gemm_qkv_rope_bf16", _p(x), _p(w_qkv), _p(bias), _p(cos), _p(sin), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), M, n_heads, n_kv,
+                        head_dim, K, _ld(x), _ld(w_qkv), self._s())
+            return q, k, v
+        qkv = self.gemm_nt(x, w_qkv, bias=bias)
+        q = self.rope_apply(qkv[:, :qd], n_heads, head_dim, cos, sin, out=q_out)
+        k = self.rope_apply(qkv[:, qd:qd + kvd], n_kv, head_dim, cos, sin, out=k_out)
+        v = qkv[:, qd + kvd:]
+        if v_out is not None:
+            v_out.copy_(v)
+            v = v_out
+        return q, k, v
+
+    def dgrad_glu_bwd(self, dh, w_down, gu):
+        """dgu[M, 2I] = swiglu_bwd(dh @ w_down, gu) with w_down [H, I] as stored (K-major operand)."""
+        self._chk(dh, w_down, gu)
+        M, H = dh.shape
+        I = w_down.shape[1]
+        if (self.FUSE_EPI and M >= 512 and I >= 256 and H % 64 == 0 and I % 8 == 0 and dh.stride(1) == 1 and w_down.stride(1) == 1 and gu.stride(1) == 1
+                and ((M + 255) // 256) * ((I + 255) // 256) >= 192):
+            dgu = self.empty(M, 2 * I)
+            self.L.call("tr1_gemm_nn_glubwd_bf16", _p(dh), _p(w_down), _p(gu), _p(dgu), M, I, H, _ld(dh), _ld(w_down), _ld(gu), _ld(dgu), self._s())
+            return dgu
+        return self.swiglu_bwd(self.gemm_nn(dh, w_down), gu)
+
     def norm_gemm(self, x, lnw, eps, w, bias=None, glu=False):
         """Decode rows: rmsnorm(x; lnw) @ w^T (+bias), or with glu=True silu(gate)*up of the [2I, K] weight - one launch."""
         self._chk(x, lnw, w, bias)
@@ -261,14 +312,19 @@ class HipOps:
                     residual.stride(0) if residual is not None else 0, _p(ws), n, self._s())
         return out
 
-    def transpose(self, x, pad_to=64, out=None):
-        """x[R,C] -> [C, Rpad] with zero-filled padding columns (Rpad = R rounded up to pad_to)."""
+    def transpose(self, x, pad_to=64, out=None, colsum=None):
+        """x[R,C] -> [C, Rpad] with zero-filled padding columns (Rpad = R rounded up to pad_to).  colsum (fp32 [C]): += the column sums of x
+        (the bias gradient of a Linear, taken from the pass that builds dY^T for its weight gradient)."""
         self._chk(x)
         R, C = x.shape
         Rp = (R + pad_to - 1) // pad_to * pad_to
         if out is None:
             out = self.empty(C, Rp)
         assert out.shape[0] == C and out.shape[1] >= R
+        if colsum is not None:
+            assert colsum.dtype == F32 and colsum.numel() == C and colsum.is_contiguous()
+            self.L.call("tr1_transpose_colsum_bf16", _p(x), _ld(x), _p(out), _ld(out), R, C, _p(colsum), self._s())
+            return out
         self.L.call("tr1_transpose_bf16", _p(x), _ld(x), _p(out), _ld(out), R, C, self._s())
         return out
 
@@ -501,8 +557,10 @@ class HipOps:
         K / V with 32-bit DMA offsets: operands of n_slots rows x ld elements must stay below 4 GiB (csrc/attn_fwd32.hip, tr1_attn_fwd_rows)."""
         return self.FWD32 and head_dim == 128 and nsplit == 1 and n_batch == 1 and n_slots * ld * 2 < 0xffffffff
 
-    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None):
-        """-> dq [T, n_heads*hd], dk, dv [n_slots, n_kv*hd]. Builds the transposed operand copies it needs."""
+    def attn_bwd(self, q, k, v, o, do, lse, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, dv_out=None, dq_out=None, dk_out=None, rope=None):
+        """-> dq [T, n_heads*hd], dk, dv [n_slots, n_kv*hd]. Builds the transposed operand copies it needs.
+        rope=(cos, sin) (fp32 [T, hd/2]): dq / dk come back already multiplied by the transposed rotary matrix (the M-RoPE backward folded into the
+        kernels' epilogues), i.e. they are the gradients of the UN-rotated projections; dq_out / dk_out / dv_out may be column views of one buffer."""
         self._chk(q, k, v, o, do)
         T = q.shape[0]
         group = n_heads // n_kv
@@ -510,16 +568,25 @@ class HipOps:
         if (head_dim + 31) // 32 * 32 not in (64, 128):     # the 8-wave dK/dV kernel reads Q^T / dO^T straight from the row-major tiles
             qt = self.pack_transpose(q, n_heads, n_kv, head_dim)
             dot = self.pack_transpose(do, n_heads, n_kv, head_dim)
-        dq = self.empty(T, n_heads * head_dim)
-        dk = self.empty(n_slots, n_kv * head_dim)
+        dq = dq_out if dq_out is not None else self.empty(T, n_heads * head_dim)
+        dk = dk_out if dk_out is not None else self.empty(n_slots, n_kv * head_dim)
         dv = dv_out if dv_out is not None else self.empty(n_slots, n_kv * head_dim)
         delta = self.empty(2 * n_heads, T, dtype=F32)       # [delta | log2-scaled LSE], both written by the backward's first kernel
         qmeta = self._workspace("attn_qmeta", 8 * ((T * group + 63) // 64), I32)
         nws = self.L.raw("tr1_attn_bwd_workspace_floats")(T, n_heads, n_kv, n_slots, head_dim)
         ws = self._workspace("attn_bwd_part", nws, F32) if nws else None
-        self.L.call("tr1_attn_bwd", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), None, 0, _p(qt), _ld(qt) if qt is not None else 0, _p(dot), _ld(dot) if dot is not None else 0,
-                    _p(o), _ld(o), _p(do), _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(pre), _p(lo),
-                    _p(hi), _p(qmeta), _p(ws), nws, T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
+        args = (_p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), None, 0, _p(qt), _ld(qt) if qt is not None else 0, _p(dot), _ld(dot) if dot is not None else 0,
+                _p(o), _ld(o), _p(do), _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(pre), _p(lo),
+                _p(hi), _p(qmeta), _p(ws), nws, T, n_heads, n_kv, n_slots, head_dim, float(scale))
+        if rope is not None and self.FUSE_EPI:
+            cos, sin = rope
+            assert cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (T, head_dim // 2) and n_slots == T
+            self.L.call("tr1_attn_bwd_rope", *args, _p(cos), _p(sin), self._s())
+            return dq, dk, dv
+        self.L.call("tr1_attn_bwd", *args, self._s())
+        if rope is not None:
+            self.rope_apply(dq, n_heads, head_dim, rope[0], rope[1], backward=True, out=dq)
+            self.rope_apply(dk, n_kv, head_dim, rope[0], rope[1], backward=True, out=dk)
         return dq, dk, dv
 
     # ---- video preprocessing --------------------------------------------------------------------------------------
