@@ -224,6 +224,10 @@ int tr1_adamw_step(void* p_f32, void* m_f32, void* v_f32, void* g_f32, void* p_b
 /* Data-parallel forms: the all-reduced gradient is consumed from its bf16 wire buffer (no copy back into the fp32 accumulator, which is only
  * zeroed).  ref: DeepSpeed's bf16 gradient all-reduce + FusedAdam (scripts/zero3.json:13-33). */
 int tr1_adamw_step_g16(void* p_f32, void* m_f32, void* v_f32, void* g_f32, const void* g_bf16, void* p_bf16, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const void* sumsq_scalar, float max_norm, float grad_mult, int zero_grad, void* stream);
+/* g[base + l*stride + r] = 0 for l < count, r in the <= 8 half-open ranges (rel_ranges = HOST array of 2*n_ranges offsets inside one period): clears the small
+ * per-layer gradient tensors when the optimizer leaves the large matrices un-zeroed (their weight-gradient GEMMs overwrite them on the first micro-step of the
+ * next accumulation window).  ref: optimizer.zero_grad() in HF Trainer.training_step / DeepSpeed engine.step (scripts/zero3.json). */
+int tr1_zero_ranges_periodic(void* g_f32, int64_t base, int64_t stride, int64_t count, const int64_t* rel_ranges, int64_t n_ranges, void* stream);
 int tr1_sumsq_accum_bf16(const void* g_bf16, int64_t n, void* out_scalar, void* stream);
 
 #ifdef __cplusplus

@@ -482,6 +482,11 @@ class RefOps:
                 finished[r] = 1
 
     # ---- optimizer (ref: torch.optim.AdamW semantics = DeepSpeed FusedAdam adam_w_mode; clip = clip_grad_norm_)
+    def zero_ranges_periodic(self, g, base, stride, count, rel_ranges):
+        for l in range(count):
+            for a, b in rel_ranges:
+                g[base + l * stride + a: base + l * stride + b] = 0
+
     def sumsq_accum(self, g, out_scalar):
         out_scalar += (g.double() ** 2).sum().float()
 

@@ -78,3 +78,15 @@ def pick_grad(cfg, get, hf_key):
     if part == "v":
         return g[t.q_dim + t.kv_dim:]
     return g
+
+
+def grads_cleared(tr):
+    """After an optimizer step: everything that ACCUMULATES from zero is zero again.  The decoder layers' large matrices may keep the last window's values -
+    the first weight-gradient GEMM of the next window overwrites them (Engine.lazy_zero_plan / AdamWFlat.lazy_zero)."""
+    g = tr.params.train.grad.clone()
+    lz = tr.optimizer.lazy_zero
+    if lz:
+        for l in range(lz["count"]):
+            for a, b in lz["keep"]:
+                g[lz["base"] + l * lz["stride"] + a: lz["base"] + l * lz["stride"] + b] = 0
+    return float(g.abs().max()) == 0.0

@@ -240,7 +240,7 @@ def test_config4_decode_32_rows_and_clip_loss_full_width(hip_ops):
 def test_row_chunked_lm_head_on_hip(hip_ops, monkeypatch):
     """The chunked head (config 4: logits for at most HEAD_CHUNK_ROWS rows at a time, recomputed in the backward) on the HIP path:
     same micro-step as the whole-head path, within the bf16 noise of re-running the same GEMM on row slices."""
-    from helpers import load_case, frames_for
+    from helpers import load_case, frames_for, grads_cleared
     from time_r1_amd.model import Engine
     fx = load_case("clip_beta")
     out = []
@@ -308,7 +308,7 @@ def test_trainer_train_checkpoint_resume_on_hip(hip_ops, tmp_path, gpu_pre):
     logs = tr.state.log_history
     assert len(logs) == 4 and all(np.isfinite(l["loss"]) and np.isfinite(l["grad_norm"]) and l["grad_norm"] > 0 for l in logs)
     assert logs[0]["learning_rate"] > logs[-1]["learning_rate"] > 0
-    assert not torch.equal(w0, tr.params.train.w16) and float(tr.params.train.grad.abs().max()) == 0.0
+    assert not torch.equal(w0, tr.params.train.w16) and grads_cleared(tr)
     st = json.load(open(tmp_path / "a" / "checkpoint-2" / "trainer_state.json"))
     assert st["global_step"] == 2 and os.path.exists(tmp_path / "a" / "checkpoint-2" / "model.safetensors")
     tr2 = make(tmp_path / "b")

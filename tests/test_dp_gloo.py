@@ -44,7 +44,7 @@ def _worker(rank, world, port, q, wire):
     tr.optimizer.step()
     assert not tr.optimizer.sync.active
     # numpy (pickled by value): torch tensors travel through shared-memory handles that die with a worker that exits before the parent reads
-    q.put((rank, tr.params.train.master.numpy().copy(), gathered.tolist(), dict(tr._metrics)))
+    q.put((rank, tr.params.train.master.numpy().copy(), gathered.tolist(), dict(tr.flush_metrics())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -112,7 +112,8 @@ def _worker_sharded(rank, world, port, q, wire, shard):
         if shard:
             assert tr.optimizer.sync.active and len(tr.optimizer.sync.pending) >= cfg.text.n_layers, "layer segments must be in flight before step()"
         norms.append(float(tr.optimizer.step()))
-        assert float(a.grad.abs().max()) == 0.0
+        from helpers import grads_cleared
+        assert grads_cleared(tr)
     master_full = torch.zeros(a.numel)
     if shard:
         for (ca, cb, la) in a.chunks():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import frames_for, CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad
+from helpers import frames_for, CASES, load_case, golden_params, HF_GRAD_KEYS, pick_grad, grads_cleared
 from oracle.ref_ops import RefOps
 from oracle.text import FakeProcessor
 import time_r1_amd  # noqa: F401
@@ -176,7 +176,7 @@ def test_train_loop_callbacks_checkpoint_resume(tmp_path):
     assert len(logs) == 4 and {"loss", "grad_norm", "learning_rate", "reward", "kl", "completion_length", "generation_entropy"} <= set(logs[0])
     assert logs[0]["learning_rate"] > logs[-1]["learning_rate"] > 0      # linear decay
     assert not torch.equal(w0, tr.params.train.w16)                      # weights moved
-    assert float(tr.params.train.grad.abs().max()) == 0.0                # grads zeroed by the fused optimizer step
+    assert grads_cleared(tr)                # grads zeroed by the fused optimizer step
     # checkpoint layout used by the reference's resume arithmetic (main.py:589-618)
     st = json.load(open(os.path.join(out, "checkpoint-2", "trainer_state.json")))
     assert st["global_step"] == 2 and os.path.exists(os.path.join(out, "checkpoint-2", "model.safetensors"))

@@ -128,3 +128,27 @@ extern "C" int tr1_sumsq_accum_bf16(const void* g_bf16, int64_t n, void* out_sca
     hipLaunchKernelGGL(sumsq_bf16_kernel, dim3(tr1_grid_1d(n / 8 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g_bf16, n, (float*)out_scalar);
     TR1_LAUNCH_CHECK();
 }
+
+// g[base + l * stride + r] = 0 for l < count and r in the (at most 8) half-open ranges rel[2i], rel[2i+1]: the SMALL per-layer tensors of the gradient arena
+// (norm weights, biases, padding).  The weight-gradient GEMMs OVERWRITE the large matrices on the first micro-step of every accumulation window, so the
+// optimizer no longer zeroes those (4 of its 34 bytes per parameter); what still accumulates from zero is cleared by this launch (a few KB per layer).
+struct ZeroRanges { int64_t a[8], b[8]; int n; };
+__global__ __launch_bounds__(256) void zero_periodic_kernel(float* __restrict__ g, int64_t base, int64_t stride, ZeroRanges zr) {
+    float* gl = g + base + (int64_t)blockIdx.y * stride;
+    for (int r = 0; r < zr.n; ++r)
+        for (int64_t i = zr.a[r] + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < zr.b[r]; i += (int64_t)gridDim.x * blockDim.x) gl[i] = 0.f;
+}
+extern "C" int tr1_zero_ranges_periodic(void* g_f32, int64_t base, int64_t stride, int64_t count, const int64_t* rel_ranges, int64_t n_ranges, void* stream) {
+    TR1_CHECK_ARG(n_ranges >= 0 && n_ranges <= 8 && (n_ranges == 0 || rel_ranges), "zero_ranges_periodic: at most 8 ranges");
+    if (count <= 0 || n_ranges == 0) return 0;
+    ZeroRanges zr; zr.n = (int)n_ranges;
+    int64_t longest = 1;
+    for (int i = 0; i < zr.n; ++i) {
+        zr.a[i] = rel_ranges[2 * i]; zr.b[i] = rel_ranges[2 * i + 1];
+        TR1_CHECK_ARG(zr.a[i] >= 0 && zr.b[i] >= zr.a[i] && zr.b[i] <= stride, "zero_ranges_periodic: range outside the period");
+        if (zr.b[i] - zr.a[i] > longest) longest = zr.b[i] - zr.a[i];
+    }
+    const unsigned gx = (unsigned)((longest + 255) / 256 < 64 ? (longest + 255) / 256 : 64);
+    hipLaunchKernelGGL(zero_periodic_kernel, dim3(gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, (float*)g_f32, base, stride, zr);
+    TR1_LAUNCH_CHECK();
+}

@@ -70,6 +70,31 @@ class Engine:
             return
         ops.gemm_nt(dyt, ops.transpose(x), out_f32=True, out=gw, accumulate=acc)
 
+    OVERWRITTEN = ("qkv.w", "o.w", "gu.w", "down.w")      # per-layer matrices whose first weight gradient of a window overwrites (see _wgrad)
+
+    def lazy_zero_plan(self):
+        """What the optimizer may leave un-zeroed: with wgrad_overwrite_first the four large matrices of every decoder layer are OVERWRITTEN by the first
+        micro-step of the next window, so zeroing them (4 of AdamW's 34 bytes per parameter, 30 GB per step at 7B) is wasted work.  Returns
+        dict(base, stride, count, keep=[(a, b) relative to a layer's start]) for AdamWFlat.lazy_zero, or None when the layout / settings do not allow it."""
+        t, a = self.cfg.text, self.params.train
+        if not self.wgrad_overwrite_first or a.grad is None or t.n_layers < 1:
+            return None
+        base = a.offsets["l0.ln1"][0]
+        stride = (a.offsets["l1.ln1"][0] - base) if t.n_layers > 1 else (a.range_of("l0.")[1] - base)
+        keep = []
+        for i in range(t.n_layers):
+            rel = []
+            for nm in self.OVERWRITTEN:
+                off, shape = a.offsets["l%d.%s" % (i, nm)]
+                rel.append((off - base - i * stride, off - base - i * stride + int(np.prod(shape))))
+            if i == 0:
+                keep = rel
+            elif rel != keep:
+                return None          # layers are not laid out periodically
+        if a.range_of("l%d." % (t.n_layers - 1))[1] > base + stride * t.n_layers:
+            return None
+        return dict(base=int(base), stride=int(stride), count=int(t.n_layers), keep=sorted(keep))
+
     # Weight gradients of the decoder layers on a second HIP stream: wgrad (dy^T x) and dgrad (dy W) of a Linear only share their input,
     # so the two GEMM chains run concurrently and each fills the CUs the other leaves idle in its last, partially filled round of tiles
     # (M = 5074 rows against 128/256-row tiles: 1.5-2.2 rounds per GEMM).

@@ -673,6 +673,14 @@ class HipOps:
         assert g.dtype in (F32, BF16) and out_scalar.dtype == F32
         self.L.call("tr1_sumsq_accum" if g.dtype == F32 else "tr1_sumsq_accum_bf16", _p(g), g.numel(), _p(out_scalar), self._s())
 
+    def zero_ranges_periodic(self, g, base, stride, count, rel_ranges):
+        """g[base + l*stride + r] = 0 for l < count and r in the half-open `rel_ranges` [(a, b), ...] (<= 8) of one period."""
+        import ctypes
+        assert g.dtype == F32 and g.is_contiguous() and base >= 0 and base + stride * count <= g.numel() and len(rel_ranges) <= 8
+        flat = [int(x) for ab in rel_ranges for x in ab]
+        arr = (ctypes.c_int64 * max(1, len(flat)))(*flat)
+        self.L.call("tr1_zero_ranges_periodic", _p(g), int(base), int(stride), int(count), arr, len(rel_ranges), self._s())
+
     def adamw_step(self, p32, m, v, g, p16, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0, grad_mult=1.0,
                    zero_grad=True, g16=None):
         """g16: read the gradient from this bf16 array instead of `g` (the all-reduced wire buffer); `g` is then only zeroed."""

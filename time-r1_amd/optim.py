@@ -27,6 +27,25 @@ class AdamWFlat:
             self.sync = GradSync(params.train.grad, self.dp, wire_dtype=grad_wire_dtype)
         self._sumsq = ops.zeros(1, dtype=torch.float32)
         self._send = None
+        # Engine.lazy_zero_plan(): the decoder layers' large matrices are overwritten by the next window's first weight gradients, so this step does
+        # not zero them (set by the owner of the engine; None = zero the whole gradient arena as DeepSpeed's engine.step / optimizer.zero_grad do)
+        self.lazy_zero = None
+
+    def _zero_spans(self, n):
+        """[(a, b, zero_flag)] covering [0, n) for the fused AdamW launches + the periodic clean-up of the small per-layer tensors."""
+        lz = self.lazy_zero
+        if not lz:
+            return [(0, n, True)], None
+        a, b = lz["base"], lz["base"] + lz["stride"] * lz["count"]
+        spans = [(x, y, z) for x, y, z in ((0, a, True), (a, b, False), (b, n, True)) if y > x]
+        small, pos = [], 0
+        for ka, kb in lz["keep"]:
+            if ka > pos:
+                small.append((pos, ka))
+            pos = max(pos, kb)
+        if pos < lz["stride"]:
+            small.append((pos, lz["stride"]))
+        return spans, small
 
     def step(self, lr=None):
         """Averages grads across ranks, clips by global norm, applies AdamW, refreshes the bf16 working weights, zeroes grads.
@@ -45,9 +64,13 @@ class AdamWFlat:
         self.ops.sumsq_accum(a.grad if g16 is None else g16, self._sumsq)
         self.step_count += 1
         a.version = getattr(a, "version", 0) + 1
-        kw = {} if g16 is None else {"g16": g16}
-        self.ops.adamw_step(a.master, a.m, a.v, a.grad, a.w16, self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
-                            self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=True, **kw)
+        spans, small = self._zero_spans(a.numel)
+        for x, y, z in spans:
+            kw = {} if g16 is None else {"g16": g16[x:y]}
+            self.ops.adamw_step(a.master[x:y], a.m[x:y], a.v[x:y], a.grad[x:y], a.w16[x:y], self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
+                                self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=z, **kw)
+        if small:
+            self.ops.zero_ranges_periodic(a.grad, self.lazy_zero["base"], self.lazy_zero["stride"], self.lazy_zero["count"], small)
         return self._sumsq.sqrt() * mult
 
     def _step_sharded(self, lr=None):
@@ -75,7 +98,12 @@ class AdamWFlat:
                            self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm,
                            grad_mult=mult, zero_grad=False)
             works.append(dist.all_gather_into_tensor(a.w16[sa:sb], self._send[la:la + n], async_op=True))
-        a.grad.zero_()                  # the full fp32 accumulator (the fused kernel only sees the reduced shard)
+        spans, small = self._zero_spans(a.numel)      # the full fp32 accumulator (the fused kernel only sees the reduced shard)
+        for x, y, z in spans:
+            if z:
+                a.grad[x:y].zero_()
+        if small:
+            ops.zero_ranges_periodic(a.grad, self.lazy_zero["base"], self.lazy_zero["stride"], self.lazy_zero["count"], small)
         for w in works:
             w.wait()
         return self._sumsq.sqrt() * mult

@@ -88,6 +88,8 @@ class GRPOConfig:
     disable_log_print: bool = False         # keep log() from printing on rank 0 (bench.py prints exactly one JSON line)
     log_rollout_drift: Optional[bool] = None   # metric rollout_logp_drift = mean |logp under the SAMPLING policy's logits - policy logp| over the
                                             # completion tokens; None = on whenever the rollout reads quantised weights (or an importance cap is set)
+    lazy_grad_zero: bool = True      # the optimizer leaves the decoder layers' large gradient matrices un-zeroed (the next window's first weight gradients
+    #                                  overwrite them: Engine.lazy_zero_plan); False = zero the whole gradient arena every step
     rollout_importance_cap: Optional[float] = None   # c: advantage term weighted by min(exp(policy logp - sampling logp), c) per token (truncated
                                             # importance sampling for a quantised sampling policy); None = off, the reference algebra unchanged
     dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
@@ -347,6 +349,8 @@ class TimeR1_Trainer:
                                    weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, dp=self.dp,
                                    grad_wire_dtype=torch.bfloat16 if getattr(args, "grad_wire_dtype", "bf16") == "bf16" else torch.float32,
                                    shard_optimizer=self._wants_shard(args, self.dp))
+        # the decoder layers' large gradient matrices are overwritten by the first micro-step of every window: the optimizer does not zero them
+        self.optimizer.lazy_zero = self.engine.lazy_zero_plan() if getattr(args, "lazy_grad_zero", True) else None
         self._metrics_store = defaultdict(list)
         self._pending = []                   # micro-steps whose device-side metric values have not been fetched yet (_flush_metrics)
         self._clock = _PhaseClock(ops)
