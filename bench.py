@@ -87,7 +87,9 @@ class Workload:
                            temperature=1.0, top_k=50, seed=1234, rope_index_mode="hf4", gradient_accumulation_steps=args.ga, learning_rate=1e-6,
                            lr_scheduler_type="constant", logging_steps=1, save_strategy="no", disable_log_print=True, shard_optimizer=self.shard,
                            rollout_batching=not args.no_rollout_batching,
-                           rollout_weight_dtype="fp8" if args.rollout_fp8_w8a16 else ("fp8-mfma" if args.rollout_fp8 else "bf16"))
+                           rollout_weight_dtype="fp8" if args.rollout_fp8_w8a16 else ("fp8-mfma" if args.rollout_fp8 else "bf16"),
+                           rollout_fp8_keep_bf16=tuple(x for x in args.rollout_fp8_keep_bf16.split(",") if x),
+                           rollout_importance_cap=args.rollout_importance_cap)
         self.trainer = TimeR1_Trainer(self.params, self.reward_funcs, [], args=targs, train_dataset=self.dataset,
                                       processing_class=SyntheticProcessor(self.cfg), ops=ops)
         tr = self.trainer
@@ -433,6 +435,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only), fp8 MFMA (W8A8)")
     ap.add_argument("--rollout-fp8-w8a16", action="store_true", help="fp8 weight copies converted to bf16 in registers (bf16 MFMA) instead of the fp8 MFMA")
+    ap.add_argument("--rollout-fp8-keep-bf16", default="", help="comma list of matrices of the fp8 sampling policy that stay bf16: qkv,o,gu,down,lm_head (config-5 drift study)")
+    ap.add_argument("--rollout-importance-cap", type=float, default=None, help="truncated importance weight min(exp(policy logp - sampling logp), c) on the advantage term")
     ap.add_argument("--engine-path", action="store_true", help="time the bare engine loop (GRPOCore + AdamWFlat, no TimeR1_Trainer) instead of the trainer class")
     ap.add_argument("--no-engine-leg", action="store_true", help="skip the short bare-engine-loop cross-check that follows the timed region")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
@@ -562,7 +566,8 @@ def main(argv=None):
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step%s"
                                    % (cfg.name, args.frames, str(wl.grid), wl.P or 0, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
                                       wl.src_hw[0], wl.src_hw[1],
-                                      "; fp8 (e4m3) weights for the SAMPLING policy only - prefill, log-probs, KL and the update read bf16" if (args.rollout_fp8 or args.rollout_fp8_w8a16) else ""),
+                                      ("; fp8 (e4m3) weights for the SAMPLING policy only - prefill, log-probs, KL and the update read bf16; advantage term weighted by the "
+                                       "truncated importance ratio min(p_update / p_sampling, %g)" % (tr._is_cap or 0.0)) if (args.rollout_fp8 or args.rollout_fp8_w8a16) else ""),
                        "frames": "pinned host memory, copied to HBM inside the timed step" if args.host_frames else "resident in HBM before the timed region",
                        "completion_lengths": "ragged: EOS injected at uniform[C/2, C) per row, seed 1" if args.ragged_eos else "all C tokens (EOS suppressed)",
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
@@ -582,8 +587,22 @@ def main(argv=None):
         wl.eng.overlap_wgrad = False        # ... and the weight-gradient GEMMs stay on the main stream: a launch timed while another GEMM
         if rank == 0 and wl.core.roll.native_decode:
             ops.decode_profile_begin()      # the C driver brackets its own GEMM launches (back to back, as in the timed windows)
+        # the same window also records, per drawn token, its log-prob under the logits it was SAMPLED from (one more pass over the step's logits -
+        # outside the timed region): |that - the update policy's log-prob| is the drift of the sampling policy.  For the bf16 policy it is the
+        # yardstick (decode kernels vs training kernels on the same weights) the fp8 policies of config 5 are read against.
+        track0 = wl.core.roll.track_logp
+        wl.core.roll.track_logp = True
+        n_hist0 = len(tr.state.log_history)
         run_window()                        # shares the GPU would be charged the other kernel's time
         torch.cuda.synchronize()
+        wl.core.roll.track_logp = track0
+        drift_vals = [h["rollout_logp_drift"] for h in tr.state.log_history[n_hist0:] if "rollout_logp_drift" in h]      # log() runs every optimizer step
+        if rank == 0 and drift_vals and not args.engine_path:
+            out["rollout_logp_drift"] = {"mean_abs_nat": sum(drift_vals) / len(drift_vals), "optimizer_steps": len(drift_vals),
+                                         "what": "mean over completion tokens of |log p_sampling(token) - log p_update(token)| in the instrumented window: "
+                                                 "sampling policy = the decode kernels' logits (%s), update policy = the bf16 training forward on the same weights"
+                                                 % ("bf16 weights" if not (args.rollout_fp8 or args.rollout_fp8_w8a16) else
+                                                    ("fp8 W8A8" if args.rollout_fp8 else "fp8 W8A16") + (", bf16 kept for " + args.rollout_fp8_keep_bf16 if args.rollout_fp8_keep_bf16 else ""))}
         dec_prof = ops.decode_profile_end() if rank == 0 and wl.core.roll.native_decode else None
         wl.core.roll.native_decode = True
         wl.eng.overlap_wgrad = True
@@ -625,7 +644,7 @@ def main(argv=None):
         # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, gfx950 x2 read
         # correction; same workload shapes) - PMC counters cannot be collected inside this un-profiled run
         try:
-            pmc_name = [f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            pmc_name = [f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             # guard: the counters are only quoted while the kernels they were collected on are the kernels that just ran - the PMC pass records
             # a fingerprint of the GEMM sources (tools/pmc_to_json.py); any edit since then detaches `traffic` until the pass is re-run
@@ -633,9 +652,14 @@ def main(argv=None):
             csrc = os.path.join(ROOT, "time-r1_amd", "csrc")
             now = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in ("gemm.hip", "decode.hip")}
             fresh = pmc.get("_source_sha16") == now
+            fp8_run = bool(args.rollout_fp8 or args.rollout_fp8_w8a16)
+            if fp8_run:       # the committed PMC pass measured the bf16 decode kernels: never quote it against the fp8 family's algorithmic bytes
+                fresh = False
             for r_ in (hbm, mfma):
                 r_["traffic_source"] = "profiles/" + pmc_name
-                r_["traffic_guard"] = "kernel sources unchanged since the PMC pass" if fresh else "STALE: csrc/gemm.hip or decode.hip changed since the PMC pass (or the file predates the guard) - traffic withheld"
+                r_["traffic_guard"] = ("kernel sources unchanged since the PMC pass" if fresh else
+                                       "withheld: the PMC pass measured the bf16 decode kernels, this run streams fp8 weights (csrc/gemm_w8.hip)" if fp8_run else
+                                       "STALE: csrc/gemm.hip or decode.hip changed since the PMC pass (or the file predates the guard) - traffic withheld")
             if fresh and args.model == "qwen2-vl-7b" and args.G == 8 and args.ga == 2:
                 def fam(*names):      # launch-weighted mean over the kernel families that make up one roofline entry
                     n = sum(pmc[k]["launches"] for k in names if k in pmc)

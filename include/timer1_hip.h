@@ -35,6 +35,10 @@ int tr1_probe_hbm_read(const void* buf, int64_t bytes, void* sink_u32, void* str
  * K % 64 == 0 (pad), N % 8 == 0.  out_f32: C is fp32; accumulate (fp32 only): C += result (weight-gradient accumulation).
  * M <= 16 dispatches the HBM-streaming skinny kernel used by rollout decode. */
 int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream);
+/* The same product for thin outputs over a long K (M * N < ~128 tiles of 256 x 256, e.g. the continuation forward's down projection 1600 x 3584 x 18944):
+ * both halves of the K reduction run as blocks of ONE launch into fp32 planes of ws_f32 (2 * M * N floats) and a second launch adds them in a fixed
+ * order (+bias, +residual) - deterministic 2-way split-K.  K % 128 == 0; bf16 output. */
+int tr1_gemm_nt_splitk2_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream);
 /* C[M,N] = A[M,K] * B[K,N], B K-major ("NN").  The dgrad of a Linear (dX = dY * W; reference: autograd of F.linear under accelerator.backward,
  * TF trainer.py:1952-1961) reads the weight as stored instead of a transposed copy.  Needs M >= 512, N >= 256, K % 64 == 0; bf16 in / out. */
 int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, void* stream);
@@ -42,7 +46,10 @@ int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N
  * kernel it absorbs (the GEMM output is rounded to bf16 exactly where the unfused path stores it).
  * tr1_gemm_glu_bf16: a[M, I] = silu(x Wg^T) * (x Wu^T), Wgu = [2I, K] gate rows then up rows (TF:459-466 Qwen2MLP, reached from
  *   src/time_r1/rl/timer1_trainer.py:452-457); gu_out (NULL = not needed) receives the projection [M, 2I] the backward reads. */
-int tr1_gemm_glu_bf16(const void* x, const void* Wgu, void* a_out, void* gu_out, int64_t M, int64_t I, int64_t K, int64_t ldx, int64_t ldw, int64_t lda, int64_t ldgu, void* stream);
+int tr1_gemm_glu_bf16(const void* x, const void* Wgu, const void* bias, void* a_out, void* gu_out, int64_t M, int64_t I, int64_t K, int64_t ldx, int64_t ldw, int64_t lda, int64_t ldgu, void* stream);
+/* y = quick_gelu(x W^T + bias): the Qwen2-VL vision MLP's fc1 + activation in one launch (TF:300-301 VisionMlp); bias (optional) of tr1_gemm_glu_bf16 is the
+ * [2I] gate|up bias of the Qwen2.5-VL vision MLP (modeling_qwen2_5_vl.py:85-96). */
+int tr1_gemm_bias_quickgelu_bf16(const void* x, const void* W, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldy, void* stream);
 /* tr1_gemm_qkv_rope_bf16: fused q|k|v projection + bias + multimodal rotary embedding for head dim 128 (TF:501-504 q/k/v_proj, TF:212-222
  *   apply_multimodal_rotary_pos_emb): q_out / k_out rotated with cos / sin fp32 [M, 64], v_out plain; k_out may point into the KV cache rows. */
 int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ldq, void* k_out, int64_t ldk, void* v_out, int64_t ldv, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, void* stream);
@@ -178,14 +185,16 @@ int tr1_gemm_skinny_fixup_w8a8(const void* x, const void* W_fp8, const void* wsc
  * o_proj + residual, norm + gate/up + SwiGLU, down_proj + residual} -> final norm + lm_head -> logits[R, vocab] (bf16).
  * ref: per-token body of model.generate (timer1_trainer.py:568-573; Qwen2VLDecoderLayer TF:559-624, norm TF:839, lm_head TF:1323).
  * layer_ptrs: HOST array of 9 * n_layers DEVICE pointers {ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache [B*s_cap, kv_dim],
- * V^T cache [kv_dim, B*s_cap]} per layer; dims: HOST int64[11] {n_layers, hidden, n_heads, n_kv, head_dim, intermediate, vocab, rows,
- * n_batch, s_cap, nsplit}; ids int32[R]; cosb/sinb fp32 [R, head_dim/2]; slots int32[R] (absolute cache slot of each row's new token);
+ * V^T cache [kv_dim, B*s_cap]} per layer; dims: HOST int64[12] {n_layers, hidden, n_heads, n_kv, head_dim, intermediate, vocab, rows,
+ * n_batch, s_cap, nsplit, fp8_mask (fp8 steps only, ignored here)}; ids int32[R]; cosb/sinb fp32 [R, head_dim/2]; slots int32[R] (absolute cache slot of each row's new token);
  * pre/lo/hi int32[R] (two-interval mask, cache-local per batch entry); work: device scratch of tr1_decode_step_workspace_bytes(dims),
  * ZERO-FILLED once by the caller before the first step (it holds self re-arming split-K ticket counters). */
 int tr1_decode_step(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 int64_t tr1_decode_step_workspace_bytes(const int64_t* dims);
 /* Same step with fp8 weights (tr1_quantize_fp8_rows): 13 pointers per layer {ln1, qkv.q, qkv.b, o.q, ln2, gu.q, down.q, K cache, V^T cache,
- * qkv.scale, o.scale, gu.scale, down.scale}; lm_head_fp8 / lm_head_scale likewise.  Embedding, norms, biases, KV cache stay bf16. */
+ * qkv.scale, o.scale, gu.scale, down.scale}; lm_head_fp8 / lm_head_scale likewise.  Embedding, norms, biases, KV cache stay bf16.
+ * dims[11] = fp8_mask: bit 0 qkv, 1 o, 2 gate/up, 3 down, 4 lm_head (31 = all).  A CLEAR bit keeps that matrix of the sampling policy in bf16: its slot
+ * (and `lm_head_fp8`) then holds the bf16 weight and the bf16 decode kernel runs - the mixed-precision policies of the config-5 drift study. */
 int tr1_decode_step_w8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
 /* Same step, every projection through tr1_gemm_skinny_w8a8 (fp8 MFMA). */
 int tr1_decode_step_w8a8(const void* layer_ptrs, const int64_t* dims, const void* embed, const void* final_norm, const void* lm_head_fp8, const void* lm_head_scale, const void* ids, const void* cosb, const void* sinb, const void* slots, const void* pre, const void* lo, const void* hi, void* work, int64_t work_bytes, void* logits, float eps, float scale, void* stream);
@@ -229,6 +238,20 @@ int tr1_adamw_step_g16(void* p_f32, void* m_f32, void* v_f32, void* g_f32, const
  * next accumulation window).  ref: optimizer.zero_grad() in HF Trainer.training_step / DeepSpeed engine.step (scripts/zero3.json). */
 int tr1_zero_ranges_periodic(void* g_f32, int64_t base, int64_t stride, int64_t count, const int64_t* rel_ranges, int64_t n_ranges, void* stream);
 int tr1_sumsq_accum_bf16(const void* g_bf16, int64_t n, void* out_scalar, void* stream);
+
+/* ---- RCCL collectives over xGMI (rccl_{init, allreduce, reduce_scatter, allgather}) ------------------------------------------------ */
+/* The data-parallel exchange for a host that binds this library directly (time-r1_amd/dist.py reaches the same librccl through torch.distributed "nccl").
+ * ref: `torchrun --nproc_per_node=8` + DeepSpeed ZeRO buckets (scripts/finetune/run_activitynet.sh:11, scripts/zero3.json:22-33) and
+ * accelerator.gather_for_metrics (src/time_r1/rl/timer1_trainer.py:741-777).  One process per GPU, device selected before tr1_rccl_init; every collective
+ * is asynchronous on `stream` and a SUM.  dtype: 0 = bf16 (gradient wire format), 1 = fp32, 2 = int32.  librccl.so is dlopen'ed on first use
+ * (TR1_RCCL_LIB overrides the name).  Errors: 1000 = argument / load failure, 2000 + ncclResult_t otherwise. */
+int64_t tr1_rccl_version(void);
+int tr1_rccl_unique_id(void* id_out_128);                                   /* HOST pointer, 128 bytes; rank 0 creates it, the launcher distributes it */
+int tr1_rccl_init(const void* id_128, int64_t world, int64_t rank, void* comm_out);     /* comm_out: HOST slot receiving the communicator (one pointer) */
+int tr1_rccl_destroy(void* comm);
+int tr1_rccl_allreduce(void* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
+int tr1_rccl_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype, void* stream);
+int tr1_rccl_allgather(void* comm, const void* send, void* recv, int64_t send_count, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -201,8 +201,11 @@ class RefOps:
         return self.swiglu_fwd(y) if glu else y
 
     # ---- fused-epilogue training GEMMs: by definition the compositions they replace (csrc/gemm.hip EPI 2 / 3 / 4)
-    def gemm_glu(self, x, w_gu, a_out=None, gu_out=None, save_gu=True):
-        gu = self.gemm_nt(x, w_gu, out=gu_out)
+    def gemm_quickgelu(self, x, w, bias=None):
+        return self.quickgelu_fwd(self.gemm_nt(x, w, bias=bias))
+
+    def gemm_glu(self, x, w_gu, a_out=None, gu_out=None, save_gu=True, bias=None):
+        gu = self.gemm_nt(x, w_gu, bias=bias, out=gu_out)
         return self.swiglu_fwd(gu, out=a_out), (gu if save_gu else None)
 
     def gemm_qkv_rope(self, x, w_qkv, bias, cos, sin, n_heads, n_kv, head_dim, q_out=None, k_out=None, v_out=None):

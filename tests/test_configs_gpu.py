@@ -286,7 +286,7 @@ def _rows(fx, n):
 def test_trainer_train_checkpoint_resume_on_hip(hip_ops, tmp_path, gpu_pre):
     """The loop that replaces main.py:589-625 on the HIP path: 2 epochs x 2 optimizer steps (GA = 2, batched rollouts, sampling on the
     GPU), checkpoint every step; a fresh trainer resumed from checkpoint-2 must reach the same weights as the uninterrupted run."""
-    from helpers import load_case
+    from helpers import load_case, grads_cleared
     fx = load_case("grpo_beta")
 
     def make(out):

@@ -179,6 +179,26 @@ def test_gather_scatter_embed(hip_ops, ref_ops):
     close(dt_h, dt_r, 1e-5, rtol=1e-5, what="embed bwd")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 8192), (1600, 3584, 18944), (70, 200, 8320)])
+def test_gemm_nt_two_way_split_k(hip_ops, ref_ops, M, N, K):
+    """Thin outputs over a long K (the continuation forward's down projection) run a deterministic 2-way split-K: both halves in one launch into fp32
+    planes, summed in a fixed order with bias and residual.  Same result as the single-pass kernel up to the fp32 summation order; repeatable bit for bit."""
+    a, b, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    assert hip_ops.SPLITK
+    y = hip_ops.gemm_nt(a.cuda(), b.cuda(), bias=bias.cuda(), residual=res.cuda())
+    y2 = hip_ops.gemm_nt(a.cuda(), b.cuda(), bias=bias.cuda(), residual=res.cuda())
+    assert torch.equal(y, y2), "split-K must be deterministic"
+    hip_ops.SPLITK = False
+    try:
+        y0 = hip_ops.gemm_nt(a.cuda(), b.cuda(), bias=bias.cuda(), residual=res.cuda())
+    finally:
+        del hip_ops.SPLITK
+    r = ref_ops.gemm_nt(a.float(), b.float(), bias=bias.float(), residual=res.float())
+    atol = 0.01 * math.sqrt(K) * 0.05 + 0.03
+    close(y, r, atol, what="split-K vs oracle")
+    close(y, y0.float().cpu(), atol, what="split-K vs single pass")
+
+
 # ------------------------------------------------------------------------------------------- fused-epilogue training GEMMs
 class _unfused:
     """The same HipOps with the fused epilogues switched off (GEMM + separate elementwise kernels: the round-3 path)."""
@@ -212,6 +232,23 @@ def test_gemm_glu_fused_epilogue(hip_ops, ref_ops, M, I, K, save):
         assert gu is None
     ar, gur = ref_ops.gemm_glu(x.float(), w.float())
     close(a, ar, 0.02 * math.sqrt(K) * 0.1 + 0.02, rtol=3e-2, what="glu a")
+
+
+@pytest.mark.parametrize("M,N,K", [(13376 // 8, 5120, 1280), (300, 200, 64), (1000, 264, 128)])
+def test_gemm_quickgelu_and_biased_glu_fused_epilogue(hip_ops, ref_ops, M, N, K):
+    """Vision-tower MLPs: fc1 + bias + QuickGELU (Qwen2-VL) and gate/up + bias + SwiGLU (Qwen2.5-VL) in the GEMM epilogue, bit-identical to the
+    separate kernels."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    y = hip_ops.gemm_quickgelu(x.cuda(), w.cuda(), b.cuda())
+    with _unfused(hip_ops) as o:
+        y0 = o.gemm_quickgelu(x.cuda(), w.cuda(), b.cuda())
+    assert torch.equal(y, y0)
+    close(y, ref_ops.gemm_quickgelu(x.float(), w.float(), b.float()), 0.02 * math.sqrt(K) * 0.1 + 0.02, rtol=3e-2, what="quickgelu")
+    I = N // 16 * 8                      # (the SwiGLU kernels need I % 8 == 0)
+    a, _ = hip_ops.gemm_glu(x.cuda(), w.cuda()[: 2 * I], save_gu=False, bias=b.cuda()[: 2 * I])
+    with _unfused(hip_ops) as o:
+        a0, _ = o.gemm_glu(x.cuda(), w.cuda()[: 2 * I], save_gu=False, bias=b.cuda()[: 2 * I])
+    assert torch.equal(a, a0)
 
 
 @pytest.mark.parametrize("M,nh,nkv,K,row0", [(300, 4, 2, 256, 0), (1000, 28, 4, 512, 0), (333, 12, 2, 192, 77), (5074, 2, 2, 64, 0)])

@@ -205,3 +205,37 @@ def test_rollout_logp_drift_is_logged_on_hip(hip_ops, wdtype):
     assert d < (0.02 if wdtype == "bf16" else 0.2), d
     if wdtype != "bf16":
         assert d > 1e-5, "an fp8 sampling policy cannot reproduce the bf16 log-probs exactly"
+
+
+@pytest.mark.parametrize("wdtype", ["bf16", "fp8-mfma"])
+def test_rollout_logp_drift_bound_at_7b_width(hip_ops, wdtype):
+    """the drift bound of the sampling policy stated in DESIGN section 5, asserted at the width config 5 names (Qwen2-VL-7B: hidden 3584,
+    28 / 4 heads of 128, intermediate 18944, V = 152064) and 8 decoder layers, random-init weights (the worst case: near-uniform next-token distributions).
+    bf16 sampling policy = decode kernels vs training kernels on the SAME weights: the yardstick, < 0.05 nat (0.028 at 28 layers on the bench).
+    fp8 (W8A8) sampling policy: e4m3 weights alone cost ~0.2 nat at 28 layers (3-bit mantissa, bench `--rollout-fp8-w8a16`), block-scaled e4m3
+    activations bring it to 0.30: bound 0.40 nat, and the update corrects for it with truncated importance weights (cap 2) by default."""
+    from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig, FP8_IMPORTANCE_CAP
+    from time_r1_amd import rewards as R
+    from time_r1_amd.config import qwen2_vl_7b
+    from time_r1_amd.params import ModelParams
+    from time_r1_amd.synthetic import SyntheticProcessor
+    cfg = qwen2_vl_7b()
+    cfg.text.n_layers = 8
+    cfg.vision.depth = 2
+    params = ModelParams(cfg, hip_ops, init="none")
+    params.init_random_device(seed=0)
+    args = GRPOConfig(output_dir="/tmp/tr1_gpu_drift7b", num_generations=8, max_completion_length=24, beta=0.0, use_grpo=True, temperature=1.0, top_k=50,
+                      save_strategy="no", rollout_weight_dtype=wdtype, log_rollout_drift=True, disable_log_print=True, rope_index_mode="hf4")
+    tr = TimeR1_Trainer(params, [R.format_reward], [], args=args, processing_class=SyntheticProcessor(cfg), ops=hip_ops)
+    assert tr._is_cap == (None if wdtype == "bf16" else FP8_IMPORTANCE_CAP)
+    frames = torch.randint(0, 256, (8, 3, 112, 168), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    row = {"problem": "person sits down", "video_path": "x.mp4", "video_frames": frames, "solution": (2.0, 12.0), "durations": 30.0}
+    loss = tr.compute_loss(tr.model, [row])
+    d = tr._metrics["rollout_logp_drift"][0]
+    assert np.isfinite(float(loss)) and np.isfinite(d)
+    if wdtype == "bf16":
+        assert d < 0.05, d
+    else:
+        assert 1e-3 < d < 0.40, d
+    del tr, params
+    torch.cuda.empty_cache()

@@ -38,7 +38,10 @@ struct Carve {
         void* r = p; p += bytes; left -= bytes; return r;
     }
 };
-enum { D_LAYERS, D_HIDDEN, D_HEADS, D_KV, D_HEAD_DIM, D_INTER, D_VOCAB, D_ROWS, D_BATCH, D_SCAP, D_NSPLIT, D_N };
+// D_QMASK (fp8 steps only): which matrices of the SAMPLING policy are fp8 - bit 0 qkv, 1 o, 2 gate/up, 3 down, 4 lm_head; a clear bit means that slot of the
+// layer table (and the lm_head argument) holds the bf16 weight and the bf16 kernel runs (mixed-precision sampling policies: config 5's drift study)
+enum { D_LAYERS, D_HIDDEN, D_HEADS, D_KV, D_HEAD_DIM, D_INTER, D_VOCAB, D_ROWS, D_BATCH, D_SCAP, D_NSPLIT, D_QMASK, D_N };
+enum { QM_QKV = 1, QM_O = 2, QM_GU = 4, QM_DOWN = 8, QM_LM = 16, QM_ALL = 31 };
 }  // namespace
 
 static int64_t decode_ws_bytes(const int64_t* d) {
@@ -63,7 +66,7 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     const int64_t V = dims[D_VOCAB], R = dims[D_ROWS], B = dims[D_BATCH], scap = dims[D_SCAP], nsplit = dims[D_NSPLIT];
     TR1_CHECK_ARG(R >= 1 && R <= 64 && B >= 1 && R % B == 0, "decode_step: 1 <= rows <= 64, rows % n_batch == 0");
     TR1_CHECK_ARG(layer_ptrs && dims && work && logits, "decode_step: null argument");
-    TR1_CHECK_ARG(!w8 || lm_head_scale, "decode_step_w8: lm_head scale missing");
+    TR1_CHECK_ARG(!w8 || !(dims[D_QMASK] & QM_LM) || lm_head_scale, "decode_step_w8: lm_head scale missing");
     const int64_t qd = nh * hd, kvd = nkv * hd, qkvd = qd + 2 * kvd, T = R / B;
     const int64_t att_floats = B * tr1_attn_fwd_workspace_floats(T, nh, nkv, hd, nsplit);
     Carve c{(char*)work, (size_t)work_bytes};
@@ -85,10 +88,11 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     if (qkv_split < 0) { const char* e = getenv("TR1_QKV_SPLIT"); qkv_split = e ? atoi(e) : 0; }
     const int64_t qsp_floats = tr1_norm_gemm_qkv_split_workspace_floats(nh, nkv, hd);
     void* qsp = c.take(qsp_floats * 4);
-    const bool use_qsp = qkv_split && !w8 && R <= 16 && hd % 32 == 0 && hid >= 512;
+    const int qm = w8 ? (int)(dims[D_QMASK] & QM_ALL) : 0;                     // fp8 matrices of this step
+    const bool use_qsp = qkv_split && !(qm & QM_QKV) && R <= 16 && hd % 32 == 0 && hid >= 512;
     const bool planned = use_plan && nsplit > 1 && L > 1;
-    const bool down_fixup = !w8 && R >= 16 && inter >= 8192;
-    const bool down_fixup8 = w8 == 2 && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
+    const bool down_fixup = !(qm & QM_DOWN) && R >= 16 && inter >= 8192;
+    const bool down_fixup8 = w8 == 2 && (qm & QM_DOWN) && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
     TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");
     const void* const* lp = (const void* const*)layer_ptrs;
     const int stride = w8 ? 13 : 9;
@@ -99,7 +103,7 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     void* h = hA; void* h2 = hB;
     for (int64_t i = 0; i < L; ++i) {
         const void* const* w = lp + i * stride;
-        if (w8) {
+        if (qm & QM_QKV) {
             CK(gemm8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
         } else if (use_qsp) {
@@ -118,23 +122,23 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
                                 scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
         {
             ProfScope ps(1, stream);
-            if (w8) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
+            if (qm & QM_O) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
             else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
         }
         {
             ProfScope ps(2, stream);
-            if (w8) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
+            if (qm & QM_GU) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
             else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
         }
         ProfScope ps3(3, stream);
         if (w8 == 2 && down_fixup8) CK(tr1_gemm_skinny_fixup_w8a8(a, w[6], w[12], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
-        else if (w8) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
+        else if (qm & QM_DOWN) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
         else if (down_fixup) CK(tr1_gemm_skinny_fixup(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
     }
     {
         ProfScope ps(4, stream);
-        if (w8) CK(gemm8(h, final_norm, lm_head, lm_head_scale, nullptr, nullptr, logits, R, V, hid, hid, hid, V, 0, eps, 0, stream));
+        if (qm & QM_LM) CK(gemm8(h, final_norm, lm_head, lm_head_scale, nullptr, nullptr, logits, R, V, hid, hid, hid, V, 0, eps, 0, stream));
         else CK(tr1_norm_gemm_skinny(h, final_norm, lm_head, nullptr, logits, R, V, hid, hid, hid, V, eps, 0, stream));
     }
 #undef CK

@@ -269,7 +269,7 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
             const int c8 = lane & 7;
             const int64_t n = ncol0 + c8 * 8;
             u32x4_t bv = {0, 0, 0, 0};
-            if (EPI == 0 && bias && n + 8 <= N) bv = *reinterpret_cast<const u32x4_t*>(bias + n);      // (EPI 1: `bias` carries the int32 targets)
+            if (EPI != 1 && bias && n + 8 <= N) bv = *reinterpret_cast<const u32x4_t*>(bias + n);      // (EPI 1: `bias` carries the int32 targets)
 #pragma unroll
             for (int r8 = 0; r8 < CH * 2; ++r8) {
                 if (r8 < cnt * 2) {
@@ -311,6 +311,10 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                             const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
+                        }
+                        if (EPI == 5) {      // QuickGELU (Qwen2-VL vision MLP, TF:300-301) on the bf16-rounded projection, as act_kernel<1> after the GEMM
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float x = bf2f(f2bf(v[e])); v[e] = x / (1.f + __expf(-1.702f * x)); }
                         }
                         u32x4_t o;
 #pragma unroll
@@ -523,6 +527,7 @@ TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ 
         const int64_t I = ep.i0;
         col_a = (n0 >> 1) + wn * 32 + c4 * 8;
         col_ok = col_a + 8 <= I;
+        if (bias && col_ok) { ba = *reinterpret_cast<const u32x4_t*>(bias + col_a); bb = *reinterpret_cast<const u32x4_t*>(bias + I + col_a); }
         dst_a = reinterpret_cast<bf16_t*>(Cv) + col_a; dst_b = nullptr; ld_o = ldc;
         if (ep.p0) { dst_ga = reinterpret_cast<bf16_t*>(ep.p0) + col_a; dst_gb = dst_ga + I; ld_g = ep.ld0; }
     } else {
@@ -564,6 +569,10 @@ TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ 
                     u32x4_t oa, ob;
                     if (EPI == 2) {
                         u32x4_t pg, pu;
+                        if (bias) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { va[2 * e] += bflo(ba[e]); va[2 * e + 1] += bfhi(ba[e]); vb[2 * e] += bflo(bb[e]); vb[2 * e + 1] += bfhi(bb[e]); }
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { pg[e] = pack2bf(va[2 * e], va[2 * e + 1]); pu[e] = pack2bf(vb[2 * e], vb[2 * e + 1]); }
                         if (dst_ga) {
@@ -680,7 +689,15 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
     const int nwg = tiles_m * tiles_n;
     int wgid;
     {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        int b = blockIdx.x;
+        if (EPI == 6) {                                  // 2-way split-K: the grid holds every tile twice; copy kz reduces k in [kz*K/2, (kz+1)*K/2)
+            const int kz = b >= nwg ? 1 : 0;             // into its own fp32 plane of C (summed by splitk_reduce_kernel in a fixed order)
+            b -= kz * nwg;
+            K >>= 1;
+            A += (int64_t)kz * K; B += (int64_t)kz * K;
+            Cv = reinterpret_cast<float*>(Cv) + (int64_t)kz * ep.ld0;
+        }
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int GROUP_M = 4;
@@ -806,6 +823,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
     else if (EPI == 4)       // V tile: bias only, into its own buffer
         store_acc256_lds<false, false, RT, 0>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), ep.p1, bias + ep.i0 + ep.i1, nullptr, M, N - ep.i0 - ep.i1,
                                               ep.ld1, 0, m0 + wm * (RT * 16), n0 - ep.i0 - ep.i1 + wn * 64, lane);
+    else if (EPI == 6)
+        store_acc256_lds<true, false, RT, 0>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, nullptr, nullptr, M, N, ldc, 0, m0 + wm * (RT * 16), n0 + wn * 64, lane);
     else if (EPI == 3)
         store_acc256_glubwd<RT>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, M, N, ldc, m0 + wm * (RT * 16), n0 + wn * 64, lane, ep);
     else
@@ -2068,8 +2087,8 @@ static int epi_pick_rt(int64_t M, int64_t Ntiles) {
 
 // a[M, I] = silu(x Wg^T) * (x Wu^T) with Wgu = [2I, K] (gate rows, then up rows); gu_out (optional) receives the projection itself [M, 2I] for the backward.
 // Bit-identical to tr1_gemm_nt_bf16 + tr1_swiglu_fwd.
-extern "C" int tr1_gemm_glu_bf16(const void* x, const void* Wgu, void* a_out, void* gu_out, int64_t M, int64_t I, int64_t K, int64_t ldx, int64_t ldw,
-                                 int64_t lda, int64_t ldgu, void* stream) {
+extern "C" int tr1_gemm_glu_bf16(const void* x, const void* Wgu, const void* bias, void* a_out, void* gu_out, int64_t M, int64_t I, int64_t K, int64_t ldx,
+                                 int64_t ldw, int64_t lda, int64_t ldgu, void* stream) {
     TR1_CHECK_ARG(K % BK == 0 && I % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && lda % 8 == 0 && (!gu_out || ldgu % 8 == 0), "gemm_glu: K%64, I%8, ld%8 required");
     TR1_CHECK_ARG(I < (1 << 30), "gemm_glu: I too large");
     if (M == 0 || I == 0) return 0;
@@ -2082,9 +2101,28 @@ extern "C" int tr1_gemm_glu_bf16(const void* x, const void* Wgu, void* a_out, vo
 #define KA_GLU(R) false, false, R, false, 2
     EPI_SETATTR(KA_GLU);
     GemmEpi ep{}; ep.p0 = gu_out; ep.ld0 = ldgu; ep.i0 = (int)I;
-    EPI_LAUNCH(KA_GLU, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)Wgu, a_out, (const bf16_t*)nullptr,
+    EPI_LAUNCH(KA_GLU, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)Wgu, a_out, (const bf16_t*)bias,
                (const bf16_t*)nullptr, M, 2 * I, K, ldx, ldw, lda, (int64_t)0, (int)t2m, (int)t2n, ep);
 #undef KA_GLU
+    TR1_LAUNCH_CHECK();
+}
+
+// y[M, N] = quick_gelu(x W^T + bias) (Qwen2-VL vision MLP fc1 + activation, TF:300-301).  Bit-identical to tr1_gemm_nt_bf16 (bias) + tr1_quickgelu_fwd.
+extern "C" int tr1_gemm_bias_quickgelu_bf16(const void* x, const void* W, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                                            int64_t ldy, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "gemm_bias_quickgelu: K%64, N%8, ld%8 required");
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t2n = (N + BN2 - 1) / BN2;
+    const int rt = epi_pick_rt(M, t2n);
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+#define KA_QG(R) false, false, R, false, 5
+    EPI_SETATTR(KA_QG);
+    EPI_LAUNCH(KA_QG, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)W, y, (const bf16_t*)bias,
+               (const bf16_t*)nullptr, M, N, K, ldx, ldw, ldy, (int64_t)0, (int)t2m, (int)t2n, GemmEpi{});
+#undef KA_QG
     TR1_LAUNCH_CHECK();
 }
 
@@ -2130,6 +2168,55 @@ extern "C" int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const voi
     EPI_LAUNCH(KA_GB, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)dh, (const bf16_t*)Wd, dgu, (const bf16_t*)nullptr,
                (const bf16_t*)nullptr, M, I, H, lda, ldb, lddgu, (int64_t)0, (int)t2m, (int)t2n, ep);
 #undef KA_GB
+    TR1_LAUNCH_CHECK();
+}
+
+// C[M, N] (bf16) = A B^T (+bias)(+residual) with a deterministic 2-way split over K: for thin outputs over a long K (the continuation forward's down
+// projection: 1600 x 3584 x 18944 = 98 tiles of 256 x 256 on 256 CUs, 838 TFLOP/s) both halves of the reduction run as separate blocks of ONE launch
+// into fp32 planes, and a second launch adds the two planes in a fixed order.  ws_f32: 2 * M * N floats.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ p0, const float* __restrict__ p1, const bf16_t* __restrict__ bias,
+                                                            const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ C, int64_t ldc, int64_t M, int64_t N) {
+    const int64_t nch = N >> 3, total = M * nch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / nch, n = (i - m * nch) * 8;
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(p0 + m * N + n), a1 = *reinterpret_cast<const f32x4_t*>(p0 + m * N + n + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p1 + m * N + n), b1 = *reinterpret_cast<const f32x4_t*>(p1 + m * N + n + 4);
+        float v[8] = {a0[0] + b0[0], a0[1] + b0[1], a0[2] + b0[2], a0[3] + b0[3], a1[0] + b1[0], a1[1] + b1[1], a1[2] + b1[2], a1[3] + b1[3]};
+        if (bias) {
+            const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(bv[e]); v[2 * e + 1] += bfhi(bv[e]); }
+        }
+        if (residual) {
+            const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(residual + m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bflo(rv[e]); v[2 * e + 1] += bfhi(rv[e]); }
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4_t*>(C + m * ldc + n) = o;
+    }
+}
+extern "C" int tr1_gemm_nt_splitk2_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream) {
+    TR1_CHECK_ARG(K % (2 * BK) == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_nt_splitk2: K%128, N%8, ld%8 required");
+    TR1_CHECK_ARG(ws_f32 && ws_floats >= 2 * M * N, "gemm_nt_splitk2: workspace of 2*M*N floats required");
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t2n = (N + BN2 - 1) / BN2;
+    const int rt = epi_pick_rt(M, 2 * t2n);
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+#define KA_SK(R) true, false, R, false, 6
+    EPI_SETATTR(KA_SK);
+    GemmEpi ep{}; ep.ld0 = M * N;
+    EPI_LAUNCH(KA_SK, rt, dim3((unsigned)(2 * t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, ws_f32, (const bf16_t*)nullptr,
+               (const bf16_t*)nullptr, M, N, K, lda, ldb, N, (int64_t)0, (int)t2m, (int)t2n, ep);
+#undef KA_SK
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tr1_grid_1d(M * N / 8, 256, 2048)), dim3(256), 0, s, (const float*)ws_f32, (const float*)ws_f32 + M * N,
+                       (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N);
     TR1_LAUNCH_CHECK();
 }
 

@@ -148,7 +148,7 @@ class Engine:
             o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
             x = ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
             y, _, _ = ops.layernorm_fwd(x, fz.w(p + "n2.w"), fz.w(p + "n2.b"), v.ln_eps, need_stats=False)
-            z = ops.quickgelu_fwd(ops.gemm_nt(y, fz.w(p + "fc1.w"), bias=fz.w(p + "fc1.b")))
+            z = ops.gemm_quickgelu(y, fz.w(p + "fc1.w"), fz.w(p + "fc1.b"))          # fc1 + bias + QuickGELU in the GEMM epilogue
             x = ops.gemm_nt(z, fz.w(p + "fc2.w"), bias=fz.w(p + "fc2.b"), residual=x)
         return x, None
 
@@ -182,7 +182,7 @@ class Engine:
             o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
             x = ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
             y, _, _ = ops.rmsnorm_fwd(x, fz.w(p + "n2.w"), v.ln_eps, need_rstd=False)
-            a = ops.swiglu_fwd(ops.gemm_nt(y, fz.w(p + "gu.w"), bias=fz.w(p + "gu.b")))
+            a, _ = ops.gemm_glu(y, fz.w(p + "gu.w"), save_gu=False, bias=fz.w(p + "gu.b"))      # gate/up + bias + SwiGLU in the GEMM epilogue
             x = ops.gemm_nt(a, fz.w(p + "down.w"), bias=fz.w(p + "down.b"), residual=x)
         return x, perm
 

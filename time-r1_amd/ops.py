@@ -148,24 +148,44 @@ class HipOps:
             assert not accumulate
             out = self.empty(M, N, dtype=F32 if out_f32 else BF16)
         assert out.shape == (M, N) and out.dtype == (F32 if out_f32 else BF16)
+        # thin output over a long reduction (the continuation forward's down projection: 1600 x 3584 x 18944 = 98 tiles of 256 x 256 for 256 CUs):
+        # deterministic 2-way split-K, both halves in one launch
+        if (self.SPLITK and not out_f32 and M > 64 and K >= 8192 and K % 128 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) <= 128
+                and a.stride(1) == 1 and b.stride(1) == 1):
+            ws = self._workspace("gemm_splitk2", 2 * M * N, F32)
+            self.L.call("tr1_gemm_nt_splitk2_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, _ld(a), _ld(b), _ld(out),
+                        _ld(residual) if residual is not None else 0, _p(ws), ws.numel(), self._s())
+            return out
         self.L.call("tr1_gemm_nt_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, _ld(a), _ld(b), _ld(out),
                     _ld(residual) if residual is not None else 0, int(out_f32), int(accumulate), self._s())
         return out
 
     # ---- fused-epilogue training GEMMs (bit-identical to the compositions in their `else` branches) ---------------------
+    SPLITK = os.environ.get("TR1_GEMM_SPLITK", "1") != "0"        # A/B switch for the 2-way split-K form of thin long-K GEMMs
     FUSE_EPI = os.environ.get("TR1_FUSE_EPI", "1") != "0"          # A/B switch: 0 = GEMM + separate elementwise kernels (the round-3 path)
 
-    def gemm_glu(self, x, w_gu, a_out=None, gu_out=None, save_gu=True):
-        """(a, gu): a[M, I] = silu(x Wg^T) * (x Wu^T); gu = the projection [M, 2I] (None unless save_gu)."""
-        self._chk(x, w_gu, a_out, gu_out)
+    def gemm_quickgelu(self, x, w, bias=None):
+        """quick_gelu(x @ w^T + bias) in one launch (Qwen2-VL vision MLP)."""
+        self._chk(x, w, bias)
+        M, K = x.shape
+        N = w.shape[0]
+        if self.FUSE_EPI and M > 64 and K % 64 == 0 and N % 8 == 0 and x.stride(1) == 1 and w.stride(1) == 1:
+            y = self.empty(M, N)
+            self.L.call("tr1_gemm_bias_quickgelu_bf16", _p(x), _p(w), _p(bias), _p(y), M, N, K, _ld(x), _ld(w), _ld(y), self._s())
+            return y
+        return self.quickgelu_fwd(self.gemm_nt(x, w, bias=bias))
+
+    def gemm_glu(self, x, w_gu, a_out=None, gu_out=None, save_gu=True, bias=None):
+        """(a, gu): a[M, I] = silu(x Wg^T + bg) * (x Wu^T + bu); gu = the projection [M, 2I] (None unless save_gu)."""
+        self._chk(x, w_gu, a_out, gu_out, bias)
         M, K = x.shape
         I = w_gu.shape[0] // 2
         if self.FUSE_EPI and M > 64 and K % 64 == 0 and I % 8 == 0 and x.stride(1) == 1 and w_gu.stride(1) == 1:
             a = a_out if a_out is not None else self.empty(M, I)
             gu = (gu_out if gu_out is not None else self.empty(M, 2 * I)) if save_gu else None
-            self.L.call("tr1_gemm_glu_bf16", _p(x), _p(w_gu), _p(a), _p(gu), M, I, K, _ld(x), _ld(w_gu), _ld(a), _ld(gu) if gu is not None else 0, self._s())
+            self.L.call("tr1_gemm_glu_bf16", _p(x), _p(w_gu), _p(bias), _p(a), _p(gu), M, I, K, _ld(x), _ld(w_gu), _ld(a), _ld(gu) if gu is not None else 0, self._s())
             return a, gu
-        gu = self.gemm_nt(x, w_gu, out=gu_out)
+        gu = self.gemm_nt(x, w_gu, bias=bias, out=gu_out)
         return self.swiglu_fwd(gu, out=a_out), (gu if save_gu else None)
 
     def gemm_qkv_rope(self, x, w_qkv, bias, cos, sin, n_heads, n_kv, head_dim, q_out=None, k_out=None, v_out=None):
@@ -269,7 +289,7 @@ class HipOps:
         return out
 
     # ---- native decode-step driver ------------------------------------------------------------------------------------
-    def decode_plan(self, layers, hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit, a8=False):
+    def decode_plan(self, layers, hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit, a8=False, qmask=31):
         """layers: per decoder layer the 9 tensors (ln1, qkv.w, qkv.b, o.w, ln2, gu.w, down.w, K cache, V^T cache).  Builds the host
         pointer table + device scratch once per rollout; decode_step then costs one C call per generated token."""
         import ctypes
@@ -277,7 +297,7 @@ class HipOps:
         per = len(flat) // max(len(layers), 1)
         assert per in (9, 13) and len(flat) == per * len(layers)      # 13 = fp8 matrices + their row scales (decode_step_w8)
         ptrs = (ctypes.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
-        dims = (ctypes.c_int64 * 11)(len(layers), hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit)
+        dims = (ctypes.c_int64 * 12)(len(layers), hidden, n_heads, n_kv, head_dim, inter, vocab, rows, n_batch, s_cap, nsplit, int(qmask))   # qmask: fp8 steps only
         nbytes = int(self.L.raw("tr1_decode_step_workspace_bytes")(dims))
         work = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)     # zero: the split-K ticket counters inside start disarmed
         logits = self.empty(rows, vocab)

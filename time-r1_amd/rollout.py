@@ -43,6 +43,7 @@ class Rollout:
         #                               per call; "fp8" converts the codes to bf16 in registers (W8A16), "fp8-mfma" feeds them to the fp8 matrix
         #                               instruction with block-quantised e4m3 activations (W8A8, BASELINE config "CDNA4 fp8 MFMA")
         self._w8 = None
+        self.fp8_keep_bf16 = ()       # matrices of the fp8 sampling policy that stay bf16: any of "qkv", "o", "gu", "down", "lm_head" (drift study)
         self.track_logp = False       # also record, per drawn token, its full-softmax log-prob under the logits it was SAMPLED from (one more pass
         #                               over the step's L2-resident logits): the drift of a quantised sampling policy against the bf16 policy of the
         #                               update is then a logged number (trainer metric rollout_logp_drift), and an importance weight is available
@@ -57,6 +58,12 @@ class Rollout:
         return c
 
     MATS = ("qkv.w", "o.w", "gu.w", "down.w")
+    QBITS = {"qkv": 1, "o": 2, "gu": 4, "down": 8, "lm_head": 16}
+
+    def fp8_mask(self):
+        keep = set(self.fp8_keep_bf16 or ())
+        assert keep <= set(self.QBITS), "fp8_keep_bf16: unknown matrix in %r" % (keep,)
+        return sum(b for n, b in self.QBITS.items() if n not in keep)
 
     def _quantize(self, arena, w_lm):
         """fp8 copies of the decode weights for THIS rollout (the weights change every optimizer step).  Only the sampling policy sees
@@ -67,10 +74,13 @@ class Rollout:
             self._w8 = dict(layers=[{n: (torch.empty(*shapes[n], dtype=torch.uint8, device=ops.device), ops.empty(shapes[n][0], dtype=torch.float32))
                                      for n in self.MATS} for _ in range(t.n_layers)],
                             lm=(torch.empty(*w_lm.shape, dtype=torch.uint8, device=ops.device), ops.empty(w_lm.shape[0], dtype=torch.float32)))
+        qm = self.fp8_mask()
         for i, L in enumerate(self._w8["layers"]):
             for n in self.MATS:
-                ops.quantize_fp8_rows(arena.w("l%d.%s" % (i, n)), q=L[n][0], scale=L[n][1])
-        ops.quantize_fp8_rows(w_lm, q=self._w8["lm"][0], scale=self._w8["lm"][1])
+                if qm & self.QBITS[n[:-2]]:
+                    ops.quantize_fp8_rows(arena.w("l%d.%s" % (i, n)), q=L[n][0], scale=L[n][1])
+        if qm & 16:
+            ops.quantize_fp8_rows(w_lm, q=self._w8["lm"][0], scale=self._w8["lm"][1])
         return self._w8
 
     def generate(self, arena, prompt_ids, vid_embeds, vid_rows, prompt_pos3, delta, save_prefill=False):
@@ -142,6 +152,7 @@ class Rollout:
         fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set
         native = fused and self.native_decode and hasattr(ops, "decode_step")
         w8 = None
+        qmask = self.fp8_mask()
         a8 = self.weight_dtype == "fp8-mfma"
         if self.weight_dtype in ("fp8", "fp8-mfma"):
             assert fused and t.hidden % 128 == 0 and t.intermediate % 128 == 0 and t.q_dim % 128 == 0, "fp8 decode: <= 64 rows, K % 128 == 0"
@@ -152,12 +163,15 @@ class Rollout:
                 if w8 is None:
                     return [arena.w("l%d.%s" % (i, n)) for n in ("ln1", "qkv.w", "qkv.b", "o.w", "ln2", "gu.w", "down.w")] + [cache.k[i], cache.vt[i]]
                 Q = w8["layers"][i]
-                return [arena.w("l%d.ln1" % i), Q["qkv.w"][0], arena.w("l%d.qkv.b" % i), Q["o.w"][0], arena.w("l%d.ln2" % i), Q["gu.w"][0], Q["down.w"][0],
+
+                def mat(n):      # fp8 codes, or the bf16 weight itself where the mask keeps this matrix in bf16
+                    return Q[n][0] if qmask & self.QBITS[n[:-2]] else arena.w("l%d.%s" % (i, n))
+                return [arena.w("l%d.ln1" % i), mat("qkv.w"), arena.w("l%d.qkv.b" % i), mat("o.w"), arena.w("l%d.ln2" % i), mat("gu.w"), mat("down.w"),
                         cache.k[i], cache.vt[i], Q["qkv.w"][1], Q["o.w"][1], Q["gu.w"][1], Q["down.w"][1]]
             plan = ops.decode_plan([layer_tensors(i) for i in range(t.n_layers)], t.hidden, t.n_heads, t.n_kv_heads, hd, t.intermediate, t.vocab_size,
-                                   R, B, cache.s_cap, nsplit, a8=a8)
+                                   R, B, cache.s_cap, nsplit, a8=a8, qmask=qmask)
             embed_p, norm_p = arena.w("embed").data_ptr(), arena.w("norm").data_ptr()
-            lm_p = w_lm.data_ptr() if w8 is None else (w8["lm"][0].data_ptr(), w8["lm"][1].data_ptr())
+            lm_p = w_lm.data_ptr() if w8 is None else ((w8["lm"][0] if qmask & 16 else w_lm).data_ptr(), w8["lm"][1].data_ptr())
             cos_p, sin_p, slot_p, hi_p = cos_all.data_ptr(), sin_all.data_ptr(), abs_slots.data_ptr(), hi_all.data_ptr()
             pre_p, lo_p = pre_all.data_ptr(), lo_all.data_ptr()
             ids_buf = ops.zeros(R, dtype=I32)
@@ -185,7 +199,8 @@ class Rollout:
             for i in range(t.n_layers):
                 p = "l%d." % i
                 Q = w8["layers"][i] if w8 is not None else None
-                if Q is not None:
+                q8 = (lambda n: Q is not None and bool(qmask & self.QBITS[n]))        # this matrix of the sampling policy is fp8
+                if q8("qkv"):
                     qkv = ops.gemm_w8(h, Q["qkv.w"][0], Q["qkv.w"][1], lnw=arena.w(p + "ln1"), eps=t.rms_eps, bias=arena.w(p + "qkv.b"), a8=a8)
                 elif fused and hd % 32 == 0:      # rmsnorm + q/k/v projection + M-RoPE + KV append: one launch (same choice as csrc/decode.hip)
                     qkv = None
@@ -206,22 +221,21 @@ class Rollout:
                     pk = dict(plan=host_plan, plan_mode=1 if i == 0 else 2)
                 o, _ = ops.attn_fwd(q, cache.k[i], cache.vt[i], pre_all, lo_all, hi_all[s], t.n_heads, t.n_kv_heads, cache.s_cap, hd, scale,
                                     nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=cache.s_cap, **pk)
-                if Q is not None:
-                    h2 = ops.gemm_w8(o, Q["o.w"][0], Q["o.w"][1], residual=h, a8=a8)
+                h2 = ops.gemm_w8(o, Q["o.w"][0], Q["o.w"][1], residual=h, a8=a8) if q8("o") else ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
+                if q8("gu"):
                     a = ops.gemm_w8(h2, Q["gu.w"][0], Q["gu.w"][1], lnw=arena.w(p + "ln2"), eps=t.rms_eps, glu=True, a8=a8)
-                    h = ops.gemm_w8(a, Q["down.w"][0], Q["down.w"][1], residual=h2, a8=a8)
-                    continue
-                h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h)
-                if fused:      # rmsnorm -> gate/up projection -> SwiGLU in one launch; the [R, 2I] intermediate never reaches HBM
+                elif fused:      # rmsnorm -> gate/up projection -> SwiGLU in one launch; the [R, 2I] intermediate never reaches HBM
                     a = ops.norm_gemm(h2, arena.w(p + "ln2"), t.rms_eps, arena.w(p + "gu.w"), glu=True)
                 else:
                     xn2, _, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=False)
                     a = ops.swiglu_fwd(ops.gemm_nt(xn2, arena.w(p + "gu.w")))
-                if fused and R >= 16 and t.intermediate >= 8192:      # same kernel choice as csrc/decode.hip (bitwise-equal paths)
+                if q8("down"):
+                    h = ops.gemm_w8(a, Q["down.w"][0], Q["down.w"][1], residual=h2, a8=a8)
+                elif fused and R >= 16 and t.intermediate >= 8192:      # same kernel choice as csrc/decode.hip (bitwise-equal paths)
                     h = ops.gemm_skinny_fixup(a, arena.w(p + "down.w"), residual=h2)
                 else:
                     h = ops.gemm_nt(a, arena.w(p + "down.w"), residual=h2)
-            if w8 is not None:
+            if w8 is not None and qmask & 16:
                 logits = ops.gemm_w8(h, w8["lm"][0], w8["lm"][1], lnw=arena.w("norm"), eps=t.rms_eps, a8=a8)
             elif fused:
                 logits = ops.norm_gemm(h, arena.w("norm"), t.rms_eps, w_lm)

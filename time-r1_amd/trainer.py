@@ -88,10 +88,14 @@ class GRPOConfig:
     disable_log_print: bool = False         # keep log() from printing on rank 0 (bench.py prints exactly one JSON line)
     log_rollout_drift: Optional[bool] = None   # metric rollout_logp_drift = mean |logp under the SAMPLING policy's logits - policy logp| over the
                                             # completion tokens; None = on whenever the rollout reads quantised weights (or an importance cap is set)
+    rollout_fp8_keep_bf16: tuple = ()   # fp8 sampling policies: matrices that stay bf16 ("qkv", "o", "gu", "down", "lm_head") - the W8A8 lm_head input is the
+    #                                     most drift-sensitive operand (DESIGN section 5, config-5 drift study)
     lazy_grad_zero: bool = True      # the optimizer leaves the decoder layers' large gradient matrices un-zeroed (the next window's first weight gradients
     #                                  overwrite them: Engine.lazy_zero_plan); False = zero the whole gradient arena every step
     rollout_importance_cap: Optional[float] = None   # c: advantage term weighted by min(exp(policy logp - sampling logp), c) per token (truncated
-                                            # importance sampling for a quantised sampling policy); None = off, the reference algebra unchanged
+                                            # importance sampling).  None = AUTO: off for a bf16 sampling policy (the reference algebra unchanged), c = 2 for the
+                                            # fp8 sampling policies, whose tokens are drawn ~0.2-0.3 nat off the update policy at 7B (e4m3's 3-bit
+                                            # mantissa bounds this from below, so the policy-gradient term is CORRECTED instead); 0 = off explicitly
     dataloader_prefetch: int = 2            # batches whose host preprocessing (decode / resize / tokenise) runs ahead on a worker thread; 0 = inline
     rope_index_mode: str = "hf4"            # position rule of the transformers version the reference pins
     # optimisation (HF TrainingArguments names)
@@ -188,6 +192,9 @@ class _PhaseClock:
             dt = e0.elapsed_time(e1) if self.cuda else (e1 - e0) * 1e3
             out[n1] = out.get(n1, 0.0) + dt
         return out
+
+
+FP8_IMPORTANCE_CAP = 2.0      # default truncation c of the per-token importance weight for quantised sampling policies (GRPOConfig.rollout_importance_cap)
 
 
 def clip_ratio_metrics(logp, old_logp, advantages, mask, eps_low=0.2, eps_high=0.2):
@@ -340,8 +347,12 @@ class TimeR1_Trainer:
                              use_grpo=self.use_grpo, temperature=args.temperature, top_k=args.top_k, seed=args.seed + 1000 * self.dp.rank,
                              rope_index_mode=args.rope_index_mode, stop_at_eos=args.stop_at_eos)
         self.core.roll.weight_dtype = getattr(args, "rollout_weight_dtype", "bf16")
+        self.core.roll.fp8_keep_bf16 = tuple(getattr(args, "rollout_fp8_keep_bf16", ()) or ())
         drift = getattr(args, "log_rollout_drift", None)
-        self._is_cap = getattr(args, "rollout_importance_cap", None)
+        cap = getattr(args, "rollout_importance_cap", None)
+        if cap is None and self.core.roll.weight_dtype != "bf16":
+            cap = FP8_IMPORTANCE_CAP          # an fp8 sampling policy is off-policy by construction: truncated importance weights by default
+        self._is_cap = float(cap) if cap else None
         self.core.roll.track_logp = bool(drift) if drift is not None else (self.core.roll.weight_dtype != "bf16" or self._is_cap is not None)
         if optimizers[0] is not None:
             raise NotImplementedError("custom torch optimizers are not supported; the engine owns a fused AdamW over its flat arena")
