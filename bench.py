@@ -584,6 +584,7 @@ def main(argv=None):
         # back exactly as in the timed windows.  (--roofline-op-by-op: rounds 1-2 method, the same kernels launched op by op from Python with
         # torch events - every pair then also brackets the interpreter time between two enqueues, which reads ~6% low.)
         wl.core.roll.native_decode = not args.roofline_op_by_op
+        overlap0 = wl.eng.overlap_wgrad
         wl.eng.overlap_wgrad = False        # ... and the weight-gradient GEMMs stay on the main stream: a launch timed while another GEMM
         if rank == 0 and wl.core.roll.native_decode:
             ops.decode_profile_begin()      # the C driver brackets its own GEMM launches (back to back, as in the timed windows)
@@ -605,7 +606,7 @@ def main(argv=None):
                                                     ("fp8 W8A8" if args.rollout_fp8 else "fp8 W8A16") + (", bf16 kept for " + args.rollout_fp8_keep_bf16 if args.rollout_fp8_keep_bf16 else ""))}
         dec_prof = ops.decode_profile_end() if rank == 0 and wl.core.roll.native_decode else None
         wl.core.roll.native_decode = True
-        wl.eng.overlap_wgrad = True
+        wl.eng.overlap_wgrad = overlap0
         if rank == 0:
             ops.gemm_nt, ops.norm_gemm, ops.gemm_skinny_fixup, ops.norm_gemm_qkv = orig
     if rank == 0 and not args.no_roofline:

@@ -25,7 +25,7 @@ F32 = torch.float32
 class Engine:
     def __init__(self, cfg: ModelConfig, ops, params: ModelParams):
         self.cfg, self.ops, self.params = cfg, ops, params
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get("TR1_WGRAD_OVERLAP", "1") != "0"      # weight gradients on a second HIP stream (A/B switch)
         # weight gradients that stay on the MAIN stream (d = down, g = gate/up, o, q = qkv); the rest runs on the side stream beside the dgrad
         # chain.  With the dgrad reading the weights as stored (NN form) the main stream has slack: keeping the down projection's weight
         # gradient there balanced the two streams best on MI355X (backward 175 ms against 180 with everything on the side stream; with the main
