@@ -53,6 +53,10 @@ int tr1_gemm_bias_quickgelu_bf16(const void* x, const void* W, const void* bias,
 /* tr1_gemm_qkv_rope_bf16: fused q|k|v projection + bias + multimodal rotary embedding for head dim 128 (TF:501-504 q/k/v_proj, TF:212-222
  *   apply_multimodal_rotary_pos_emb): q_out / k_out rotated with cos / sin fp32 [M, 64], v_out plain; k_out may point into the KV cache rows. */
 int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ldq, void* k_out, int64_t ldk, void* v_out, int64_t ldv, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, void* stream);
+/* tr1_gemm_qkv_rope_vit_bf16: the vision blocks' q|k|v projection + bias + 2-D rotary embedding (TF:225-248 apply_rotary_pos_emb_vision inside VisionAttention
+ *   TF:322-360; Qwen2.5-VL modeling_qwen2_5_vl.py:160-230) for head dim 2 * half = 80, written as 128-wide zero-padded heads (d < half at column d, d + half at
+ *   64 + d; the caller zero-fills q128 / k128 / v128 once) so that the head-dim-128 attention kernel (tr1_attn_fwd_rows) runs the tower.  cos / sin fp32 [M, half]. */
+int tr1_gemm_qkv_rope_vit_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q128, int64_t ldq, void* k128, int64_t ldk, void* v128, int64_t ldv, int64_t M, int64_t n_heads, int64_t half, int64_t K, int64_t ldx, int64_t ldw, void* stream);
 /* tr1_gemm_nn_glubwd_bf16: dgu[M, 2I] = SwiGLU backward of da = dh[M, H] Wd[H, I] (the down projection as stored) with the saved gu[M, 2I]; da is never
  *   written (autograd of TF:459-466 under accelerator.backward, src/time_r1/rl/timer1_trainer.py:709-737). */
 int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void* dgu, int64_t M, int64_t I, int64_t H, int64_t lda, int64_t ldb, int64_t ldgu, int64_t lddgu, void* stream);

@@ -78,6 +78,45 @@ def test_qwen25_vision_tower_matches_oracle(hip_ops, grid):
     assert err < 0.03 * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("variant,grid", [("qwen2_vl", [(3, 12, 16)]), ("qwen2_5_vl", [(2, 12, 20)])])
+def test_vision_tower_on_padded_heads_at_real_head_dim(hip_ops, variant, grid):
+    """The towers at their real attention geometry (16 heads of 80) run on 128-wide zero-padded heads: q|k|v GEMM with bias + 2-D rotary in its epilogue,
+    the head-dim-128 attention kernel, a zero-column-padded output projection (Engine._vit_pad128).  Same features as the 96-wide path (rope / V^T / 16x16-MFMA
+    attention kernels) and as the oracle tower."""
+    import time_r1_amd  # noqa: F401
+    from time_r1_amd.config import tiny_test, tiny_test_25, VisionConfig
+    from time_r1_amd.params import ModelParams
+    from time_r1_amd.model import Engine
+    from oracle import ref_model as RM
+    cfg = tiny_test_25() if variant == "qwen2_5_vl" else tiny_test()
+    cfg.vision = VisionConfig(depth=3, embed_dim=1280, num_heads=16, mlp_dim=3420 if variant == "qwen2_5_vl" else 5120, out_hidden=128, variant=variant,
+                              **({"window_size": 112, "fullatt_block_indexes": (1,)} if variant == "qwen2_5_vl" else {}))
+    ops = hip_ops
+    params = ModelParams(cfg, ops, seed=5)
+    eng = Engine(cfg, ops, params)
+    v = cfg.vision
+    assert v.head_dim == 80 and ops.vit_pad128_ok(v.num_heads, v.head_dim)
+    n = sum(t * h * w for t, h, w in grid)
+    pix = torch.randn(n, v.patch_dim, generator=torch.Generator().manual_seed(3))
+    pp = ops.zeros(n, v.patch_dim_padded)
+    pp[:, : v.patch_dim] = pix.to(pp.device).to(pp.dtype)
+    feats, perm = eng.vit_features(pp, grid)
+    assert eng._vit_pad128(n) is not None
+    ops.FUSE_EPI = False
+    try:
+        assert eng._vit_pad128(n) is None
+        feats0, _ = eng.vit_features(pp, grid)
+    finally:
+        del ops.FUSE_EPI
+    scale = max(1.0, float(feats0.float().abs().max()))
+    assert float((feats.float() - feats0.float()).abs().max()) < 0.03 * scale
+    out, _ = eng.merger_fwd(params.train, feats, save=False, perm=perm)
+    W = RM.weights_from_params(params)
+    want = RM.vision_tower(W, cfg, pp[:, : v.patch_dim].float().cpu(), grid)
+    err = (out.float().cpu() - want).abs().max().item()
+    assert err < 0.03 * max(1.0, want.abs().max().item()), err
+
+
 @pytest.mark.parametrize("B,inter", [(1, 256), (2, 256), (2, 8192)])     # inter 8192 with 16 rows engages the split-K fixup down projection
 def test_native_decode_step_equals_op_by_op(hip_ops, B, inter):
     """csrc/decode.hip enqueues the same kernels in the same order as the host-driven loop: sampled tokens must be identical."""

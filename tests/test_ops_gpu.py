@@ -274,6 +274,31 @@ def test_gemm_qkv_rope_fused_epilogue(hip_ops, ref_ops, M, nh, nkv, K, row0):
     close(q, qr, atol, rtol=3e-2, what="q rope"); close(k, kr, atol, rtol=3e-2, what="k rope"); close(v, vr, atol, rtol=3e-2, what="v")
 
 
+@pytest.mark.parametrize("M,H,K", [(1000, 16, 1280), (300, 16, 128), (5074, 32, 64)])
+def test_gemm_qkv_rope_vit_padded_heads(hip_ops, ref_ops, M, H, K):
+    """Vision q|k|v projection + bias + 2-D rotary embedding written as 128-wide zero-padded heads (csrc/gemm.hip EPI 7): d < 40 at column d, d + 40 at 64 + d.
+    Bit-identical to GEMM + rope_apply(head dim 80) scattered into that layout; pad columns untouched (zero)."""
+    hd, half = 80, 40
+    E = H * hd
+    x, w, b = rnd(M, K, seed=1), rnd(3 * E, K, seed=2, scale=0.1), rnd(3 * E, seed=3)
+    ang = torch.rand(M, half, generator=torch.Generator().manual_seed(5)) * 6.28
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+    assert hip_ops.vit_pad128_ok(H, hd)
+    q128, k128, v128 = [torch.zeros(M, H * 128, dtype=BF16, device="cuda:0") for _ in range(3)]
+    hip_ops.gemm_qkv_rope_vit(x.cuda(), w.cuda(), b.cuda(), cos.cuda(), sin.cuda(), H, half, q128, k128, v128)
+    with _unfused(hip_ops) as o:
+        qkv = o.gemm_nt(x.cuda(), w.cuda(), bias=b.cuda())
+        q = o.rope_apply(qkv[:, :E], H, hd, cos.cuda(), sin.cuda())
+        k = o.rope_apply(qkv[:, E:2 * E], H, hd, cos.cuda(), sin.cuda())
+        v = qkv[:, 2 * E:]
+    for got, want, nm in ((q128, q, "q"), (k128, k, "k"), (v128, v, "v")):
+        g3, w3 = got.view(M, H, 128), want.reshape(M, H, hd)
+        assert torch.equal(g3[:, :, :half], w3[:, :, :half]) and torch.equal(g3[:, :, 64:64 + half], w3[:, :, half:]), nm
+        assert float(g3[:, :, half:64].abs().max()) == 0.0 and float(g3[:, :, 64 + half:].abs().max()) == 0.0, nm + " pad columns"
+    qr = ref_ops.rope_apply(ref_ops.gemm_nt(x.float(), w.float(), bias=b.float())[:, :E], H, hd, cos, sin)
+    close(q128.view(M, H, 128)[:, :, :half], qr.view(M, H, hd)[:, :, :half], 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=3e-2, what="q vs oracle")
+
+
 @pytest.mark.parametrize("M,I,H", [(2048, 6400, 256), (1600, 8192, 128), (5074, 4096, 64)])
 def test_dgrad_glu_bwd_fused_epilogue(hip_ops, ref_ops, M, I, H):
     """Down-projection dgrad (weight as stored) with the SwiGLU backward in its epilogue (EPI 3): bit-identical to gemm_nn + swiglu_bwd."""

@@ -55,6 +55,12 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
         const int id = (int)blockIdx.x, xcd = id & 7, per = 8 / p.n_kv;
         kvh = xcd % p.n_kv; qb = (id >> 3) * per + xcd / p.n_kv;
         if (qb >= nqb) return;
+    } else if ((p.n_kv & 7) == 0) {
+        // >= 8 kv heads (the vision towers: 16 heads, group 1): head h is served by XCD h % 8, which walks that head's query blocks in order - a segment's
+        // K / V (0.4 MB at config 3) is then fetched into ONE L2 instead of into all eight (the plain map dealt the query blocks of a head round-robin
+        // over the XCDs: 8 x the operand bytes from HBM, the round-2 finding for the 96-wide kernel)
+        const int id = (int)blockIdx.x, xcd = id & 7, sq = id >> 3;
+        kvh = xcd + 8 * (sq / nqb); qb = sq - (sq / nqb) * nqb;
     } else { qb = (int)blockIdx.x % nqb; kvh = (int)blockIdx.x / nqb; }
     const unsigned Rw0 = (unsigned)(nqb - 1 - qb) * 256u + (unsigned)wave * 32u;
     const unsigned R = Rw0 + (unsigned)c32;

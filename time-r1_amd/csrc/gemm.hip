@@ -490,6 +490,12 @@ TR1_DEV int64_t epi_brow(int row, int64_t n0, int64_t N, const GemmEpi& ep) {
         const int64_t r = n0 + row;
         return r < N ? r : N - 1;
     }
+    if (EPI == 7) {          // vision q|k|v: ep.i0 = pairs per section (n_heads * half), ep.i1 = half (40); a tile = 128 consecutive pairs of one section
+        const int tps = ep.i0 >> 7, tile = (int)(n0 >> 8);
+        const int sec = tile / tps, pair = (tile - sec * tps) * 128 + (row >> 6) * 32 + (row & 31);
+        const int head = pair / ep.i1, d = pair - head * ep.i1;
+        return (int64_t)sec * 2 * ep.i0 + head * 2 * ep.i1 + d + ((row >> 5) & 1) * ep.i1;
+    }
     const int64_t r = n0 + row;
     return r < N ? r : N - 1;
 }
@@ -503,7 +509,7 @@ TR1_DEV void stage_round(const bf16_t* __restrict__ g, int64_t ld, int64_t row0,
     if (REGION_ROWS % 64 != 0 && inst * 8 >= REGION_ROWS) { dst = junk + (wave & 3) * 1024; row = REGION_ROWS - 8 + (lane >> 3); }   // wave-uniform
     const int logical = (lane & 7) ^ (IS_B ? keyB(row) : keyA(row));
     int64_t grow;
-    if (IS_B && (EPI == 2 || EPI == 4)) grow = epi_brow<EPI>(row, row0, rows_valid, *ep);
+    if (IS_B && (EPI == 2 || EPI == 4 || EPI == 7)) grow = epi_brow<EPI>(row, row0, rows_valid, *ep);
     else { grow = row0 + row; if (grow >= rows_valid) grow = rows_valid - 1; }
     __builtin_amdgcn_global_load_lds((gptr_t)(g + grow * ld + k0 + logical * 8), (lptr_t)dst, 16, 0, 0);
 }
@@ -530,6 +536,23 @@ TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ 
         if (bias && col_ok) { ba = *reinterpret_cast<const u32x4_t*>(bias + col_a); bb = *reinterpret_cast<const u32x4_t*>(bias + I + col_a); }
         dst_a = reinterpret_cast<bf16_t*>(Cv) + col_a; dst_b = nullptr; ld_o = ldc;
         if (ep.p0) { dst_ga = reinterpret_cast<bf16_t*>(ep.p0) + col_a; dst_gb = dst_ga + I; ld_g = ep.ld0; }
+    } else if (EPI == 7) {
+        // Qwen2-VL / 2.5-VL vision attention (TF:225-248 apply_rotary_pos_emb_vision, head dim 80): section = q | k | v, the lane's 8 pair columns d0..d0+7
+        // (< 40) of one head and their partners d0 + 40.  Outputs go to 128-wide PADDED heads: d -> head*128 + d, d + 40 -> head*128 + 64 + d, so the head-dim-128
+        // attention kernels (32x32x16 MFMA, K / V row-major) take the tower; the pad columns are zero-filled once by the caller.
+        const int tps = ep.i0 >> 7, tile = (int)(n0 >> 8);
+        const int sec = tile / tps, pair0 = (tile - sec * tps) * 128 + wn * 32 + c4 * 8;
+        const int head = pair0 / ep.i1, d0 = pair0 - head * ep.i1;
+        const int64_t ncol = (int64_t)sec * 2 * ep.i0 + head * 2 * ep.i1 + d0;
+        col_ok = true;
+        dcs = sec < 2 ? d0 : -1;                                        // -1: v, no rotation
+        if (bias) { ba = *reinterpret_cast<const u32x4_t*>(bias + ncol); bb = *reinterpret_cast<const u32x4_t*>(bias + ncol + ep.i1); }
+        if (sec == 0) { dst_a = reinterpret_cast<bf16_t*>(Cv); ld_o = ldc; }
+        else if (sec == 1) { dst_a = reinterpret_cast<bf16_t*>(ep.p0); ld_o = ep.ld0; }
+        else { dst_a = reinterpret_cast<bf16_t*>(ep.p1); ld_o = ep.ld1; }
+        dst_a += head * 128 + d0;
+        dst_b = dst_a + 64;
+        col_a = ncol;
     } else {
         const int d = (wn & 1) * 32 + c4 * 8;
         const int64_t ncol = n0 + (wn >> 1) * 128 + d;                  // column of the fused q|k|v projection
@@ -587,10 +610,12 @@ TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ 
                         }
                         *reinterpret_cast<u32x4_t*>(dst_a + m * ld_o) = oa;
                     } else {
-                        const float* cp = ep.f0 + m * 64 + dcs;
-                        const float* sp = ep.f1 + m * 64 + dcs;
-                        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cp), c1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
-                        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sp), s1 = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                        const int rs = EPI == 7 ? ep.i1 : 64, dc = dcs < 0 ? 0 : dcs;
+                        const float* cp = ep.f0 + m * rs + dc;
+                        const float* sp = ep.f1 + m * rs + dc;
+                        f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cp), c1 = *reinterpret_cast<const f32x4_t*>(cp + 4);
+                        f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sp), s1 = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                        if (EPI == 7 && dcs < 0) { c0 = c1 = (f32x4_t){1.f, 1.f, 1.f, 1.f}; s0 = s1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }    // v: x * 1 - y * 0 = x exactly
                         const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
                         const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
@@ -818,7 +843,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 #undef STAGE_B
 #if TR1_EPI_LDS
     // every wave is past its last LDS read (the realignment barrier above): the operand buffers become 8 private staging slices
-    if (EPI == 2 || (EPI == 4 && n0 < (int64_t)ep.i0 + ep.i1))
+    if (EPI == 2 || EPI == 7 || (EPI == 4 && n0 < (int64_t)ep.i0 + ep.i1))
         store_acc256_pairs<RT, EPI>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, M, N, ldc, m0 + wm * (RT * 16), n0, wn, lane, ep);
     else if (EPI == 4)       // V tile: bias only, into its own buffer
         store_acc256_lds<false, false, RT, 0>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), ep.p1, bias + ep.i0 + ep.i1, nullptr, M, N - ep.i0 - ep.i1,
@@ -2147,6 +2172,31 @@ extern "C" int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const voi
     EPI_LAUNCH(KA_QKV, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)Wqkv, q_out, (const bf16_t*)bias,
                (const bf16_t*)nullptr, M, N, K, ldx, ldw, ldq, (int64_t)0, (int)t2m, (int)t2n, ep);
 #undef KA_QKV
+    TR1_LAUNCH_CHECK();
+}
+
+// Vision-tower attention input (Qwen2-VL / Qwen2.5-VL blocks, head dim 2 * half = 80): fused q|k|v projection + bias + 2-D rotary embedding (cos / sin fp32
+// [M, half]), written as 128-wide zero-PADDED heads q128 / k128 / v128 [M, n_heads * 128] (feature d < half at d, d + half at 64 + d; the caller zero-fills
+// the buffers once).  Values bit-identical to tr1_gemm_nt_bf16 (bias) + tr1_rope_apply on q and k.  n_heads * half must be a multiple of 128.
+extern "C" int tr1_gemm_qkv_rope_vit_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q128, int64_t ldq,
+                                          void* k128, int64_t ldk, void* v128, int64_t ldv, int64_t M, int64_t n_heads, int64_t half, int64_t K,
+                                          int64_t ldx, int64_t ldw, void* stream) {
+    TR1_CHECK_ARG(half % 8 == 0 && half <= 64 && (n_heads * half) % 128 == 0, "gemm_qkv_rope_vit: half % 8 == 0, half <= 64, n_heads * half % 128 == 0 required");
+    TR1_CHECK_ARG(K % BK == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "gemm_qkv_rope_vit: K%64, ld%8 required");
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t pairs = n_heads * half, N = 6 * pairs, t2n = N / 256;
+    const int rt = epi_pick_rt(M, t2n);
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx;
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+#define KA_VQ(R) false, false, R, false, 7
+    EPI_SETATTR(KA_VQ);
+    GemmEpi ep{}; ep.p0 = k128; ep.ld0 = ldk; ep.p1 = v128; ep.ld1 = ldv; ep.f0 = (const float*)cosb; ep.f1 = (const float*)sinb;
+    ep.i0 = (int)pairs; ep.i1 = (int)half;
+    EPI_LAUNCH(KA_VQ, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)x, (const bf16_t*)Wqkv, q128, (const bf16_t*)bias,
+               (const bf16_t*)nullptr, M, N, K, ldx, ldw, ldq, (int64_t)0, (int)t2m, (int)t2n, ep);
+#undef KA_VQ
     TR1_LAUNCH_CHECK();
 }
 

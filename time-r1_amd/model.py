@@ -138,19 +138,58 @@ class Engine:
         cos, sin = ops.vision_rope_table(hw, hd)
         x = ops.gemm_nt(pixels, fz.w("patch.w"))
         scale = hd ** -0.5
+        pad = self._vit_pad128(N)
         for i in range(v.depth):
             p = "v%d." % i
             y, _, _ = ops.layernorm_fwd(x, fz.w(p + "n1.w"), fz.w(p + "n1.b"), v.ln_eps, need_stats=False)
-            qkv = ops.gemm_nt(y, fz.w(p + "qkv.w"), bias=fz.w(p + "qkv.b"))
-            q = ops.rope_apply(qkv[:, :E], H, hd, cos, sin)
-            k = ops.rope_apply(qkv[:, E:2 * E], H, hd, cos, sin)
-            vt = ops.pack_transpose(qkv[:, 2 * E:], H, H, hd)
-            o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
-            x = ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
+            x = self._vit_attention(i, y, x, cos, sin, pre, lo, hi, N, scale, pad)
             y, _, _ = ops.layernorm_fwd(x, fz.w(p + "n2.w"), fz.w(p + "n2.b"), v.ln_eps, need_stats=False)
             z = ops.gemm_quickgelu(y, fz.w(p + "fc1.w"), fz.w(p + "fc1.b"))          # fc1 + bias + QuickGELU in the GEMM epilogue
             x = ops.gemm_nt(z, fz.w(p + "fc2.w"), bias=fz.w(p + "fc2.b"), residual=x)
         return x, None
+
+    # ---- vision attention sub-block (both towers): x + proj(attention(rope(q), rope(k), v))
+    def _vit_pad128(self, N):
+        """Head dim 80 on 128-wide zero-padded heads: feature d < 40 at column d, d + 40 at 64 + d, so that (a) the q|k|v GEMM's epilogue adds the bias and
+        applies the 2-D rotary embedding (its rotate-half partners sit 64 apart, like the LLM's) and (b) the head-dim-128 attention kernel (32x32x16 MFMA,
+        K and V row-major: no V^T copy) runs the tower - 236 -> ~140 us per block at config 3 against the 96-wide 16x16 kernel, and the two rope launches
+        and the V^T pack disappear.  Returns None when the shapes / backend do not allow it.  The padded output-projection weights (zero columns at the pad
+        positions) are derived ONCE per version of the frozen arena."""
+        ops, v, fz = self.ops, self.cfg.vision, self.params.frozen
+        ok = getattr(ops, "vit_pad128_ok", None)
+        if ok is None or not ok(v.num_heads, v.head_dim):
+            return None
+        H, hd, E, half = v.num_heads, v.head_dim, v.embed_dim, v.head_dim // 2
+        cache = self.__dict__.setdefault("_vit_pad_cache", {})
+        ver = (fz.w16.data_ptr(), fz.w16._version)         # torch's in-place version counter: any write to the frozen arena (loaders, tests) rebuilds
+        if cache.get("ver") != ver:
+            proj = []
+            for i in range(v.depth):
+                w = fz.w("v%d.proj.w" % i).view(E, H, hd)
+                wp = ops.zeros(E, H, 128)
+                wp[:, :, :half] = w[:, :, :half]
+                wp[:, :, 64:64 + half] = w[:, :, half:]
+                proj.append(wp.view(E, H * 128))
+            cache.update(ver=ver, proj=proj, bufs=None)
+        if cache.get("bufs") is None or cache["bufs"][0].shape[0] != N:
+            cache["bufs"] = [ops.zeros(N, H * 128) for _ in range(3)] + [ops.empty(N, H * 128)]      # q, k, v (pad columns stay zero), o
+        return dict(proj=cache["proj"], bufs=cache["bufs"])
+
+    def _vit_attention(self, i, y, x, cos, sin, pre, lo, hi, N, scale, pad):
+        ops, v, fz = self.ops, self.cfg.vision, self.params.frozen
+        E, H, hd = v.embed_dim, v.num_heads, v.head_dim
+        p = "v%d." % i
+        if pad is not None:
+            q, k, vv, o = pad["bufs"]
+            ops.gemm_qkv_rope_vit(y, fz.w(p + "qkv.w"), fz.w(p + "qkv.b"), cos, sin, H, hd // 2, q, k, vv)
+            ops.attn_fwd(q, k, None, pre, lo, hi, H, H, N, 128, scale, need_lse=False, v_rows=vv, out=o)
+            return ops.gemm_nt(o, pad["proj"][i], bias=fz.w(p + "proj.b"), residual=x)
+        qkv = ops.gemm_nt(y, fz.w(p + "qkv.w"), bias=fz.w(p + "qkv.b"))
+        q = ops.rope_apply(qkv[:, :E], H, hd, cos, sin)
+        k = ops.rope_apply(qkv[:, E:2 * E], H, hd, cos, sin)
+        vt = ops.pack_transpose(qkv[:, 2 * E:], H, H, hd)
+        o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
+        return ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
 
     def _vit_features_25(self, pixels, grid_thw):
         """Qwen2.5-VL tower (transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:408-470 forward, :294-325 block, :85-96 MLP):
@@ -171,16 +210,12 @@ class Engine:
         x = ops.gemm_nt(pixels, fz.w("patch.w"))
         x = ops.gather_rows(x.view(N // U, U * E), perm).view(N, E)
         scale = hd ** -0.5
+        pad = self._vit_pad128(N)
         for i in range(v.depth):
             p = "v%d." % i
             pre, lo, hi = seg_full if i in v.fullatt_block_indexes else seg_win
             y, _, _ = ops.rmsnorm_fwd(x, fz.w(p + "n1.w"), v.ln_eps, need_rstd=False)
-            qkv = ops.gemm_nt(y, fz.w(p + "qkv.w"), bias=fz.w(p + "qkv.b"))
-            q = ops.rope_apply(qkv[:, :E], H, hd, cos, sin)
-            k = ops.rope_apply(qkv[:, E:2 * E], H, hd, cos, sin)
-            vt = ops.pack_transpose(qkv[:, 2 * E:], H, H, hd)
-            o, _ = ops.attn_fwd(q, k, vt, pre, lo, hi, H, H, N, hd, scale, need_lse=False)
-            x = ops.gemm_nt(o, fz.w(p + "proj.w"), bias=fz.w(p + "proj.b"), residual=x)
+            x = self._vit_attention(i, y, x, cos, sin, pre, lo, hi, N, scale, pad)
             y, _, _ = ops.rmsnorm_fwd(x, fz.w(p + "n2.w"), v.ln_eps, need_rstd=False)
             a, _ = ops.gemm_glu(y, fz.w(p + "gu.w"), save_gu=False, bias=fz.w(p + "gu.b"))      # gate/up + bias + SwiGLU in the GEMM epilogue
             x = ops.gemm_nt(a, fz.w(p + "down.w"), bias=fz.w(p + "down.b"), residual=x)

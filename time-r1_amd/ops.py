@@ -211,6 +211,20 @@ class HipOps:
             v = v_out
         return q, k, v
 
+    def vit_pad128_ok(self, n_heads, head_dim):
+        """The vision tower can run on 128-wide zero-padded heads (fused q|k|v + rotary epilogue -> head-dim-128 attention kernel)."""
+        half = head_dim // 2
+        return bool(self.FUSE_EPI and self.FWD32 and head_dim < 128 and head_dim % 16 == 0 and half <= 64 and (n_heads * half) % 128 == 0)
+
+    def gemm_qkv_rope_vit(self, x, w_qkv, bias, cos, sin, n_heads, half, q128, k128, v128):
+        """Vision q|k|v projection + bias + rotary into 128-wide padded heads (pad columns of q128 / k128 / v128 must already be zero)."""
+        self._chk(x, w_qkv, bias, q128, k128, v128)
+        M, K = x.shape
+        assert cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (M, half)
+        assert w_qkv.shape[0] == 6 * n_heads * half and q128.shape == (M, n_heads * 128) == k128.shape == v128.shape
+        self.L.call("tr1_gemm_qkv_rope_vit_bf16", _p(x), _p(w_qkv), _p(bias), _p(cos), _p(sin), _p(q128), _ld(q128), _p(k128), _ld(k128), _p(v128), _ld(v128),
+                    M, n_heads, half, K, _ld(x), _ld(w_qkv), self._s())
+
     def dgrad_glu_bwd(self, dh, w_down, gu):
         """dgu[M, 2I] = swiglu_bwd(dh @ w_down, gu) with w_down [H, I] as stored (K-major operand)."""
         self._chk(dh, w_down, gu)
