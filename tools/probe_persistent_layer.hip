@@ -5,7 +5,7 @@
 //   B  one persistent kernel, hierarchical grid barrier between phases,
 //   C  as B, and the first ring stages of the NEXT phase's weights are requested before the barrier.
 // No MFMA work, no fixups, no attention arithmetic: everything a real engine adds makes B / C slower, not faster.
-//   hipcc --offload-arch=gfx950 -O2 tools/probe_persistent_layer.hip -o /tmp/ppl && /tmp/ppl
+//   hipcc --offload-arch=gfx950 -O2 tools/probe_persistent_layer.hip -o /tmp/ppl && /tmp/ppl [2b]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
@@ -109,9 +109,13 @@ __global__ __launch_bounds__(512) void layer_kernel(const Phases* layers, int n_
     }
 }
 
-int main() {
-    // bytes per phase of a 7B decode layer at 16 rows: qkv, attention KV (config 3), split-KV partials, o, gate/up, down
-    const double mb[NPH] = {33.0, 17.5, 6.4, 25.7, 271.6, 135.8};
+int main(int argc, char** argv) {
+    // bytes per phase of a decode layer at 16 rows: qkv, attention KV, split-KV partials, o, gate/up, down.  Default: Qwen2-VL-7B (config 3);
+    // `2b`: Qwen2-VL-2B at config 2 (hidden 1536, 12 / 2 heads of 128, intermediate 8960, 16 frames: P ~ 2 520 prompt tokens, 20 splits)
+    const double mb7[NPH] = {33.0, 17.5, 6.4, 25.7, 271.6, 135.8}, mb2[NPH] = {6.3, 5.2, 2.0, 4.7, 55.0, 27.5};
+    const bool two_b = argc > 1 && argv[1][0] == '2';
+    const double* mb = two_b ? mb2 : mb7;
+    printf("model: %s\n", two_b ? "Qwen2-VL-2B (config 2)" : "Qwen2-VL-7B (config 3)");
     const int nb = 256;
     std::vector<Phases> h(NLAYER);
     for (int L = 0; L < NLAYER; ++L)
