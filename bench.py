@@ -88,7 +88,7 @@ class Workload:
                            lr_scheduler_type="constant", logging_steps=1, save_strategy="no", disable_log_print=True, shard_optimizer=self.shard,
                            rollout_batching=not args.no_rollout_batching,
                            rollout_weight_dtype="fp8" if args.rollout_fp8_w8a16 else ("fp8-mfma" if args.rollout_fp8 else "bf16"),
-                           rollout_fp8_keep_bf16=tuple(x for x in args.rollout_fp8_keep_bf16.split(",") if x),
+                           rollout_fp8_keep_bf16=None if args.rollout_fp8_keep_bf16 == "auto" else tuple(x for x in args.rollout_fp8_keep_bf16.split(",") if x and x != "none"),
                            rollout_importance_cap=args.rollout_importance_cap)
         self.trainer = TimeR1_Trainer(self.params, self.reward_funcs, [], args=targs, train_dataset=self.dataset,
                                       processing_class=SyntheticProcessor(self.cfg), ops=ops)
@@ -435,7 +435,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-rollout-batching", action="store_true", help="decode each prompt of the accumulation window separately")
     ap.add_argument("--rollout-fp8", action="store_true", help="BASELINE config 'fp8 weights': decode GEMMs read e4m3 weight copies (sampling policy only), fp8 MFMA (W8A8)")
     ap.add_argument("--rollout-fp8-w8a16", action="store_true", help="fp8 weight copies converted to bf16 in registers (bf16 MFMA) instead of the fp8 MFMA")
-    ap.add_argument("--rollout-fp8-keep-bf16", default="", help="comma list of matrices of the fp8 sampling policy that stay bf16: qkv,o,gu,down,lm_head (config-5 drift study)")
+    ap.add_argument("--rollout-fp8-keep-bf16", default="auto", help="comma list of matrices of the fp8 sampling policy that stay bf16: qkv,o,gu,down,lm_head; 'auto' = the trainer's "
+                    "default (qkv,o for the fp8-MFMA policy: faster and less drift than all-fp8, DESIGN 7d), 'none' = every matrix fp8")
     ap.add_argument("--rollout-importance-cap", type=float, default=None, help="truncated importance weight min(exp(policy logp - sampling logp), c) on the advantage term")
     ap.add_argument("--engine-path", action="store_true", help="time the bare engine loop (GRPOCore + AdamWFlat, no TimeR1_Trainer) instead of the trainer class")
     ap.add_argument("--no-engine-leg", action="store_true", help="skip the short bare-engine-loop cross-check that follows the timed region")
@@ -540,6 +541,12 @@ def main(argv=None):
         engine_leg = {"ms_per_step": 1000.0 * (time.perf_counter() - t1) / n_leg, "steps": n_leg,
                       "what": "GRPOCore + AdamWFlat driven by a bare loop (no TimeR1_Trainer, no metrics, no log): the round-1/2 measurement path"}
 
+    # per-rank peak HBM (every rank takes part in the gather): the optimizer-state sharding shows up here as bytes, not as a claim
+    mem_here = round(torch.cuda.max_memory_allocated() / 1e9, 3)
+    mem_all = [mem_here]
+    if dp.enabled:
+        mem_all = [None] * world
+        torch.distributed.all_gather_object(mem_all, mem_here)
     out = None
     if rank == 0:
         cfg = wl.cfg
@@ -556,7 +563,7 @@ def main(argv=None):
             "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
             "engine_path": engine_leg,
             "distributed": {**diag, "grad_exchange_exposed_ms_per_optimizer_step": round(exch_ms / max(len(timed_plan), 1), 3),
-                            "optimizer_sharded": bool(wl.shard), "grad_wire_dtype": "bf16",
+                            "optimizer_sharded": bool(wl.shard), "grad_wire_dtype": "bf16", "hbm_gb_allocated_peak_per_rank": mem_all,
                             "process_group_timeout_s": float(os.environ.get("TR1_DIST_TIMEOUT_S", "600"))},
             "trainer_log_last": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (logs[-1] if logs else {}).items()},
             "optimizer_steps": len(timed_plan), "windows": "%d x %d" % (args.steps // args.ga, args.ga) + (" + 1 x %d" % (args.steps % args.ga) if args.steps % args.ga else ""),
@@ -566,8 +573,10 @@ def main(argv=None):
                                    "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step%s"
                                    % (cfg.name, args.frames, str(wl.grid), wl.P or 0, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
                                       wl.src_hw[0], wl.src_hw[1],
-                                      ("; fp8 (e4m3) weights for the SAMPLING policy only - prefill, log-probs, KL and the update read bf16; advantage term weighted by the "
-                                       "truncated importance ratio min(p_update / p_sampling, %g)" % (tr._is_cap or 0.0)) if (args.rollout_fp8 or args.rollout_fp8_w8a16) else ""),
+                                      ("; fp8 (e4m3) weights for the SAMPLING policy only (fp8: %s; bf16: %s) - prefill, log-probs, KL and the update read bf16; advantage term weighted by "
+                                       "the truncated importance ratio min(p_update / p_sampling, %g)"
+                                       % (",".join(n for n in ("qkv", "o", "gu", "down", "lm_head") if n not in tr.core.roll.fp8_keep_bf16),
+                                          ",".join(tr.core.roll.fp8_keep_bf16) or "-", tr._is_cap or 0.0)) if (args.rollout_fp8 or args.rollout_fp8_w8a16) else ""),
                        "frames": "pinned host memory, copied to HBM inside the timed step" if args.host_frames else "resident in HBM before the timed region",
                        "completion_lengths": "ragged: EOS injected at uniform[C/2, C) per row, seed 1" if args.ragged_eos else "all C tokens (EOS suppressed)",
                        "parallelism": "dp%d" % world, "weights": "random-init", "rollout_prompts_in_flight": 1 if args.no_rollout_batching else args.ga,
@@ -603,7 +612,7 @@ def main(argv=None):
                                          "what": "mean over completion tokens of |log p_sampling(token) - log p_update(token)| in the instrumented window: "
                                                  "sampling policy = the decode kernels' logits (%s), update policy = the bf16 training forward on the same weights"
                                                  % ("bf16 weights" if not (args.rollout_fp8 or args.rollout_fp8_w8a16) else
-                                                    ("fp8 W8A8" if args.rollout_fp8 else "fp8 W8A16") + (", bf16 kept for " + args.rollout_fp8_keep_bf16 if args.rollout_fp8_keep_bf16 else ""))}
+                                                    ("fp8 W8A8" if args.rollout_fp8 else "fp8 W8A16") + (", bf16 kept for " + ",".join(tr.core.roll.fp8_keep_bf16) if tr.core.roll.fp8_keep_bf16 else ""))}
         dec_prof = ops.decode_profile_end() if rank == 0 and wl.core.roll.native_decode else None
         wl.core.roll.native_decode = True
         wl.eng.overlap_wgrad = overlap0
@@ -624,9 +633,12 @@ def main(argv=None):
             qd, kvd = c.n_heads * c.head_dim, c.n_kv_heads * c.head_dim
             nk = {"qkv": (qd + 2 * kvd, c.hidden), "o": (c.hidden, qd), "gate_up": (2 * c.intermediate, c.hidden), "down": (c.hidden, c.intermediate),
                   "lm_head": (c.vocab_size, c.hidden)}
-            wb = 1.0 if (args.rollout_fp8 or args.rollout_fp8_w8a16) else 2.0        # bytes per weight element of the sampling policy
+            fp8_run_ = bool(args.rollout_fp8 or args.rollout_fp8_w8a16)
+            keep_ = set(tr.core.roll.fp8_keep_bf16) if fp8_run_ else set()
+            short_ = {"qkv": "qkv", "o": "o", "gate_up": "gu", "down": "down", "lm_head": "lm_head"}
             for k_, (ms_, mn_, n_) in dec_prof.items():
                 N_, K_ = nk[k_]
+                wb = 1.0 if (fp8_run_ and short_[k_] not in keep_) else 2.0      # bytes per weight element of THIS matrix of the sampling policy
                 by = wb * N_ * K_ + 2.0 * (R_ * K_ + R_ * N_)
                 sk_ms += ms_; sk_by += by * n_; sk_n += n_
                 if n_ and N_ * K_ >= (1 << 26) and mn_ > 0:

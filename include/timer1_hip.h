@@ -228,6 +228,10 @@ int tr1_grpo_loss(const void* logp, const void* ref_logp, const void* mask, cons
  * group_rows > 0: rows [b*group_rows, (b+1)*group_rows) belong to prompt b and draw from the stream (seed + b*seed_stride, row % group_rows, step),
  * so several prompts sampled in one launch get exactly the tokens of one launch per prompt. */
 int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* stream);
+/* The decode loop's form (model.generate's per-token sampling, timer1_trainer.py:568-573): next_ids[row] (optional) receives the drawn token as well - the
+ * buffer the next step's embedding gather reads - and ws_zeroed != 0 promises a workspace zero-filled ONCE and only used through this entry point (the pick
+ * kernel re-zeroes it), so neither a copy kernel nor a memset runs between two decode steps. */
+int tr1_sample_tokens_step(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k, uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld, void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words, void* next_ids, int ws_zeroed, void* stream);
 int64_t tr1_sample_workspace_words(int64_t rows);
 
 /* ---- optimizer -------------------------------------------------------------------------------------------------------- */

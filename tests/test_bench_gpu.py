@@ -61,6 +61,11 @@ def test_self_spawned_two_rank_run(shard):
     assert d["backend"] == "gloo" and d["world"] == 2 and d["ranks_seen"] == [0, 1] and d["ranks_seen_ok"] and len(d["devices"]) == 2
     assert d["optimizer_sharded"] == shard and d["grad_exchange_exposed_ms_per_optimizer_step"] >= 0.0 and d["process_group_timeout_s"] > 0
     assert "rccl_version" in d
+    assert len(d["hbm_gb_allocated_peak_per_rank"]) == 2 and all(m > 0 for m in d["hbm_gb_allocated_peak_per_rank"])       # measured per rank
+    test_self_spawned_two_rank_run.mem = getattr(test_self_spawned_two_rank_run, "mem", {})
+    test_self_spawned_two_rank_run.mem[shard] = max(d["hbm_gb_allocated_peak_per_rank"])
+    if len(test_self_spawned_two_rank_run.mem) == 2:           # master / m / v sharded over 2 ranks: the per-rank peak must not grow
+        assert test_self_spawned_two_rank_run.mem[True] <= test_self_spawned_two_rank_run.mem[False] * 1.02, test_self_spawned_two_rank_run.mem
 
 
 def test_world_size_mismatch_is_an_error():

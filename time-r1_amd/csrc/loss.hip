@@ -158,6 +158,8 @@ TR1_DEV float key_logit(unsigned k) { const unsigned b = (k & 0x8000u) ? (k & 0x
 struct SampleArgs {
     const bf16_t* logits; int64_t ld; int V; float inv_temp; int top_k; unsigned long long seed; int group_rows; unsigned long long seed_stride; const int* step_ptr; int* tokens; int64_t tok_ld;
     int* finished; int eos_id, pad_id, stop_at_eos; float* u_out; unsigned* ws;
+    int* next_ids;      // optional [rows]: the drawn token once more, where the next decode step's embedding gather reads it (no copy kernel in between)
+    int ws_clean;       // the caller zero-filled ws once: the fused pick kernel re-zeroes what the histogram kernels dirtied (no memset per call)
 };
 
 TR1_DEV bool samp_row_done(const SampleArgs& a, int r) { return a.finished && a.stop_at_eos && a.finished[r]; }
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void samp_pick_kernel(SampleArgs a) {
     const int r = blockIdx.x, tid = threadIdx.x;
     const int step = a.step_ptr ? *a.step_ptr : 0;
     int* tok_out = a.tokens + (int64_t)r * a.tok_ld + step;
-    if (samp_row_done(a, r)) { if (tid == 0) *tok_out = a.pad_id; return; }
+    if (samp_row_done(a, r)) { if (tid == 0) { *tok_out = a.pad_id; if (a.next_ids) a.next_ids[r] = a.pad_id; } return; }
     unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
     const float* sums = reinterpret_cast<const float*>(ws + 520);
     if (tid == 0) {
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256) void samp_pick_kernel(SampleArgs a) {
             if (tok < 0) { for (int i = 0; i < a.V; ++i) { if (bfkey(row[i]) >= thr) { tok = i; break; } } }
         }
         *tok_out = tok;
+        if (a.next_ids) a.next_ids[r] = tok;
         if (a.finished && tok == a.eos_id) a.finished[r] = 1;
     }
 }
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(1024) void samp_sum_pick_kernel(SampleArgs a) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int step = a.step_ptr ? *a.step_ptr : 0;
     int* tok_out = a.tokens + (int64_t)r * a.tok_ld + step;
-    if (samp_row_done(a, r)) { if (tid == 0) *tok_out = a.pad_id; return; }
+    if (samp_row_done(a, r)) { if (tid == 0) { *tok_out = a.pad_id; if (a.next_ids) a.next_ids[r] = a.pad_id; } return; }
     unsigned* ws = a.ws + (int64_t)r * SAMP_WS_WORDS;
     __shared__ unsigned shist[512];                 // both histograms staged once: the threshold search of thread 0 then walks LDS, not global memory
     __shared__ unsigned scr[8];
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(1024) void samp_sum_pick_kernel(SampleArgs a) {
     }
     if (lane == 0) wsum[wave] = wtot;
     __syncthreads();
+    if (a.ws_clean && tid < SAMP_WS_WORDS) ws[tid] = 0u;        // every thread has read the histograms and the row max: leave the row's workspace zero for the next call
     if (tid == 0) {
         float Z = 0.f;
         for (int w = 0; w < 16; ++w) Z += wsum[w];
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(1024) void samp_sum_pick_kernel(SampleArgs a) {
         if (tok < 0) { for (int i = 0; i < a.V; ++i) { if (bfkey(row[i]) >= thr) { tok = i; break; } } }
     }
     *tok_out = tok;
+    if (a.next_ids) a.next_ids[r] = tok;
     if (a.finished && tok == a.eos_id) a.finished[r] = 1;
 }
 
@@ -465,10 +470,10 @@ extern "C" int tr1_grpo_loss(const void* logp, const void* ref_logp, const void*
 }
 extern "C" int64_t tr1_sample_workspace_words(int64_t rows) { return rows * SAMP_WS_WORDS; }
 
-extern "C" int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k,
+static int sample_tokens_impl(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k,
                                  uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld,
                                  void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words,
-                                 void* stream) {
+                                 void* next_ids, int ws_zeroed, void* stream) {
     TR1_CHECK_ARG(temperature > 0.f, "sample: temperature must be > 0");
     TR1_CHECK_ARG(ws_u32 && ws_words >= rows * SAMP_WS_WORDS, "sample: workspace too small (tr1_sample_workspace_words)");
     if (rows == 0) return 0;
@@ -477,15 +482,38 @@ extern "C" int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, i
     a.logits = (const bf16_t*)logits; a.ld = ld; a.V = (int)V; a.inv_temp = 1.0f / temperature; a.top_k = (int)top_k; a.seed = seed; a.group_rows = (int)group_rows; a.seed_stride = seed_stride;
     a.step_ptr = (const int*)step_ptr; a.tokens = (int*)tokens; a.tok_ld = tok_ld; a.finished = (int*)finished; a.eos_id = (int)eos_id;
     a.pad_id = (int)pad_id; a.stop_at_eos = stop_at_eos; a.u_out = (float*)u_out; a.ws = (unsigned*)ws_u32;
-    hipMemsetAsync(ws_u32, 0, (size_t)rows * SAMP_WS_WORDS * 4, s);
+    a.next_ids = (int*)next_ids;
+    const bool fused = V % 8 == 0 && ld % 8 == 0 && V <= SAMP_FUSED_MAXV && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+    a.ws_clean = (ws_zeroed && fused) ? 1 : 0;
+    if (!a.ws_clean) hipMemsetAsync(ws_u32, 0, (size_t)rows * SAMP_WS_WORDS * 4, s);
     dim3 grid(SAMP_S, (unsigned)rows);
     hipLaunchKernelGGL(samp_hist_hi_kernel, grid, dim3(256), 0, s, a);     // also yields the row max (needed without top-k too)
     if (top_k > 0 && top_k < V) hipLaunchKernelGGL(samp_hist_lo_kernel, grid, dim3(256), 0, s, a);
-    if (V % 8 == 0 && ld % 8 == 0 && V <= SAMP_FUSED_MAXV && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+    if (fused) {
         hipLaunchKernelGGL(samp_sum_pick_kernel, dim3((unsigned)rows), dim3(1024), 0, s, a);
     } else {
         hipLaunchKernelGGL(samp_slice_sum_kernel, grid, dim3(256), 0, s, a);
         hipLaunchKernelGGL(samp_pick_kernel, dim3((unsigned)rows), dim3(256), 0, s, a);
+        if (ws_zeroed) hipMemsetAsync(ws_u32, 0, (size_t)rows * SAMP_WS_WORDS * 4, s);      // keep the caller's "zero between calls" contract on this path too
     }
     TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_sample_tokens(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k,
+                                 uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld,
+                                 void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words,
+                                 void* stream) {
+    return sample_tokens_impl(logits, ld, rows, V, temperature, top_k, seed, group_rows, seed_stride, step_ptr, tokens, tok_ld, finished, eos_id, pad_id,
+                              stop_at_eos, u_out, ws_u32, ws_words, nullptr, 0, stream);
+}
+
+// The decode loop's form: next_ids[row] (optional) receives the drawn token as well - the buffer the next step's embedding gather reads, so no copy
+// kernel runs between two steps - and ws_zeroed != 0 promises a workspace that was zero-filled ONCE and is only ever used through this entry point:
+// the pick kernel then re-zeroes what the histogram kernels dirtied instead of a memset in front of every call.
+extern "C" int tr1_sample_tokens_step(const void* logits, int64_t ld, int64_t rows, int64_t V, float temperature, int64_t top_k,
+                                      uint64_t seed, int64_t group_rows, uint64_t seed_stride, const void* step_ptr, void* tokens, int64_t tok_ld,
+                                      void* finished, int64_t eos_id, int64_t pad_id, int stop_at_eos, void* u_out, void* ws_u32, int64_t ws_words,
+                                      void* next_ids, int ws_zeroed, void* stream) {
+    return sample_tokens_impl(logits, ld, rows, V, temperature, top_k, seed, group_rows, seed_stride, step_ptr, tokens, tok_ld, finished, eos_id, pad_id,
+                              stop_at_eos, u_out, ws_u32, ws_words, next_ids, ws_zeroed, stream);
 }

@@ -692,11 +692,22 @@ class HipOps:
         return dlogp, out3, row_len, row_kl
 
     def sample_tokens(self, logits, temperature, top_k, seed, step_dev, tokens, finished, eos_id, pad_id, stop_at_eos, u_out=None, group_rows=0,
-                      seed_stride=0):
+                      seed_stride=0, next_ids=None):
+        """next_ids (int32 [rows], optional): also receives the drawn tokens (the next decode step's embedding gather reads it: no copy kernel)."""
         self._chk(logits)
         assert tokens.dtype == I32 and (step_dev is None or step_dev.dtype == I32)
         rows, V = logits.shape
         nws = self.L.raw("tr1_sample_workspace_words")(rows)
+        if next_ids is not None:
+            assert next_ids.dtype == I32 and next_ids.numel() == rows and next_ids.is_contiguous()
+            key = ("sampler_step", rows)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.zeros(nws, dtype=I32, device=self.device)      # zero ONCE: the pick kernel leaves it zero after every call
+            self.L.call("tr1_sample_tokens_step", _p(logits), _ld(logits), rows, V, float(temperature), int(top_k or 0), int(seed) & (2**64 - 1),
+                        int(group_rows), int(seed_stride) & (2**64 - 1), _p(step_dev), _p(tokens), tokens.stride(0), _p(finished), int(eos_id), int(pad_id),
+                        int(bool(stop_at_eos)), _p(u_out), _p(ws), nws, _p(next_ids), 1, self._s())
+            return
         ws = self._workspace("sampler", nws, I32)
         self.L.call("tr1_sample_tokens", _p(logits), _ld(logits), rows, V, float(temperature), int(top_k or 0), int(seed) & (2**64 - 1),
                     int(group_rows), int(seed_stride) & (2**64 - 1), _p(step_dev), _p(tokens), tokens.stride(0), _p(finished), int(eos_id), int(pad_id), int(bool(stop_at_eos)), _p(u_out),

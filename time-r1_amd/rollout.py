@@ -184,12 +184,13 @@ class Rollout:
         host_plan = ops.attn_plan(G, t.n_heads, t.n_kv_heads, B) if (not native and fused and hasattr(ops, "attn_plan")) else None
         for s in range(C - 1):
             if native:
-                ids_buf.copy_(tokens_all[:, s])
+                if s == 0:
+                    ids_buf.copy_(tokens_all[:, 0])          # later steps: the sampler wrote the drawn tokens into ids_buf itself (next_ids)
                 logits = ops.decode_step(plan, embed_p, norm_p, lm_p, ids_p, cos_p + s * R * half * 4, sin_p + s * R * half * 4, slot_p + s * R * 4,
                                          pre_p, lo_p, hi_p + s * R * 4, t.rms_eps, scale)
                 # all prompts of the window in ONE sampler launch set; every prompt keeps its own Philox stream (seed_b = seed_0 + 7919 b)
                 ops.sample_tokens(logits, self.temperature, self.top_k, per[0]["seed"], steps[s + 1:s + 2], tokens_all, finished_all, cfg.eos_token_id,
-                                  cfg.pad_token_id, self.stop_at_eos, group_rows=G, seed_stride=7919)
+                                  cfg.pad_token_id, self.stop_at_eos, group_rows=G, seed_stride=7919, next_ids=ids_buf)
                 if slogp_all is not None:
                     slogp_all[:, s + 1] = ops.logp_entropy_fwd(logits, tokens_all[:, s + 1].contiguous())[0]
                 continue

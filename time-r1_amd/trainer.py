@@ -88,8 +88,10 @@ class GRPOConfig:
     disable_log_print: bool = False         # keep log() from printing on rank 0 (bench.py prints exactly one JSON line)
     log_rollout_drift: Optional[bool] = None   # metric rollout_logp_drift = mean |logp under the SAMPLING policy's logits - policy logp| over the
                                             # completion tokens; None = on whenever the rollout reads quantised weights (or an importance cap is set)
-    rollout_fp8_keep_bf16: tuple = ()   # fp8 sampling policies: matrices that stay bf16 ("qkv", "o", "gu", "down", "lm_head") - the W8A8 lm_head input is the
-    #                                     most drift-sensitive operand (DESIGN section 5, config-5 drift study)
+    rollout_fp8_keep_bf16: Optional[tuple] = None   # fp8 sampling policies: matrices that stay bf16 ("qkv", "o", "gu", "down", "lm_head").  None = AUTO: the fp8-MFMA
+    #                                     policy keeps the attention projections ("qkv", "o": 12 % of the decoder's weight bytes) in bf16 - at 16 decode rows their fp8 kernels
+    #                                     are no faster than the bf16 ones (latency-bound; the fp8 q|k|v path also pays a separate rope / KV-append launch), and the policy
+    #                                     drifts less: 589.5 ms / 0.244 nat against 593.6 ms / 0.303 nat with every matrix in fp8; () = every matrix fp8
     lazy_grad_zero: bool = True      # the optimizer leaves the decoder layers' large gradient matrices un-zeroed (the next window's first weight gradients
     #                                  overwrite them: Engine.lazy_zero_plan); False = zero the whole gradient arena every step
     rollout_importance_cap: Optional[float] = None   # c: advantage term weighted by min(exp(policy logp - sampling logp), c) per token (truncated
@@ -194,6 +196,7 @@ class _PhaseClock:
         return out
 
 
+FP8_MFMA_KEEP_BF16 = ("qkv", "o")      # default of GRPOConfig.rollout_fp8_keep_bf16 for the fp8-MFMA sampling policy
 FP8_IMPORTANCE_CAP = 2.0      # default truncation c of the per-token importance weight for quantised sampling policies (GRPOConfig.rollout_importance_cap)
 
 
@@ -347,7 +350,10 @@ class TimeR1_Trainer:
                              use_grpo=self.use_grpo, temperature=args.temperature, top_k=args.top_k, seed=args.seed + 1000 * self.dp.rank,
                              rope_index_mode=args.rope_index_mode, stop_at_eos=args.stop_at_eos)
         self.core.roll.weight_dtype = getattr(args, "rollout_weight_dtype", "bf16")
-        self.core.roll.fp8_keep_bf16 = tuple(getattr(args, "rollout_fp8_keep_bf16", ()) or ())
+        keep = getattr(args, "rollout_fp8_keep_bf16", None)
+        if keep is None:
+            keep = FP8_MFMA_KEEP_BF16 if self.core.roll.weight_dtype == "fp8-mfma" else ()
+        self.core.roll.fp8_keep_bf16 = tuple(keep)
         drift = getattr(args, "log_rollout_drift", None)
         cap = getattr(args, "rollout_importance_cap", None)
         if cap is None and self.core.roll.weight_dtype != "bf16":
