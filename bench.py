@@ -165,7 +165,10 @@ class Workload:
         if last and self.opt.dp.enabled and not a.no_grad_overlap:
             sync = self.opt.sync
             sync.begin()                # last micro-step of the window: overlap the RCCL gradient exchange with its backward
+        if last:
+            self.eng.norm_sink = self.opt.norm_sink_begin(self.eng)
         core.loss_backward(st, self.ops.tensor(mask, torch.int32), self.ops.tensor(adv.numpy(), torch.float32), 1.0 / a.ga, grad_sync=sync)
+        self.eng.norm_sink = None
 
     def engine_window(self, n=None):
         a, core, v, tr = self.args, self.core, self.cfg.vision, self.trainer

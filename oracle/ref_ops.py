@@ -485,6 +485,11 @@ class RefOps:
                 finished[r] = 1
 
     # ---- optimizer (ref: torch.optim.AdamW semantics = DeepSpeed FusedAdam adam_w_mode; clip = clip_grad_norm_)
+    def sumsq_ranges_periodic(self, g, base, stride, count, rel_ranges, out_scalar):
+        for l in range(count):
+            for a, b in rel_ranges:
+                out_scalar += (g[base + l * stride + a: base + l * stride + b].double() ** 2).sum().float()
+
     def zero_ranges_periodic(self, g, base, stride, count, rel_ranges):
         for l in range(count):
             for a, b in rel_ranges:

@@ -239,3 +239,35 @@ def test_rollout_logp_drift_bound_at_7b_width(hip_ops, wdtype):
         assert 1e-3 < d < 0.40, d
     del tr, params
     torch.cuda.empty_cache()
+
+
+def test_grad_norm_from_weight_gradient_epilogues(hip_ops):
+    """The last micro-step's weight-gradient GEMMs leave the squared norm of the FINAL gradient of the decoder layers' large matrices (tr1_wgrad_f32_sumsq);
+    AdamWFlat.step adds the rest of the arena.  Same norm as a full pass over the gradient arena, same gradients as the plain GEMM path."""
+    from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig
+    from time_r1_amd import rewards as R
+    from time_r1_amd.config import tiny_test, TextConfig
+    from time_r1_amd.params import ModelParams
+    from oracle.text import FakeProcessor
+    cfg = tiny_test()
+    cfg.text = TextConfig(vocab_size=512, hidden=512, intermediate=1024, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, mrope_section=(16, 24, 24))
+    cfg.vision.out_hidden = 512
+    norms, grads = [], []
+    for use_sink in (True, False):
+        args = GRPOConfig(output_dir="/tmp/tr1_gpu_sink", num_generations=4, max_completion_length=8, beta=0.04, use_grpo=True, temperature=1.0,
+                          save_strategy="no", disable_log_print=True, gradient_accumulation_steps=2, lazy_grad_zero=use_sink)
+        tr = TimeR1_Trainer(ModelParams(cfg, hip_ops, seed=1), [R.format_reward], [], args=args, processing_class=FakeProcessor(cfg), ops=hip_ops)
+        rows = []
+        for i in range(2):
+            frames = torch.randint(0, 256, (4, 3, 84, 112), generator=torch.Generator().manual_seed(3 + i), dtype=torch.uint8)
+            rows.append([{"problem": "event %d" % i, "video_path": "x.mp4", "video_frames": frames, "solution": (2.0, 12.0), "durations": 30.0}])
+        tr.accumulation_window(rows)
+        g = tr.params.train.grad.clone()
+        want = float(g.double().norm())
+        gn = float(tr.optimizer.step())
+        assert tr.optimizer.norm_from_sink == use_sink, "lazy_grad_zero=False has no periodic layout plan: the full pass runs"
+        assert abs(gn - want) < 2e-4 * want, (gn, want)
+        norms.append(gn); grads.append({n: tr.params.train.view(g, n).clone() for n in ("l0.qkv.w", "l0.o.w", "l1.gu.w", "l1.down.w")})
+    # (the norm / embedding gradients use fp32 atomics and are not bit-reproducible between two runs; the GEMM outputs are)
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), "the sum-of-squares epilogue must not change the gradient: " + n

@@ -229,9 +229,10 @@ TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, co
 template <bool OUT_F32, bool ACCUM, int RT, int EPI = 0>
 TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wave_lds, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
                               const bf16_t* __restrict__ residual, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int64_t mrow0, int64_t ncol0,
-                              int lane) {
+                              int lane, float* __restrict__ sumsq_slot = nullptr) {
     constexpr int CH = (RT % 2 == 0) ? 4 : 3;                             // 16-row tiles per pass: 8 waves x CH x 4 KiB fit the operand buffers
     const int u = lane & 15, g = lane >> 4;
+    float ssq = 0.f;                                                      // fp32 output only: sum of squares of what this wave stores (gradient norm)
 #pragma unroll
     for (int i0 = 0; i0 < RT; i0 += CH) {
         const int cnt = RT - i0 < CH ? RT - i0 : CH;
@@ -262,6 +263,7 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                         float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
                         if (ACCUM) v += *reinterpret_cast<const f32x4_t*>(cp);
                         *reinterpret_cast<f32x4_t*>(cp) = v;
+                        ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     }
                 }
             }
@@ -325,6 +327,11 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the next pass overwrites the slice
+    }
+    if (OUT_F32 && sumsq_slot) {      // the FINAL value of every gradient element passes through this epilogue in the window's last micro-step: its
+#pragma unroll                        // squared norm costs a few FMAs here instead of a 30 GB read of the arena (sumsq_kernel) before AdamW
+        for (int o = 32; o >= 1; o >>= 1) ssq += __shfl_xor(ssq, o, 64);
+        if (lane == 0) *sumsq_slot = ssq;
     }
 }
 
@@ -854,7 +861,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
         store_acc256_glubwd<RT>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, M, N, ldc, m0 + wm * (RT * 16), n0 + wn * 64, lane, ep);
     else
     store_acc256_lds<OUT_F32, ACCUM, RT, EPI>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, residual, M, N, ldc, ldr,
-                                              m0 + wm * (RT * 16), n0 + wn * 64, lane);
+                                              m0 + wm * (RT * 16), n0 + wn * 64, lane,
+                                              (OUT_F32 && EPI == 0 && ep.p0) ? reinterpret_cast<float*>(ep.p0) + (int64_t)blockIdx.x * 8 + wave : nullptr);
 #else
     store_acc256<OUT_F32, ACCUM, RT>(acc, Cv, bias, residual, M, N, ldc, ldr, m0 + wm * (RT * 16), n0 + wn * 64, u, g);
 #endif
@@ -2083,6 +2091,54 @@ extern "C" int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C, int64_
     if (rt == 7) LAUNCHNAR(7); else if (rt == 9) LAUNCHNAR(9); else if (rt == 10) LAUNCHNAR(10); else LAUNCHNAR(8);
 #undef LAUNCHNAR
 #undef LAUNCHNA
+    TR1_LAUNCH_CHECK();
+}
+
+static int epi_pick_rt(int64_t M, int64_t Ntiles);
+// Weight gradient C[M, N] fp32 (+)= A B^T (b_kmajor = 0: B = X^T [N, K]) or A B (b_kmajor = 1: B = X as stored [K, N], its first b_rows rows valid), on the
+// phased 8-wave kernel, which ALSO leaves the sum of squares of every value it stored in sumsq_partials (one float per wave: 8 x blocks; *n_partials receives
+// the count) - in the last micro-step of an accumulation window that is the squared norm of the final gradient, so the optimizer's grad-norm pass does not
+// have to read these matrices again.  Same kernel, k order and (for shapes the NT dispatch gives to the 8-wave tiles) tile choice as tr1_gemm_nt_bf16(out_f32) / tr1_gemm_nn_acc_f32: bit-identical C.
+extern "C" int tr1_wgrad_f32_sumsq(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate,
+                                   int b_kmajor, int64_t b_rows, void* sumsq_partials, int64_t partials_capacity, int64_t* n_partials, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "wgrad_f32_sumsq: K%64, N%8, lda%8, ldb%8, ldc%4 required");
+    TR1_CHECK_ARG(M >= 512 && N >= 256, "wgrad_f32_sumsq: M >= 512 and N >= 256 required (smaller gradients: plain GEMM + tr1_sumsq_accum)");
+    TR1_CHECK_ARG(!b_kmajor || (b_rows >= 1 && b_rows <= K), "wgrad_f32_sumsq: 1 <= b_rows <= K");
+    TR1_CHECK_ARG(sumsq_partials && n_partials, "wgrad_f32_sumsq: partials buffer required");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t2n = (N + BN2 - 1) / BN2;
+    int rt;
+    if (b_kmajor) rt = epi_pick_rt(M, t2n);
+    else {      // the NT dispatch's own choice among the 8-wave tiles (tr1_gemm_nt_bf16), so C is bit-identical to that path
+        auto cost = [&](int64_t bm, double eff) { const int64_t t = ((M + bm - 1) / bm) * t2n; return (double)((t + 255) / 256) * 256.0 * (double)(bm * BN2) / eff; };
+        static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
+        rt = 7; double best = cost(224, eff[0]);
+        for (int r = 8; r <= 10; ++r) { const double c = cost(r * 32, eff[r - 7]); if (c < best) { best = c; rt = r; } }
+    }
+    const int bmx = rt * 32;
+    const int64_t t2m = (M + bmx - 1) / bmx, blocks = t2m * t2n;
+    TR1_CHECK_ARG(blocks * 8 <= partials_capacity, "wgrad_f32_sumsq: partials buffer too small (8 floats per 256-column tile block)");
+    const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+    {
+        static bool set_ = false;
+        if (!set_) {
+            const int mx = (int)(2 * (320 * BK * 2 + TILE2_BYTES)) + 4096;
+#define SETW(AC, R, KM) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt8p_kernel<true, AC, R, KM>), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+#define SETWR(R) do { SETW(false, R, false); SETW(true, R, false); SETW(false, R, true); SETW(true, R, true); } while (0)
+            SETWR(7); SETWR(8); SETWR(9); SETWR(10);
+#undef SETWR
+#undef SETW
+            set_ = true;
+        }
+    }
+    GemmEpi ep{}; ep.p0 = sumsq_partials;
+#define LW(AC, R, KM) hipLaunchKernelGGL((gemm_nt8p_kernel<true, AC, R, KM>), dim3((unsigned)blocks), dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, \
+                                         (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, (int64_t)(KM ? b_rows : 0), (int)t2m, (int)t2n, ep)
+#define LWR(R) do { if (b_kmajor) { if (accumulate) LW(true, R, true); else LW(false, R, true); } else { if (accumulate) LW(true, R, false); else LW(false, R, false); } } while (0)
+    if (rt == 7) LWR(7); else if (rt == 9) LWR(9); else if (rt == 10) LWR(10); else LWR(8);
+#undef LWR
+#undef LW
+    *n_partials = blocks * 8;
     TR1_LAUNCH_CHECK();
 }
 

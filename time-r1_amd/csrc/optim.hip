@@ -152,3 +152,45 @@ extern "C" int tr1_zero_ranges_periodic(void* g_f32, int64_t base, int64_t strid
     hipLaunchKernelGGL(zero_periodic_kernel, dim3(gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, (float*)g_f32, base, stride, zr);
     TR1_LAUNCH_CHECK();
 }
+
+// out += sum of partials[0 .. n) in a FIXED order (one block: thread t adds partials[t], partials[t + 1024], ...; then the block tree) - the per-wave sums of
+// squares the weight-gradient epilogues left (tr1_wgrad_f32_sumsq)
+__global__ __launch_bounds__(1024) void sumsq_partials_kernel(const float* __restrict__ part, int64_t n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+extern "C" int tr1_sumsq_partials_accum(const void* partials_f32, int64_t n, void* out_scalar, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)partials_f32, n, (float*)out_scalar);
+    TR1_LAUNCH_CHECK();
+}
+
+// out += sum of g[base + l * stride + r]^2 over l < count and r in the (<= 8) half-open ranges: the SMALL per-layer gradient tensors next to the large matrices
+// whose squared norm came out of the weight-gradient epilogues
+__global__ __launch_bounds__(256) void sumsq_periodic_kernel(const float* __restrict__ g, int64_t base, int64_t stride, ZeroRanges zr, float* __restrict__ out) {
+    __shared__ float red[16];
+    const float* gl = g + base + (int64_t)blockIdx.y * stride;
+    float s = 0.f;
+    for (int r = 0; r < zr.n; ++r)
+        for (int64_t i = zr.a[r] + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < zr.b[r]; i += (int64_t)gridDim.x * blockDim.x) { const float v = gl[i]; s += v * v; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+extern "C" int tr1_sumsq_ranges_periodic(const void* g_f32, int64_t base, int64_t stride, int64_t count, const int64_t* rel_ranges, int64_t n_ranges, void* out_scalar,
+                                         void* stream) {
+    TR1_CHECK_ARG(n_ranges >= 0 && n_ranges <= 8 && (n_ranges == 0 || rel_ranges) && out_scalar, "sumsq_ranges_periodic: at most 8 ranges");
+    if (count <= 0 || n_ranges == 0) return 0;
+    ZeroRanges zr; zr.n = (int)n_ranges;
+    int64_t longest = 1;
+    for (int i = 0; i < zr.n; ++i) {
+        zr.a[i] = rel_ranges[2 * i]; zr.b[i] = rel_ranges[2 * i + 1];
+        TR1_CHECK_ARG(zr.a[i] >= 0 && zr.b[i] >= zr.a[i] && zr.b[i] <= stride, "sumsq_ranges_periodic: range outside the period");
+        if (zr.b[i] - zr.a[i] > longest) longest = zr.b[i] - zr.a[i];
+    }
+    const unsigned gx = (unsigned)((longest + 255) / 256 < 64 ? (longest + 255) / 256 : 64);
+    hipLaunchKernelGGL(sumsq_periodic_kernel, dim3(gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, (const float*)g_f32, base, stride, zr, (float*)out_scalar);
+    TR1_LAUNCH_CHECK();
+}

@@ -37,6 +37,9 @@ class Engine:
         self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
         self.wgrad_tn = os.environ.get("TR1_WGRAD_TN", "0") == "1"      # ... and dy as stored too (round 3, csrc/gemm_tn.hip): measured, NOT adopted
         self._side = None
+        # set (by the owner of the optimizer) for the backward of a window's LAST micro-step: the weight-gradient epilogues of the decoder layers' large
+        # matrices then also leave the squared norm of the final gradient (AdamWFlat.norm_sink_begin / step)
+        self.norm_sink = None
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
@@ -61,6 +64,15 @@ class Engine:
             return
         # bias_g: the Linear's bias gradient (column sums of dy) rides on the pass that builds dy^T
         dyt = ops.transpose(dy, colsum=bias_g) if bias_g is not None else ops.transpose(dy)          # [N, Mp], zero-padded columns
+        sink = self.norm_sink
+        if sink is not None and key is not None and key.split(".", 1)[-1] in self.OVERWRITTEN and hasattr(ops, "wgrad_sumsq"):
+            # last micro-step of the window: same GEMM, and its epilogue also leaves the sum of squares of the FINAL gradient values it stores
+            kmaj = self.wgrad_nn and x.shape[1] >= 2 * dy.shape[1]
+            n = ops.wgrad_sumsq(dyt, x if kmaj else ops.transpose(x), gw, acc, sink["partials"], sink["n"], b_kmajor=kmaj, b_rows=x.shape[0])
+            if n >= 0:
+                sink["n"] += n
+                sink["covered"].add(key)
+                return
         # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out).
         # Its transposing LDS reads cost 8-17 % of the GEMM rate (tools/bench_wgrad.py: 1060 against 1244 TFLOP/s at the down-projection
         # shape), so it only pays where the saved transpose is the larger piece: x at least twice as wide as dy (the down projection,

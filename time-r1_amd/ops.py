@@ -718,6 +718,32 @@ class HipOps:
         assert g.dtype in (F32, BF16) and out_scalar.dtype == F32
         self.L.call("tr1_sumsq_accum" if g.dtype == F32 else "tr1_sumsq_accum_bf16", _p(g), g.numel(), _p(out_scalar), self._s())
 
+    def wgrad_sumsq(self, a, b, gw, accumulate, partials, offset, b_kmajor=False, b_rows=0):
+        """gw[N, K] fp32 (+)= a[N, Mp] @ b^T (b = X^T [K, Mp]) or a @ b (b_kmajor: b = X [>= b_rows, K] as stored), and partials[offset : offset + n] receives
+        the per-wave sums of squares of the values stored (n returned; -1 when the shape is not covered and nothing was launched)."""
+        import ctypes
+        N, Mp = a.shape
+        K = b.shape[1] if b_kmajor else b.shape[0]
+        if not (self.FUSE_EPI and N >= 512 and K >= 256 and K % 8 == 0 and Mp % 64 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and _ld(a) % 8 == 0 and _ld(b) % 8 == 0):
+            return -1
+        self._chk(a, b)
+        assert gw.dtype == F32 and gw.shape == (N, K) and partials.dtype == F32 and partials.is_contiguous()
+        n = ctypes.c_int64(0)
+        self.L.call("tr1_wgrad_f32_sumsq", _p(a), _p(b), _p(gw), N, K, Mp, _ld(a), _ld(b), _ld(gw), int(accumulate), int(b_kmajor), int(b_rows),
+                    partials.data_ptr() + 4 * int(offset), partials.numel() - int(offset), ctypes.byref(n), self._s())
+        return int(n.value)
+
+    def sumsq_partials_accum(self, partials, n, out_scalar):
+        assert partials.dtype == F32 and out_scalar.dtype == F32
+        self.L.call("tr1_sumsq_partials_accum", _p(partials), int(n), _p(out_scalar), self._s())
+
+    def sumsq_ranges_periodic(self, g, base, stride, count, rel_ranges, out_scalar):
+        import ctypes
+        assert g.dtype == F32 and g.is_contiguous() and base + stride * count <= g.numel() and len(rel_ranges) <= 8
+        flat = [int(x) for ab in rel_ranges for x in ab]
+        arr = (ctypes.c_int64 * max(1, len(flat)))(*flat)
+        self.L.call("tr1_sumsq_ranges_periodic", _p(g), int(base), int(stride), int(count), arr, len(rel_ranges), _p(out_scalar), self._s())
+
     def zero_ranges_periodic(self, g, base, stride, count, rel_ranges):
         """g[base + l*stride + r] = 0 for l < count and r in the half-open `rel_ranges` [(a, b), ...] (<= 8) of one period."""
         import ctypes

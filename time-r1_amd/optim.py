@@ -31,6 +31,37 @@ class AdamWFlat:
         # not zero them (set by the owner of the engine; None = zero the whole gradient arena as DeepSpeed's engine.step / optimizer.zero_grad do)
         self.lazy_zero = None
 
+    def norm_sink_begin(self, engine):
+        """Call before the backward of a window's LAST micro-step (single process): returns the sink to hang on `engine.norm_sink` for that backward, or
+        None.  The weight-gradient epilogues of the decoder layers' large matrices then leave the squared norm of the final gradient values, and step()
+        reads only the rest of the arena (embedding, norms, biases, lm_head, merger) for the global norm: 30 GB less to stream per step at 7B."""
+        self._sink = None
+        lz = self.lazy_zero
+        if self.dp.enabled or not lz or engine is None:
+            return None
+        if getattr(self, "_partials", None) is None:
+            self._partials = torch.empty(1 << 21, dtype=torch.float32, device=self.params.train.grad.device)
+        self._sink = dict(partials=self._partials, n=0, covered=set(),
+                          want={"l%d.%s" % (i, nm) for i in range(lz["count"]) for nm in type(engine).OVERWRITTEN}, gver=getattr(self.params.train, "version", 0))
+        return self._sink
+
+    def _norm_from_sink(self):
+        """True when the global squared norm could be assembled from the sink + the uncovered parts of the arena (self._sumsq then holds it)."""
+        sink, a, lz = getattr(self, "_sink", None), self.params.train, self.lazy_zero
+        self._sink = None
+        if not sink or not lz or sink["covered"] != sink["want"] or sink["gver"] != getattr(a, "version", 0):
+            return False
+        ops = self.ops
+        lo, hi = lz["base"], lz["base"] + lz["stride"] * lz["count"]
+        ops.sumsq_partials_accum(sink["partials"], sink["n"], self._sumsq)
+        for x, y in ((0, lo), (hi, a.numel)):
+            if y > x:
+                ops.sumsq_accum(a.grad[x:y], self._sumsq)
+        _, small = self._zero_spans(a.numel)
+        if small:
+            ops.sumsq_ranges_periodic(a.grad, lz["base"], lz["stride"], lz["count"], small, self._sumsq)
+        return True
+
     def _zero_spans(self, n):
         """[(a, b, zero_flag)] covering [0, n) for the fused AdamW launches + the periodic clean-up of the small per-layer tensors."""
         lz = self.lazy_zero
@@ -61,7 +92,9 @@ class AdamWFlat:
         self.sync.finish(copy_back=g16 is None)
         mult = 1.0 / self.dp.world
         self._sumsq.zero_()
-        self.ops.sumsq_accum(a.grad if g16 is None else g16, self._sumsq)
+        self.norm_from_sink = g16 is None and self._norm_from_sink()      # (diagnostic: did the weight-gradient epilogues supply the large matrices' norm?)
+        if not self.norm_from_sink:
+            self.ops.sumsq_accum(a.grad if g16 is None else g16, self._sumsq)
         self.step_count += 1
         a.version = getattr(a, "version", 0) + 1
         spans, small = self._zero_spans(a.numel)

@@ -538,7 +538,12 @@ class TimeR1_Trainer:
             drift_t = (d.abs() * maskf).sum() / maskf.sum().clamp(min=1)
             if self._is_cap is not None:
                 tokw = torch.exp(d).clamp(max=float(self._is_cap))
-        out3, row_len = self.core.loss_backward(st, mask_dev, adv_dev, scale, grad_sync=sync, **({"tok_weight": tokw} if tokw is not None else {}))
+        if last_in_window:      # the final gradient passes through this backward's weight-gradient epilogues: they leave its squared norm (AdamWFlat.step)
+            self.engine.norm_sink = self.optimizer.norm_sink_begin(self.engine)
+        try:
+            out3, row_len = self.core.loss_backward(st, mask_dev, adv_dev, scale, grad_sync=sync, **({"tok_weight": tokw} if tokw is not None else {}))
+        finally:
+            self.engine.norm_sink = None
         self._clock.mark("backward")
         out3f = out3.float()
         z = torch.zeros(3, dtype=torch.float32, device=out3f.device)
