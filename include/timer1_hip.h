@@ -35,10 +35,12 @@ int tr1_probe_hbm_read(const void* buf, int64_t bytes, void* sink_u32, void* str
  * K % 64 == 0 (pad), N % 8 == 0.  out_f32: C is fp32; accumulate (fp32 only): C += result (weight-gradient accumulation).
  * M <= 16 dispatches the HBM-streaming skinny kernel used by rollout decode. */
 int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int accumulate, void* stream);
-/* The same product for thin outputs over a long K (M * N < ~128 tiles of 256 x 256, e.g. the continuation forward's down projection 1600 x 3584 x 18944):
- * both halves of the K reduction run as blocks of ONE launch into fp32 planes of ws_f32 (2 * M * N floats) and a second launch adds them in a fixed
- * order (+bias, +residual) - deterministic 2-way split-K.  K % 128 == 0; bf16 output. */
-int tr1_gemm_nt_splitk2_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream);
+/* The same product (b_kmajor = 0: B = [N, K]; 1: B = [K, N] as stored, e.g. the weight itself in a dgrad) for THIN outputs over a long K - the continuation
+ * forward's down / o projections (1600 x 3584 x 18944 / 3584), the lm_head's data gradient (1600 x 3584 over K = 152064): the K tiles are dealt to S <= 8 shares
+ * that run as blocks of ONE launch into fp32 planes of ws_f32 (>= 2*M*N floats; 8*M*N lets the cost model pick any S), a second launch adds the planes in a
+ * fixed order (+bias, +residual): deterministic split-K.  K % 64 == 0; bf16 output. */
+int tr1_gemm_splitk_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int b_kmajor, void* ws_f32, int64_t ws_floats, void* stream);
+int64_t tr1_gemm_splitk_max_splits(void);
 /* C[M,N] = A[M,K] * B[K,N], B K-major ("NN").  The dgrad of a Linear (dX = dY * W; reference: autograd of F.linear under accelerator.backward,
  * TF trainer.py:1952-1961) reads the weight as stored instead of a transposed copy.  Needs M >= 512, N >= 256, K % 64 == 0; bf16 in / out. */
 int tr1_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, void* stream);

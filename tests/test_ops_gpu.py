@@ -179,9 +179,9 @@ def test_gather_scatter_embed(hip_ops, ref_ops):
     close(dt_h, dt_r, 1e-5, rtol=1e-5, what="embed bwd")
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 8192), (1600, 3584, 18944), (70, 200, 8320)])
-def test_gemm_nt_two_way_split_k(hip_ops, ref_ops, M, N, K):
-    """Thin outputs over a long K (the continuation forward's down projection) run a deterministic 2-way split-K: both halves in one launch into fp32
+@pytest.mark.parametrize("M,N,K", [(300, 512, 8192), (1600, 3584, 18944), (70, 200, 8320), (1600, 3584, 3584), (200, 264, 2112)])
+def test_gemm_nt_split_k(hip_ops, ref_ops, M, N, K):
+    """Thin outputs over a long K (the continuation forward's down / o projections) run a deterministic S-way split-K: all shares in one launch into fp32
     planes, summed in a fixed order with bias and residual.  Same result as the single-pass kernel up to the fp32 summation order; repeatable bit for bit."""
     a, b, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
     assert hip_ops.SPLITK
@@ -197,6 +197,17 @@ def test_gemm_nt_two_way_split_k(hip_ops, ref_ops, M, N, K):
     atol = 0.01 * math.sqrt(K) * 0.05 + 0.03
     close(y, r, atol, what="split-K vs oracle")
     close(y, y0.float().cpu(), atol, what="split-K vs single pass")
+
+
+@pytest.mark.parametrize("M,K,N", [(1600, 152064 // 8, 3584), (300, 4096, 512), (129, 2112, 264)])
+def test_gemm_nn_split_k_weight_as_stored(hip_ops, ref_ops, M, K, N):
+    """dX = dY W with the weight as stored [K, N] and few output tiles (the lm_head's data gradient: K = vocabulary): split-K over the K-major form,
+    no transposed weight copy."""
+    a, w = rnd(M, K, seed=1, scale=0.1), rnd(K, N, seed=2, scale=0.1)
+    assert hip_ops._splitk_ok(M, N, K)
+    y = hip_ops.gemm_nn(a.cuda(), w.cuda())
+    assert torch.equal(y, hip_ops.gemm_nn(a.cuda(), w.cuda())), "split-K must be deterministic"
+    close(y, a.float() @ w.float(), 0.01 * math.sqrt(K) * 0.01 + 0.03, rtol=3e-2, what="NN split-K vs fp32")
 
 
 # ------------------------------------------------------------------------------------------- fused-epilogue training GEMMs

@@ -722,11 +722,14 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
     int wgid;
     {
         int b = blockIdx.x;
-        if (EPI == 6) {                                  // 2-way split-K: the grid holds every tile twice; copy kz reduces k in [kz*K/2, (kz+1)*K/2)
-            const int kz = b >= nwg ? 1 : 0;             // into its own fp32 plane of C (summed by splitk_reduce_kernel in a fixed order)
+        if (EPI == 6) {                                  // S-way split-K (S = ep.i0): the grid holds every tile S times; copy kz reduces its share of the
+            const int kz = b / nwg;                      // K tiles into its own fp32 plane of C (summed by splitk_reduce_kernel in a fixed order)
             b -= kz * nwg;
-            K >>= 1;
-            A += (int64_t)kz * K; B += (int64_t)kz * K;
+            const int nk_all = (int)(K / BK), q = nk_all / ep.i0, r = nk_all - q * ep.i0;
+            const int64_t k0 = (int64_t)(kz * q + (kz < r ? kz : r)) * BK;
+            K = (int64_t)(q + (kz < r ? 1 : 0)) * BK;
+            A += k0;
+            B += BKM ? k0 * ldb : k0;
             Cv = reinterpret_cast<float*>(Cv) + (int64_t)kz * ep.ld0;
         }
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
@@ -2277,17 +2280,22 @@ extern "C" int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const voi
     TR1_LAUNCH_CHECK();
 }
 
-// C[M, N] (bf16) = A B^T (+bias)(+residual) with a deterministic 2-way split over K: for thin outputs over a long K (the continuation forward's down
-// projection: 1600 x 3584 x 18944 = 98 tiles of 256 x 256 on 256 CUs, 838 TFLOP/s) both halves of the reduction run as separate blocks of ONE launch
-// into fp32 planes, and a second launch adds the two planes in a fixed order.  ws_f32: 2 * M * N floats.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ p0, const float* __restrict__ p1, const bf16_t* __restrict__ bias,
+// C[M, N] (bf16) = A B^T or A B (+bias)(+residual) with a deterministic S-way split over K: thin outputs over a long K leave most CUs idle in the plain
+// forms - the continuation forward's down projection (1600 x 3584 x 18944: 98 tiles of 256 x 256 for 256 CUs, 838 TFLOP/s), its o projection, and the
+// lm_head's data gradient (1600 x 3584 over K = 152064, which used to pay a 2.2 GB transpose of the lm_head weight in front of a 128 x 128-tile GEMM).
+// All S shares of the reduction run as blocks of ONE launch into fp32 planes of ws_f32, a second launch adds the planes in a fixed order.  (RT, S) by the
+// cost model below: rounds of 256 blocks x tile rows x k tiles per share.  b_kmajor: B = [K, N] as stored (the weight itself in a dgrad).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ planes, int S, int64_t plane, const bf16_t* __restrict__ bias,
                                                             const bf16_t* __restrict__ residual, int64_t ldr, bf16_t* __restrict__ C, int64_t ldc, int64_t M, int64_t N) {
     const int64_t nch = N >> 3, total = M * nch;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / nch, n = (i - m * nch) * 8;
-        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(p0 + m * N + n), a1 = *reinterpret_cast<const f32x4_t*>(p0 + m * N + n + 4);
-        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p1 + m * N + n), b1 = *reinterpret_cast<const f32x4_t*>(p1 + m * N + n + 4);
-        float v[8] = {a0[0] + b0[0], a0[1] + b0[1], a0[2] + b0[2], a0[3] + b0[3], a1[0] + b1[0], a1[1] + b1[1], a1[2] + b1[2], a1[3] + b1[3]};
+        const float* p = planes + m * N + n;
+        f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(p), a1 = *reinterpret_cast<const f32x4_t*>(p + 4);
+        for (int z = 1; z < S; ++z) {
+            a0 += *reinterpret_cast<const f32x4_t*>(p + z * plane); a1 += *reinterpret_cast<const f32x4_t*>(p + z * plane + 4);
+        }
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         if (bias) {
             const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(bias + n);
 #pragma unroll
@@ -2304,24 +2312,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         *reinterpret_cast<u32x4_t*>(C + m * ldc + n) = o;
     }
 }
-extern "C" int tr1_gemm_nt_splitk2_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
-                                        int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* ws_f32, int64_t ws_floats, void* stream) {
-    TR1_CHECK_ARG(K % (2 * BK) == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_nt_splitk2: K%128, N%8, ld%8 required");
-    TR1_CHECK_ARG(ws_f32 && ws_floats >= 2 * M * N, "gemm_nt_splitk2: workspace of 2*M*N floats required");
+// (RT, S) for a split-K launch: minimise rounds(256 blocks) x tile rows x k tiles per share / efficiency, plus the partial planes' traffic
+static void splitk_pick(int64_t M, int64_t N, int64_t K, int max_s, int* rt_out, int* s_out) {
+    static const double eff[4] = {0.94, 1.0, 1.025, 1.03};
+    const int64_t t2n = (N + BN2 - 1) / BN2, nk = K / BK;
+    double best = 1e300; int brt = 8, bs = 1;
+    for (int r = 7; r <= 10; ++r)
+        for (int S = 1; S <= max_s && S <= nk; ++S) {
+            const int64_t tiles = ((M + r * 32 - 1) / (r * 32)) * t2n, blocks = tiles * S;
+            const double rounds = (double)((blocks + 255) / 256), kshare = (double)((nk + S - 1) / S);
+            // block time ~ rows x k tiles; a plane costs one fp32 write + read of M x N per share, priced against the GEMM's per-CU rate (~25 k-tile rows per 4 KB)
+            const double c = rounds * (r * 32) * kshare / eff[r - 7] + (S > 1 ? 0.02 * S * (double)(M * N) / 256.0 / 64.0 : 0.0);
+            if (c < best) { best = c; brt = r; bs = S; }
+        }
+    *rt_out = brt; *s_out = bs;
+}
+extern "C" int64_t tr1_gemm_splitk_max_splits(void) { return 8; }
+extern "C" int tr1_gemm_splitk_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
+                                    int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int b_kmajor, void* ws_f32, int64_t ws_floats, void* stream) {
+    TR1_CHECK_ARG(K % BK == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_splitk: K%64, N%8, ld%8 required");
+    TR1_CHECK_ARG(ws_f32 && ws_floats >= 2 * M * N, "gemm_splitk: workspace of at least 2*M*N floats required (8*M*N for every split count)");
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    int rt, S;
+    const int64_t max_s = ws_floats / (M * N);
+    splitk_pick(M, N, K, (int)(max_s < 8 ? max_s : 8), &rt, &S);
+    if (S < 2) S = 2;        // (the caller asked for the split form: thin outputs; S = 1 would be the plain GEMM)
     const int64_t t2n = (N + BN2 - 1) / BN2;
-    const int rt = epi_pick_rt(M, 2 * t2n);
     const int bmx = rt * 32;
     const int64_t t2m = (M + bmx - 1) / bmx;
     const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
+    GemmEpi ep{}; ep.ld0 = M * N; ep.i0 = S;
 #define KA_SK(R) true, false, R, false, 6
-    EPI_SETATTR(KA_SK);
-    GemmEpi ep{}; ep.ld0 = M * N;
-    EPI_LAUNCH(KA_SK, rt, dim3((unsigned)(2 * t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, ws_f32, (const bf16_t*)nullptr,
-               (const bf16_t*)nullptr, M, N, K, lda, ldb, N, (int64_t)0, (int)t2m, (int)t2n, ep);
+#define KA_SKM(R) true, false, R, true, 6
+    if (b_kmajor) {
+        EPI_SETATTR(KA_SKM);
+        EPI_LAUNCH(KA_SKM, rt, dim3((unsigned)(S * t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, ws_f32, (const bf16_t*)nullptr,
+                   (const bf16_t*)nullptr, M, N, K, lda, ldb, N, (int64_t)0, (int)t2m, (int)t2n, ep);
+    } else {
+        EPI_SETATTR(KA_SK);
+        EPI_LAUNCH(KA_SK, rt, dim3((unsigned)(S * t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, ws_f32, (const bf16_t*)nullptr,
+                   (const bf16_t*)nullptr, M, N, K, lda, ldb, N, (int64_t)0, (int)t2m, (int)t2n, ep);
+    }
 #undef KA_SK
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tr1_grid_1d(M * N / 8, 256, 2048)), dim3(256), 0, s, (const float*)ws_f32, (const float*)ws_f32 + M * N,
+#undef KA_SKM
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(tr1_grid_1d(M * N / 8, 256, 2048)), dim3(256), 0, s, (const float*)ws_f32, S, M * N,
                        (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N);
     TR1_LAUNCH_CHECK();
 }

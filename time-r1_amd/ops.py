@@ -98,6 +98,10 @@ class HipOps:
                 assert t.device.type == "cuda" and t.dtype == dtype, (t.device, t.dtype, dtype)
 
     # ---- GEMM -----------------------------------------------------------------------------------------------------
+    def _splitk_ok(self, M, N, K):
+        """Few 256 x 256 tiles, many K tiles: the split-K form pays (A/B switch TR1_GEMM_SPLITK)."""
+        return bool(self.SPLITK and M > 64 and K >= 2048 and K % 64 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and 8 * M * N * 4 <= (1 << 31))
+
     def gemm_nn(self, a, b):
         """C[M,N] = a[M,K] @ b[K,N] (b K-major, e.g. the weight itself in a dgrad).  Large problems run the K-major form of the phased GEMM
         (no transposed copy); small ones transpose b and use gemm_nt."""
@@ -110,6 +114,11 @@ class HipOps:
         if M >= 512 and N >= 256 and K % 64 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 192:
             c = self.empty(M, N)
             self.L.call("tr1_gemm_nn_bf16", _p(a), _p(b), _p(c), M, N, K, _ld(a), _ld(b), _ld(c), self._s())
+            return c
+        if self._splitk_ok(M, N, K) and a.stride(1) == 1 and b.stride(1) == 1:      # e.g. the lm_head's data gradient: the weight as stored, K = vocabulary
+            c = self.empty(M, N)
+            ws = self._workspace("gemm_splitk", 8 * M * N, F32)
+            self.L.call("tr1_gemm_splitk_bf16", _p(a), _p(b), _p(c), None, None, M, N, K, _ld(a), _ld(b), _ld(c), 0, 1, _p(ws), ws.numel(), self._s())
             return c
         return self.gemm_nt(a, self.transpose(b))
 
@@ -148,13 +157,11 @@ class HipOps:
             assert not accumulate
             out = self.empty(M, N, dtype=F32 if out_f32 else BF16)
         assert out.shape == (M, N) and out.dtype == (F32 if out_f32 else BF16)
-        # thin output over a long reduction (the continuation forward's down projection: 1600 x 3584 x 18944 = 98 tiles of 256 x 256 for 256 CUs):
-        # deterministic 2-way split-K, both halves in one launch
-        if (self.SPLITK and not out_f32 and M > 64 and K >= 8192 and K % 128 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) <= 128
-                and a.stride(1) == 1 and b.stride(1) == 1):
-            ws = self._workspace("gemm_splitk2", 2 * M * N, F32)
-            self.L.call("tr1_gemm_nt_splitk2_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, _ld(a), _ld(b), _ld(out),
-                        _ld(residual) if residual is not None else 0, _p(ws), ws.numel(), self._s())
+        # thin output over a long reduction (continuation down / o projections: 98 tiles of 256 x 256 for 256 CUs): deterministic S-way split-K
+        if not out_f32 and self._splitk_ok(M, N, K) and a.stride(1) == 1 and b.stride(1) == 1:
+            ws = self._workspace("gemm_splitk", 8 * M * N, F32)
+            self.L.call("tr1_gemm_splitk_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, _ld(a), _ld(b), _ld(out),
+                        _ld(residual) if residual is not None else 0, 0, _p(ws), ws.numel(), self._s())
             return out
         self.L.call("tr1_gemm_nt_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, _ld(a), _ld(b), _ld(out),
                     _ld(residual) if residual is not None else 0, int(out_f32), int(accumulate), self._s())
