@@ -41,6 +41,9 @@ extern "C" int probe_fwd_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_
 #define FWD_DUMP() do { } while (0)
 #endif
 
+#ifndef FWD_LAZY_MAX
+#define FWD_LAZY_MAX 6      // log2 units; 0 = rescale whenever a row's maximum moves (round-3 behaviour)
+#endif
 __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE;
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][K rows | V rows] + block mask summary
@@ -199,7 +202,16 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             for (int r = 0; r < 16; r += 2) { mxa = att_max3(mxa, cs[0][r], cs[0][r + 1]); mxb = att_max3(mxb, cs[1][r], cs[1][r + 1]); }
             float mx = fmaxf(mxa, mxb);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx * p.scale_log2);          // max over RAW scores (scale > 0 commutes with max)
+            // Lazy running maximum: when no row of the wave would raise its maximum by more than FWD_LAZY_MAX (log2 units), the OLD maximum stays the
+            // reference point of this tile - alpha == 1 for every row, so the 64 accumulator multiplies per lane are skipped and P = exp2(s - m_old) <= 2^6;
+            // l, the accumulators and the LSE (m + log2 l) stay mutually consistent because all three use the same reference.  With the exact test
+            // (maximum unchanged) the skip only fired late in a row's key range: a tile of 64 new keys holds a new row maximum with probability 1 / (t + 1).
+            const float m_cand = fmaxf(m, mx * p.scale_log2);         // max over RAW scores (scale > 0 commutes with max)
+#if FWD_LAZY_MAX > 0
+            const float m_new = __all(m_cand - m <= (float)FWD_LAZY_MAX) ? m : m_cand;      // (m = -inf: the difference is inf or NaN -> false -> take the new maximum)
+#else
+            const float m_new = m_cand;
+#endif
             const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m - m_safe);
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
