@@ -245,25 +245,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
                 v = (u32x4_t){t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16), t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16)};
             }
         }
-        *reinterpret_cast<u32x4_t*>(&tile[rr][cc]) = v;
+        *reinterpret_cast<u32x4_t*>(&tile[rr][(((cc >> 3) ^ ((rr >> 3) & 7)) << 3)]) = v;       // 16-byte chunk c of row r sits at c ^ (r / 8 % 8)
     }
     __syncthreads();
     const bool vec_out = (ld_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int idx = threadIdx.x + i * 256;                             // 64 output rows (c) x 8 chunks of 8 source rows
-        const int cc = idx & 63, rr = (idx >> 6) * 8;
+        // 64 output rows (c) x 8 chunks of 8 source rows; 8 consecutive lanes write ONE output row's 128 bytes (whole lines per store instruction - the
+        // round-1 map had the 64 lanes of an instruction write 16 bytes into 64 different rows).  With the chunk swizzle above the 2-byte column reads of a
+        // wave (8 output rows x 8 chunks) land on 32 distinct banks.
+        const int idx = threadIdx.x + i * 256;
+        const int cc = idx >> 3, ch = idx & 7, rr = ch * 8;
         const int64_t c = c0 + cc, r = r0 + rr;
-        if (COLSUM) csum[idx >> 6][cc] = 0.f;
+        if (COLSUM) csum[ch][cc] = 0.f;
         if (c >= C || r >= ld_out) continue;
         bf16_t t[8];
+        const int col = (((cc >> 3) ^ ch) << 3) | (cc & 7);                // (rows rr .. rr + 7 share r / 8 % 8 == ch)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = tile[rr + e][cc];               // rows >= R were zero-filled on load: they are the padding
+        for (int e = 0; e < 8; ++e) t[e] = tile[rr + e][col];              // rows >= R were zero-filled on load: they are the padding
         if (COLSUM) {
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) a += bf2f(t[e]);
-            csum[idx >> 6][cc] = a;
+            csum[ch][cc] = a;
         }
         if (vec_out && r + 8 <= ld_out) {
             const u32x4_t v = {t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16), t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16)};
