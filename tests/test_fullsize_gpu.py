@@ -169,3 +169,79 @@ def test_decode_step_logits_match_training_forward_full_width(hip_ops):
     for s in range(1, Cs):
         rows = torch.tensor([G + g * (Cs - 1) + (s - 1) for g in range(G)]).cuda()
         assert torch.allclose(hl[rows], rec[s], atol=0.02 * scale, rtol=0.03), "decode step %d" % s
+
+
+class _unfused_ops:
+    def __init__(self, ops):
+        self.ops = ops
+
+    def __enter__(self):
+        self.ops.FUSE_EPI = False
+        return self.ops
+
+    def __exit__(self, *a):
+        del self.ops.FUSE_EPI
+
+
+def test_fused_epilogue_gemms_at_full_7b_shapes(hip_ops):
+    """Round 4: the training GEMMs that carry their elementwise neighbours in the epilogue, at the config-3 shapes (M = P + G*C = 5074 packed rows, hidden 3584,
+    intermediate 18944, 28 / 4 heads of 128; ViT 13376 tokens x 16 heads of 80): bit-identical to GEMM + elementwise kernel, and right against fp32 torch."""
+    M = P + G * C
+    x = dev_rnd(M, HID, seed=1)
+    # gate/up + SwiGLU
+    wgu = dev_rnd(2 * INTER, HID, seed=2, scale=1.0 / math.sqrt(HID))
+    a, gu = hip_ops.gemm_glu(x, wgu, save_gu=True)
+    with _unfused_ops(hip_ops) as o:
+        a0, gu0 = o.gemm_glu(x, wgu, save_gu=True)
+    assert torch.equal(a, a0) and torch.equal(gu, gu0)
+    g32 = x.float() @ wgu.float().t()
+    ref = torch.nn.functional.silu(g32[:, :INTER]) * g32[:, INTER:]
+    assert rel_l2(a, ref) < 8e-3
+    del g32, ref
+    # down-projection dgrad + SwiGLU backward
+    dh, wd = dev_rnd(M, HID, seed=3, scale=0.05), dev_rnd(HID, INTER, seed=4, scale=1.0 / math.sqrt(INTER))
+    dgu = hip_ops.dgrad_glu_bwd(dh, wd, gu)
+    with _unfused_ops(hip_ops) as o:
+        dgu0 = o.dgrad_glu_bwd(dh, wd, gu)
+    assert torch.equal(dgu, dgu0)
+    del dgu, dgu0, a, a0, gu0
+    # q|k|v + bias + M-RoPE, k into a cache buffer at a row offset
+    qd, kvd = H * HD, NKV * HD
+    wq, bq = dev_rnd(qd + 2 * kvd, HID, seed=5, scale=1.0 / math.sqrt(HID)), dev_rnd(qd + 2 * kvd, seed=6)
+    ang = torch.rand(M, HD // 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)) * 6.28
+    cos, sin = torch.cos(ang).to(BF16).float(), torch.sin(ang).to(BF16).float()
+    kc = torch.zeros(M + 64, kvd, dtype=BF16, device="cuda")
+    q, k, v = hip_ops.gemm_qkv_rope(x, wq, bq, cos, sin, H, NKV, HD, k_out=kc[:M])
+    with _unfused_ops(hip_ops) as o:
+        q0, k0, v0 = o.gemm_qkv_rope(x, wq, bq, cos, sin, H, NKV, HD)
+    assert torch.equal(q, q0) and torch.equal(k, k0) and torch.equal(v, v0) and float(kc[M:].abs().max()) == 0.0
+    # vision q|k|v + bias + 2-D rotary on 128-wide padded heads
+    Nv, Hv, Ev = 13376, 16, 1280
+    xv, wv, bv = dev_rnd(Nv, Ev, seed=8), dev_rnd(3 * Ev, Ev, seed=9, scale=1.0 / math.sqrt(Ev)), dev_rnd(3 * Ev, seed=10)
+    angv = torch.rand(Nv, 40, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11)) * 6.28
+    cv, sv = torch.cos(angv).contiguous(), torch.sin(angv).contiguous()
+    bufs = [torch.zeros(Nv, Hv * 128, dtype=BF16, device="cuda") for _ in range(3)]
+    hip_ops.gemm_qkv_rope_vit(xv, wv, bv, cv, sv, Hv, 40, *bufs)
+    with _unfused_ops(hip_ops) as o:
+        qkv = o.gemm_nt(xv, wv, bias=bv)
+        want = [o.rope_apply(qkv[:, :Ev], Hv, 80, cv, sv), o.rope_apply(qkv[:, Ev:2 * Ev], Hv, 80, cv, sv), qkv[:, 2 * Ev:]]
+    for got, w_ in zip(bufs, want):
+        g3, w3 = got.view(Nv, Hv, 128), w_.reshape(Nv, Hv, 80)
+        assert torch.equal(g3[:, :, :40], w3[:, :, :40]) and torch.equal(g3[:, :, 64:104], w3[:, :, 40:])
+        assert float(g3[:, :, 40:64].abs().max()) == 0.0 and float(g3[:, :, 104:].abs().max()) == 0.0
+
+
+def test_split_k_and_lm_head_dgrad_at_full_7b_shapes(hip_ops):
+    """Round 4: the continuation forward's down projection (1600 x 3584 x 18944) and the lm_head's data gradient (1600 x 3584 over K = 152064, weight as stored)
+    on the deterministic split-K forms, against fp32 torch."""
+    R = G * C
+    a, w, res = dev_rnd(R, INTER, seed=1), dev_rnd(HID, INTER, seed=2, scale=1.0 / math.sqrt(INTER)), dev_rnd(R, HID, seed=3)
+    assert hip_ops._splitk_ok(R, HID, INTER)
+    y = hip_ops.gemm_nt(a, w, residual=res)
+    assert rel_l2(y, a.float() @ w.float().t() + res.float()) < 3e-3
+    V = 152064
+    dl, wl = dev_rnd(R, V, seed=4, scale=0.01), dev_rnd(V, HID, seed=5, scale=0.02)
+    assert hip_ops._splitk_ok(R, HID, V)
+    d = hip_ops.gemm_nn(dl, wl)
+    assert rel_l2(d, dl.float() @ wl.float()) < 3e-3
+    assert torch.equal(d, hip_ops.gemm_nn(dl, wl)), "deterministic"
