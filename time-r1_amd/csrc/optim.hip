@@ -155,16 +155,29 @@ extern "C" int tr1_zero_ranges_periodic(void* g_f32, int64_t base, int64_t strid
 
 // out += sum of partials[0 .. n) in a FIXED order (one block: thread t adds partials[t], partials[t + 1024], ...; then the block tree) - the per-wave sums of
 // squares the weight-gradient epilogues left (tr1_wgrad_f32_sumsq)
-__global__ __launch_bounds__(1024) void sumsq_partials_kernel(const float* __restrict__ part, int64_t n, float* __restrict__ out) {
+// two fixed-order levels (a single 1024-thread block took 0.33 ms for the 7B step's 720 k partials): level 1 - block b sums its contiguous share and leaves
+// the result in scratch[b]; level 2 - one wave-sized block adds the <= 256 block sums to `out`
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ part, int64_t n, float* __restrict__ scratch) {
     __shared__ float red[16];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, a = (int64_t)blockIdx.x * per, b = a + per < n ? a + per : n;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) s += part[i];
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_partials_final_kernel(const float* __restrict__ scratch, int nb, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = threadIdx.x < nb ? scratch[threadIdx.x] : 0.f;
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
+// partials_f32 must have room for 256 more floats behind its n entries (scratch of the first level)
 extern "C" int tr1_sumsq_partials_accum(const void* partials_f32, int64_t n, void* out_scalar, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)partials_f32, n, (float*)out_scalar);
+    const int nb = (int)(n < 256 * 256 ? (n + 255) / 256 : 256);
+    float* scratch = (float*)partials_f32 + n;
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)partials_f32, n, scratch);
+    hipLaunchKernelGGL(sumsq_partials_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, nb, (float*)out_scalar);
     TR1_LAUNCH_CHECK();
 }
 

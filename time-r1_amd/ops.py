@@ -737,11 +737,11 @@ class HipOps:
         assert gw.dtype == F32 and gw.shape == (N, K) and partials.dtype == F32 and partials.is_contiguous()
         n = ctypes.c_int64(0)
         self.L.call("tr1_wgrad_f32_sumsq", _p(a), _p(b), _p(gw), N, K, Mp, _ld(a), _ld(b), _ld(gw), int(accumulate), int(b_kmajor), int(b_rows),
-                    partials.data_ptr() + 4 * int(offset), partials.numel() - int(offset), ctypes.byref(n), self._s())
+                    partials.data_ptr() + 4 * int(offset), partials.numel() - int(offset) - 256, ctypes.byref(n), self._s())
         return int(n.value)
 
     def sumsq_partials_accum(self, partials, n, out_scalar):
-        assert partials.dtype == F32 and out_scalar.dtype == F32
+        assert partials.dtype == F32 and out_scalar.dtype == F32 and partials.numel() >= int(n) + 256
         self.L.call("tr1_sumsq_partials_accum", _p(partials), int(n), _p(out_scalar), self._s())
 
     def sumsq_ranges_periodic(self, g, base, stride, count, rel_ranges, out_scalar):
