@@ -60,8 +60,10 @@ int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const void* bias, co
  *   64 + d; the caller zero-fills q128 / k128 / v128 once) so that the head-dim-128 attention kernel (tr1_attn_fwd_rows) runs the tower.  cos / sin fp32 [M, half]. */
 int tr1_gemm_qkv_rope_vit_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q128, int64_t ldq, void* k128, int64_t ldk, void* v128, int64_t ldv, int64_t M, int64_t n_heads, int64_t half, int64_t K, int64_t ldx, int64_t ldw, void* stream);
 /* tr1_gemm_nn_glubwd_bf16: dgu[M, 2I] = SwiGLU backward of da = dh[M, H] Wd[H, I] (the down projection as stored) with the saved gu[M, 2I]; da is never
- *   written (autograd of TF:459-466 under accelerator.backward, src/time_r1/rl/timer1_trainer.py:709-737). */
-int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void* dgu, int64_t M, int64_t I, int64_t H, int64_t lda, int64_t ldb, int64_t ldgu, int64_t lddgu, void* stream);
+ *   written (autograd of TF:459-466 under accelerator.backward, src/time_r1/rl/timer1_trainer.py:709-737).  dgu_t (optional): the same values once more as
+ *   dgu^T [2I, ld_t] (ld_t = M rounded up to 64, columns >= M zero) - the operand of the gate/up weight gradient, written from the epilogue's LDS staging
+ *   instead of by a separate transpose pass over the 384 MB of dgu. */
+int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void* dgu, int64_t M, int64_t I, int64_t H, int64_t lda, int64_t ldb, int64_t ldgu, int64_t lddgu, void* dgu_t, int64_t ld_t, void* stream);
 /* Weight gradient without the X^T copy: C[M,N] fp32 (+)= A[M,K] B[K,N], B K-major with only its first b_rows rows valid (A = dY^T zero-padded to
  * K = tokens rounded up to 64, B = the saved activation as stored).  ref: autograd of nn.Linear inside HF Trainer.training_step (TF trainer.py:1892-1961). */
 int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int64_t b_rows, void* stream);

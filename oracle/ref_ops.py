@@ -219,8 +219,9 @@ class RefOps:
             v = v_out
         return q, k, v
 
-    def dgrad_glu_bwd(self, dh, w_down, gu):
-        return self.swiglu_bwd(self.gemm_nn(dh, w_down), gu)
+    def dgrad_glu_bwd(self, dh, w_down, gu, want_t=False):
+        dgu = self.swiglu_bwd(self.gemm_nn(dh, w_down), gu)
+        return (dgu, None) if want_t else dgu
 
     def swiglu_fwd(self, gu, out=None):
         i = gu.shape[1] // 2

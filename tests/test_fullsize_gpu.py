@@ -200,11 +200,12 @@ def test_fused_epilogue_gemms_at_full_7b_shapes(hip_ops):
     del g32, ref
     # down-projection dgrad + SwiGLU backward
     dh, wd = dev_rnd(M, HID, seed=3, scale=0.05), dev_rnd(HID, INTER, seed=4, scale=1.0 / math.sqrt(INTER))
-    dgu = hip_ops.dgrad_glu_bwd(dh, wd, gu)
+    dgu, dgut = hip_ops.dgrad_glu_bwd(dh, wd, gu, want_t=True)
     with _unfused_ops(hip_ops) as o:
         dgu0 = o.dgrad_glu_bwd(dh, wd, gu)
     assert torch.equal(dgu, dgu0)
-    del dgu, dgu0, a, a0, gu0
+    assert dgut is not None and torch.equal(dgut, hip_ops.transpose(dgu0)), "dgu^T from the dgrad epilogue (the gate/up weight gradient's operand)"
+    del dgu, dgu0, dgut, a, a0, gu0
     # q|k|v + bias + M-RoPE, k into a cache buffer at a row offset
     qd, kvd = H * HD, NKV * HD
     wq, bq = dev_rnd(qd + 2 * kvd, HID, seed=5, scale=1.0 / math.sqrt(HID)), dev_rnd(qd + 2 * kvd, seed=6)

@@ -310,7 +310,7 @@ def test_gemm_qkv_rope_vit_padded_heads(hip_ops, ref_ops, M, H, K):
     close(q128.view(M, H, 128)[:, :, :half], qr.view(M, H, hd)[:, :, :half], 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=3e-2, what="q vs oracle")
 
 
-@pytest.mark.parametrize("M,I,H", [(2048, 6400, 256), (1600, 8192, 128), (5074, 4096, 64)])
+@pytest.mark.parametrize("M,I,H", [(2048, 6400, 256), (1600, 8192, 128), (5074, 4096, 64), (1537, 8200, 64), (1440, 8192, 64), (1568, 8192, 64), (1824, 8192, 128), (2016, 8192, 64)])
 def test_dgrad_glu_bwd_fused_epilogue(hip_ops, ref_ops, M, I, H):
     """Down-projection dgrad (weight as stored) with the SwiGLU backward in its epilogue (EPI 3): bit-identical to gemm_nn + swiglu_bwd."""
     dh, w, gu = rnd(M, H, seed=1), rnd(H, I, seed=2, scale=0.1), rnd(M, 2 * I, seed=3)
@@ -318,6 +318,9 @@ def test_dgrad_glu_bwd_fused_epilogue(hip_ops, ref_ops, M, I, H):
     with _unfused(hip_ops) as o:
         d0 = o.dgrad_glu_bwd(dh.cuda(), w.cuda(), gu.cuda())
     assert torch.equal(d, d0), "fused SwiGLU-backward epilogue differs from gemm_nn + swiglu_bwd"
+    d2, dt = hip_ops.dgrad_glu_bwd(dh.cuda(), w.cuda(), gu.cuda(), want_t=True)
+    assert dt is not None and torch.equal(d2, d0)
+    assert torch.equal(dt, hip_ops.transpose(d0)), "dgu^T from the epilogue staging must equal transpose(dgu), zero padding included"
     if M <= 2048:
         close(d, ref_ops.dgrad_glu_bwd(dh.float(), w.float(), gu.float()), 0.02 * math.sqrt(H) * 0.1 + 0.03, rtol=4e-2, what="dgu")
 

@@ -655,6 +655,17 @@ TR1_DEV void store_acc256_glubwd(const f32x4_t (&acc)[RT][4], char* __restrict__
     const int c8 = lane & 7;
     const int64_t n = ncol0 + c8 * 8, I = ep.i0;
     const bf16_t* gu = reinterpret_cast<const bf16_t*>(ep.p0);
+    bf16_t* dguT = reinterpret_cast<bf16_t*>(ep.p1);          // optional second output: dgu^T [2I, ep.ld1] (ep.ld1 = tokens rounded up to 64, columns >= M zero)
+    if (dguT && mrow0 + RT * 16 >= M && mrow0 + RT * 16 < ep.ld1 && ((mrow0 + RT * 16) % (RT * 32)) == 0) {
+        // the tile rows end (a multiple of 32) short of the padded width (a multiple of 64): the lower wave row of the last row tile zero-fills the 32 columns left
+        const int64_t mz = mrow0 + RT * 16;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 64 + lane, col = idx >> 2, ch = idx & 3, part = col >> 6, ncol = col & 63;
+            if (ncol0 + ncol < N && mz + ch * 8 < ep.ld1)
+                *reinterpret_cast<u32x4_t*>(dguT + ((int64_t)part * I + ncol0 + ncol) * ep.ld1 + mz + ch * 8) = u32x4_t{0, 0, 0, 0};
+        }
+    }
 #pragma unroll
     for (int i0 = 0; i0 < RT; i0 += CH) {
         const int cnt = RT - i0 < CH ? RT - i0 : CH;
@@ -674,11 +685,12 @@ TR1_DEV void store_acc256_glubwd(const f32x4_t (&acc)[RT][4], char* __restrict__
                 const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8) ^ (rr & 15)) << 4));
                 const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(wave_lds + rr * 256 + (((2 * c8 + 1) ^ (rr & 15)) << 4));
                 const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (dguT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (both reads of every lane have returned before the row is rewritten below)
                 const int64_t m = mrow0 + i0 * 16 + rr;
+                u32x4_t og = {0, 0, 0, 0}, ou = {0, 0, 0, 0};
                 if (m < M && n + 8 <= N) {
                     const u32x4_t gg = *reinterpret_cast<const u32x4_t*>(gu + m * ep.ld0 + n);
                     const u32x4_t uu = *reinterpret_cast<const u32x4_t*>(gu + m * ep.ld0 + I + n);
-                    u32x4_t og, ou;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gv[2] = {bflo(gg[e]), bfhi(gg[e])}, uv[2] = {bflo(uu[e]), bfhi(uu[e])};
@@ -697,9 +709,39 @@ TR1_DEV void store_acc256_glubwd(const f32x4_t (&acc)[RT][4], char* __restrict__
                     *reinterpret_cast<u32x4_t*>(cp) = og;
                     *reinterpret_cast<u32x4_t*>(cp + I) = ou;
                 }
+                if (dguT) {
+                    // the row's fp32 values have been read (its 8 lanes cover all 16 chunks, LDS operations of a wave retire in order): its 256 bytes now
+                    // hold the bf16 results (zeros for rows >= M: the transposed copy is zero-padded), gate chunk c8 at ((row & 1) << 3 | c8 ^ (row / 8 % 8)), up in
+                    // the other half - conflict-free for these row writes (two rows per quarter wave use opposite halves) and for the column reads below
+                    const int k3 = (rr >> 3) & 7, hb = rr & 1;
+                    *reinterpret_cast<u32x4_t*>(wave_lds + rr * 256 + (((hb << 3) | (c8 ^ k3)) << 4)) = og;
+                    *reinterpret_cast<u32x4_t*>(wave_lds + rr * 256 + ((((hb ^ 1) << 3) | (c8 ^ k3)) << 4)) = ou;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (dguT) {
+            // transposed read-back: lane -> (column, 8-row chunk); the 8 lanes of a column write 128 contiguous bytes of dgu^T (8 row chunks = 64 rows)
+            const int rc = lane & 7;
+            const int64_t mchunk = mrow0 + i0 * 16 + rc * 8;
+            if (rc < cnt * 2 && mchunk < ep.ld1) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int part = it >> 3, ncol = (it & 7) * 8 + (lane >> 3);
+                    if (ncol0 + ncol < N) {
+                        unsigned short t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int row = rc * 8 + e;
+                            t[e] = *reinterpret_cast<const unsigned short*>(wave_lds + row * 256 + ((((part ^ (row & 1)) << 3) | ((ncol >> 3) ^ rc)) << 4) + (ncol & 7) * 2);
+                        }
+                        const u32x4_t w = {t[0] | ((unsigned)t[1] << 16), t[2] | ((unsigned)t[3] << 16), t[4] | ((unsigned)t[5] << 16), t[6] | ((unsigned)t[7] << 16)};
+                        *reinterpret_cast<u32x4_t*>(dguT + ((int64_t)part * I + ncol0 + ncol) * ep.ld1 + mchunk) = w;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
 }
 
@@ -2262,7 +2304,8 @@ extern "C" int tr1_gemm_qkv_rope_vit_bf16(const void* x, const void* Wqkv, const
 // dgu[M, 2I] = SwiGLU backward of da = dh[M, H] * Wd[H, I] (Wd = the down projection as stored, K-major operand), with gu[M, 2I] the saved projection.
 // Bit-identical to tr1_gemm_nn_bf16 + tr1_swiglu_bwd; da never exists in HBM.
 extern "C" int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void* dgu, int64_t M, int64_t I, int64_t H, int64_t lda, int64_t ldb,
-                                       int64_t ldgu, int64_t lddgu, void* stream) {
+                                       int64_t ldgu, int64_t lddgu, void* dgu_t, int64_t ld_t, void* stream) {
+    TR1_CHECK_ARG(!dgu_t || (ld_t % 64 == 0 && ld_t >= M && ld_t < M + 64), "gemm_nn_glubwd: dgu^T needs ld_t = tokens rounded up to 64");
     TR1_CHECK_ARG(H % BK == 0 && I % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0, "gemm_nn_glubwd: H%64, I%8, ld%8 required");
     TR1_CHECK_ARG(M >= 512 && I >= 256, "gemm_nn_glubwd: M >= 512 and I >= 256 required");
     hipStream_t s = (hipStream_t)stream;
@@ -2273,7 +2316,7 @@ extern "C" int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const voi
     const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + 4096;
 #define KA_GB(R) false, false, R, true, 3
     EPI_SETATTR(KA_GB);
-    GemmEpi ep{}; ep.p0 = const_cast<void*>(gu); ep.ld0 = ldgu; ep.i0 = (int)I;
+    GemmEpi ep{}; ep.p0 = const_cast<void*>(gu); ep.ld0 = ldgu; ep.i0 = (int)I; ep.p1 = dgu_t; ep.ld1 = ld_t;
     EPI_LAUNCH(KA_GB, rt, dim3((unsigned)(t2m * t2n)), dim3(512), dyn, s, (const bf16_t*)dh, (const bf16_t*)Wd, dgu, (const bf16_t*)nullptr,
                (const bf16_t*)nullptr, M, I, H, lda, ldb, lddgu, (int64_t)0, (int)t2m, (int)t2n, ep);
 #undef KA_GB

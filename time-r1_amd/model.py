@@ -43,7 +43,7 @@ class Engine:
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
-    def _wgrad(self, dy, x, gw, key=None, bias_g=None):
+    def _wgrad(self, dy, x, gw, key=None, bias_g=None, dyt=None):
         """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K].  key (decoder-layer weights): the FIRST weight gradient after an optimizer step (the arena's
         version changed) overwrites gw instead of accumulating - AdamW left it at zero, so the result is identical and the GEMM epilogue skips
         reading 4 bytes per parameter (33 GB per accumulation window at 7B)."""
@@ -63,7 +63,8 @@ class Engine:
                 ops.colsum_accum(dy, bias_g)
             return
         # bias_g: the Linear's bias gradient (column sums of dy) rides on the pass that builds dy^T
-        dyt = ops.transpose(dy, colsum=bias_g) if bias_g is not None else ops.transpose(dy)          # [N, Mp], zero-padded columns
+        if dyt is None:                                  # (the fused down dgrad hands over dgu^T from its epilogue)
+            dyt = ops.transpose(dy, colsum=bias_g) if bias_g is not None else ops.transpose(dy)      # [N, Mp], zero-padded columns
         sink = self.norm_sink
         if sink is not None and key is not None and key.split(".", 1)[-1] in self.OVERWRITTEN and hasattr(ops, "wgrad_sumsq"):
             # last micro-step of the window: same GEMM, and its epilogue also leaves the sum of squares of the FINAL gradient values it stores
@@ -117,15 +118,17 @@ class Engine:
             self._side = torch.cuda.Stream(device=self.ops.device)
         return self._side
 
-    def _wgrad_async(self, dy, x, gw, side, key=None, bias_g=None):
+    def _wgrad_async(self, dy, x, gw, side, key=None, bias_g=None, dyt=None):
         if side is None:
-            return self._wgrad(dy, x, gw, key, bias_g)
+            return self._wgrad(dy, x, gw, key, bias_g, dyt)
         main = torch.cuda.current_stream(self.ops.device)
         side.wait_stream(main)                         # dy (and every earlier write of gw) is ordered before the side work
         with torch.cuda.stream(side):
-            self._wgrad(dy, x, gw, key, bias_g)
+            self._wgrad(dy, x, gw, key, bias_g, dyt)
         dy.record_stream(side)                         # keep the caching allocator from recycling them under the side stream
         x.record_stream(side)
+        if dyt is not None:
+            dyt.record_stream(side)
 
     def _dgrad(self, dy, w, key=None):
         """dx[M,K] = dy[M,N] @ w[N,K].  The weight is the K-major operand of an "NN" GEMM: large problems read it as stored through the
@@ -425,8 +428,9 @@ class Engine:
             # h_out = a @ Wd^T + h2
             _sync = self.wgrad_on_main
             self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side, key=p + "down.w")
-            dgu = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"])       # down-projection dgrad with the SwiGLU backward in its epilogue
-            self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side, key=p + "gu.w")
+            # down-projection dgrad with the SwiGLU backward in its epilogue, which also leaves dgu^T (the gate/up weight gradient's operand) from its LDS staging
+            dgu, dgut = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"], want_t=True)
+            self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side, key=p + "gu.w", dyt=dgut)
             dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"), key=p + "gu.w")
             dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))
             # h2 = o @ Wo^T + h

@@ -232,17 +232,23 @@ class HipOps:
         self.L.call("tr1_gemm_qkv_rope_vit_bf16", _p(x), _p(w_qkv), _p(bias), _p(cos), _p(sin), _p(q128), _ld(q128), _p(k128), _ld(k128), _p(v128), _ld(v128),
                     M, n_heads, half, K, _ld(x), _ld(w_qkv), self._s())
 
-    def dgrad_glu_bwd(self, dh, w_down, gu):
-        """dgu[M, 2I] = swiglu_bwd(dh @ w_down, gu) with w_down [H, I] as stored (K-major operand)."""
+    DGU_T = os.environ.get("TR1_DGU_T", "1") != "0"        # A/B switch: dgu^T from the fused dgrad's epilogue instead of a transpose pass
+
+    def dgrad_glu_bwd(self, dh, w_down, gu, want_t=False):
+        """dgu[M, 2I] = swiglu_bwd(dh @ w_down, gu) with w_down [H, I] as stored (K-major operand).  want_t: -> (dgu, dgu^T or None); the fused kernel can
+        write dgu^T [2I, Mp] (Mp = M rounded up to 64, padding zero: what transpose(dgu) returns) from its epilogue staging."""
         self._chk(dh, w_down, gu)
         M, H = dh.shape
         I = w_down.shape[1]
         if (self.FUSE_EPI and M >= 512 and I >= 256 and H % 64 == 0 and I % 8 == 0 and dh.stride(1) == 1 and w_down.stride(1) == 1 and gu.stride(1) == 1
                 and ((M + 255) // 256) * ((I + 255) // 256) >= 192):
             dgu = self.empty(M, 2 * I)
-            self.L.call("tr1_gemm_nn_glubwd_bf16", _p(dh), _p(w_down), _p(gu), _p(dgu), M, I, H, _ld(dh), _ld(w_down), _ld(gu), _ld(dgu), self._s())
-            return dgu
-        return self.swiglu_bwd(self.gemm_nn(dh, w_down), gu)
+            dgt = self.empty(2 * I, (M + 63) // 64 * 64) if (want_t and self.DGU_T) else None
+            self.L.call("tr1_gemm_nn_glubwd_bf16", _p(dh), _p(w_down), _p(gu), _p(dgu), M, I, H, _ld(dh), _ld(w_down), _ld(gu), _ld(dgu),
+                        _p(dgt), _ld(dgt) if dgt is not None else 0, self._s())
+            return (dgu, dgt) if want_t else dgu
+        dgu = self.swiglu_bwd(self.gemm_nn(dh, w_down), gu)
+        return (dgu, None) if want_t else dgu
 
     def norm_gemm(self, x, lnw, eps, w, bias=None, glu=False):
         """Decode rows: rmsnorm(x; lnw) @ w^T (+bias), or with glu=True silu(gate)*up of the [2I, K] weight - one launch."""
