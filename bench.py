@@ -34,7 +34,7 @@ from time_r1_amd.grpo import GRPOCore, eos_mask, group_advantages  # noqa: E402
 from time_r1_amd.synthetic import synthetic_prompt, piece_decode  # noqa: E402
 from time_r1_amd import rewards as R  # noqa: E402
 from time_r1_amd import vision_process as VP  # noqa: E402
-from time_r1_amd.dist import init_from_env, DataParallel  # noqa: E402
+from time_r1_amd.dist import init_from_env, DataParallel, shard_world_ok  # noqa: E402
 
 # (frames -> video_grid_thw) for a 360x640 source under the reference's pixel budget
 GRIDS = {8: (4, 26, 46), 16: (8, 26, 46), 32: (16, 22, 38), 64: (32, 14, 28)}
@@ -66,7 +66,7 @@ class Workload:
         dp = DataParallel()
         # N > 1 defaults to the sharded optimizer (every reference multi-GPU script runs ZeRO, scripts/zero3.json): master / m / v are allocated as
         # 1/world shards only (AdamWFlat -> Arena.set_shard); --replicated-optimizer opts out, world sizes other than 2 / 4 / 8 fall back
-        self.shard = dp.enabled and dp.world in (2, 4, 8) and not args.replicated_optimizer
+        self.shard = dp.enabled and shard_world_ok(dp.world) and not args.replicated_optimizer
         self.params = ModelParams(self.cfg, ops, init="none", optimizer_state=not self.shard)
         if hasattr(self.params, "init_random_device"):
             self.params.init_random_device(seed=0)
@@ -89,7 +89,8 @@ class Workload:
                            rollout_batching=not args.no_rollout_batching,
                            rollout_weight_dtype="fp8" if args.rollout_fp8_w8a16 else ("fp8-mfma" if args.rollout_fp8 else "bf16"),
                            rollout_fp8_keep_bf16=None if args.rollout_fp8_keep_bf16 == "auto" else tuple(x for x in args.rollout_fp8_keep_bf16.split(",") if x and x != "none"),
-                           rollout_importance_cap=args.rollout_importance_cap)
+                           rollout_importance_cap=args.rollout_importance_cap, grad_wire_dtype=args.grad_wire)
+        self.ballast = torch.empty(int(args.ballast_gb * (1 << 30)), dtype=torch.uint8, device=device) if (args.ballast_gb > 0 and not args.ballast_early) else None
         self.trainer = TimeR1_Trainer(self.params, self.reward_funcs, [], args=targs, train_dataset=self.dataset,
                                       processing_class=SyntheticProcessor(self.cfg), ops=ops)
         tr = self.trainer
@@ -442,6 +443,9 @@ def parse_args(argv=None):
                     "default (qkv,o for the fp8-MFMA policy: faster and less drift than all-fp8, DESIGN 7d), 'none' = every matrix fp8")
     ap.add_argument("--rollout-importance-cap", type=float, default=None, help="truncated importance weight min(exp(policy logp - sampling logp), c) on the advantage term")
     ap.add_argument("--engine-path", action="store_true", help="time the bare engine loop (GRPOCore + AdamWFlat, no TimeR1_Trainer) instead of the trainer class")
+    ap.add_argument("--grad-wire", default="bf16", choices=["bf16", "fp32"], help="N > 1: wire format of the gradient exchange (bf16: a 2 B / parameter staging arena)")
+    ap.add_argument("--ballast-gb", type=float, default=0.0, help="diagnostic: hold this many GiB of untouched HBM (footprint / address-placement A/B runs)")
+    ap.add_argument("--ballast-early", action="store_true", help="diagnostic: take the ballast before anything else is allocated (shifts every later address)")
     ap.add_argument("--no-engine-leg", action="store_true", help="skip the short bare-engine-loop cross-check that follows the timed region")
     ap.add_argument("--no-grad-overlap", action="store_true", help="N > 1: exchange the gradient arena after backward instead of during it")
     ap.add_argument("--shard-optimizer", action="store_true", help="DEPRECATED, no effect: ZeRO-style optimizer sharding (reduce-scatter grads, AdamW on the local 1/N "
@@ -491,6 +495,7 @@ def main(argv=None):
         local = int(os.environ["TR1_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
+    early_ballast = torch.empty(int(args.ballast_gb * (1 << 30)), dtype=torch.uint8, device=device) if (args.ballast_gb > 0 and args.ballast_early) else None  # noqa: F841
     from time_r1_amd.ops import HipOps
     ops = HipOps(device)
     ops.use_priority_stream()            # main chain ahead of the weight-gradient side stream in the dispatcher (same call as the trainer)
@@ -566,7 +571,7 @@ def main(argv=None):
             "phases_ms_per_step": {k: round(v, 2) for k, v in phases.items()},
             "engine_path": engine_leg,
             "distributed": {**diag, "grad_exchange_exposed_ms_per_optimizer_step": round(exch_ms / max(len(timed_plan), 1), 3),
-                            "optimizer_sharded": bool(wl.shard), "grad_wire_dtype": "bf16", "hbm_gb_allocated_peak_per_rank": mem_all,
+                            "optimizer_sharded": bool(wl.shard), "grad_wire_dtype": args.grad_wire, "hbm_gb_allocated_peak_per_rank": mem_all,
                             "process_group_timeout_s": float(os.environ.get("TR1_DIST_TIMEOUT_S", "600"))},
             "trainer_log_last": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (logs[-1] if logs else {}).items()},
             "optimizer_steps": len(timed_plan), "windows": "%d x %d" % (args.steps // args.ga, args.ga) + (" + 1 x %d" % (args.steps % args.ga) if args.steps % args.ga else ""),

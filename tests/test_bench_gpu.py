@@ -68,6 +68,34 @@ def test_self_spawned_two_rank_run(shard):
         assert test_self_spawned_two_rank_run.mem[True] <= test_self_spawned_two_rank_run.mem[False] * 1.02, test_self_spawned_two_rank_run.mem
 
 
+@pytest.mark.parametrize("shard", [False, True])
+def test_single_rank_process_group_runs_the_collective_path_on_rccl(shard):
+    """TR1_DIST_FORCE=1 under the driver's own launch line (torch.distributed.run, 1 rank): the process group is built on "nccl" (= RCCL) and the
+    gradient exchange of the data-parallel path (all-reduce; reduce-scatter + all-gather when sharded), the diagnostics collectives, the barrier and the
+    max-over-ranks timing all execute on the GPU with world size 1 - every torch.distributed call the 8-GPU run makes, on the one GPU this box has."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, TR1_DIST_FORCE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TR1_DIST_BACKEND", "TR1_FORCE_DEVICE"):
+        e.pop(k, None)
+    base = ["--model", "tiny", "--G", "4", "--C", "8", "--no-cpu-baseline", "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-roofline", "--no-peak-probe"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py")] + base + ([] if shard else ["--replicated-optimizer"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = out["distributed"]
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["ranks_seen"] == [0] and d["ranks_seen_ok"] and d["optimizer_sharded"] == shard
+    assert ("zero-sharded" in out["config"]["optimizer"]) == shard and out["n_gpus"] == 1
+    plain = _run(base[6:])                                       # the same run without a process group: same seeds, same samples, same update
+    a, b = out["trainer_log_last"], plain["trainer_log_last"]
+    for k in ("loss", "grad_norm", "reward", "completion_length"):
+        if k in a and k in b:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+
+
 def test_world_size_mismatch_is_an_error():
     e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--gpus", "2"], capture_output=True, text=True, env=e, cwd=ROOT)

@@ -15,9 +15,26 @@ import torch
 import torch.distributed as dist
 
 
+def force_single_rank():
+    """TR1_DIST_FORCE=1: build the process group and run every collective of the data-parallel path with world size 1 too - the way to execute the
+    RCCL calls of this module (all-reduce, reduce-scatter, all-gather on torch.distributed "nccl") on a ONE-GPU box (tests/test_bench_gpu.py)."""
+    return os.environ.get("TR1_DIST_FORCE", "0") == "1"
+
+
+def group_active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_single_rank())
+
+
+SHARD_WORLDS = (2, 4, 8)
+
+
+def shard_world_ok(world):
+    return world in SHARD_WORLDS or (world == 1 and force_single_rank())
+
+
 class DataParallel:
     def __init__(self, bucket_bytes=1 << 30):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.enabled = group_active()
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         self.bucket_bytes = bucket_bytes
@@ -211,7 +228,7 @@ def init_from_env(device_type="cuda"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_single_rank()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("TR1_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")   # "nccl" IS RCCL on ROCm
@@ -237,7 +254,7 @@ def dist_diagnostics(device):
         out["rccl_version"] = "unavailable: %r" % (e,)
     dev = torch.device(device)
     name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not group_active():
         out["devices"] = [name]
         return out
     world, rank = dist.get_world_size(), dist.get_rank()

@@ -41,9 +41,18 @@ class HipOps:
         runs its weight gradients on a normal-priority side stream (Engine._side_stream): with both at the same priority every small
         kernel of the main chain queues behind the pending workgroups of a 1-block-per-CU weight-gradient GEMM (~150 us per launch);
         with the main chain ahead in the dispatcher's arbitration the 7B backward drops from 171 to 164 ms.  TR1_MAIN_PRIO=0 keeps the
-        default stream (A/B measurements)."""
-        if os.environ.get("TR1_MAIN_PRIO", "1") == "0":
+        default stream (A/B measurements).
+        With a torch.distributed process group in the process the default is the DEFAULT stream: the group's streams take HIP past its four hardware
+        queues, and with the main chain on a priority stream every small kernel of the forward / backward then starts late (measured on one MI355X with a
+        single-rank RCCL group, tools/ab_dp_single_rank.sh: log-probs 87 -> 101 ms, backward 152 -> 161 ms per micro-step; the default stream, or
+        GPU_MAX_HW_QUEUES=2, restores 87 / 152).  TR1_MAIN_PRIO=1 forces the priority stream there too."""
+        want = os.environ.get("TR1_MAIN_PRIO")
+        if want == "0":
             return None
+        if want is None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return None
         if getattr(self, "_main_stream", None) is None:
             self._main_stream = torch.cuda.Stream(device=self.device, priority=-1)
             torch.cuda.set_stream(self._main_stream)

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .config import ModelConfig, PRESETS
-from .dist import DataParallel
+from .dist import DataParallel, shard_world_ok
 from .grpo import GRPOCore, eos_mask, group_advantages
 from .model import Engine
 from .optim import AdamWFlat
@@ -392,7 +392,7 @@ class TimeR1_Trainer:
             want = "zero" in os.path.basename(ds).lower()
         else:
             want = dp is not None and dp.enabled
-        if want and dp is not None and dp.enabled and dp.world not in (2, 4, 8):
+        if want and dp is not None and dp.enabled and not shard_world_ok(dp.world):
             # arena segments split into 1/2/4/8 equal 128-byte-aligned chunks (params.SEG_ALIGN); other world sizes train with the replicated
             # optimizer (same results, more optimizer-state memory) instead of failing at construction where the reference script ran
             if dp.rank == 0:
