@@ -249,3 +249,45 @@ def test_layer_done_hook_sees_final_gradients(hip_ops):
         assert float(snaps[tuple(rng)].abs().sum()) > 0
     announced_layers = [r for r in order if r in [tuple(x) for x in layer_ranges]]
     assert announced_layers == [tuple(x) for x in reversed(layer_ranges)], "layers are announced in backward order"
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_last_layer_tail_rows_only_gives_the_same_logps_and_gradients(hip_ops, reuse):
+    """llm_fwd(tail_from=P - 1): the last layer's o projection / MLP run on the rows the head reads (last prompt row + completion rows) only, forward and
+    backward.  Same log-probs, reference log-probs and parameter gradients as running every row (Engine.TAIL_SKIP = False), with and without the
+    rollout's prefill being reused; bf16 kernels picked by row count may differ in the last bit, hence the tolerances."""
+    import time_r1_amd  # noqa: F401
+    from time_r1_amd.config import tiny_test
+    from time_r1_amd.params import ModelParams
+    from time_r1_amd.model import Engine
+    from time_r1_amd.grpo import GRPOCore
+    from time_r1_amd.synthetic import synthetic_prompt
+    cfg = tiny_test(n_layers=3)
+    ops = hip_ops
+    G, C = 4, 10
+    ids, pix, grid = synthetic_prompt(cfg, (4, 6, 8), 9, 7, seed=2, text_vocab=400)
+    out = {}
+    old = Engine.TAIL_SKIP
+    try:
+        for skip in (True, False):
+            Engine.TAIL_SKIP = skip
+            params = ModelParams(cfg, ops, seed=1)
+            eng = Engine(cfg, ops, params)
+            core = GRPOCore(eng, params.train.clone_weights_only(), G, C, beta=0.04, seed=3, rope_index_mode="hf4", reuse_prefill=reuse)
+            st = core.prepare(ids, pix, grid)
+            core.rollout(st)
+            core.forward_logps(st)
+            assert int(st.llm_ctx.get("tail_from", 0)) == (st.P - 1 if skip else 0)
+            mask = torch.ones(G, C, dtype=torch.int32, device=ops.device)
+            adv = torch.linspace(-1.0, 1.0, G, device=ops.device)
+            core.loss_backward(st, mask, adv)
+            torch.cuda.synchronize()
+            out[skip] = dict(tok=st.completion_ids.cpu().clone(), logp=st.logp.float().cpu().clone(), ref=st.ref_logp.float().cpu().clone(),
+                             grad=params.train.grad.float().cpu().clone())
+    finally:
+        Engine.TAIL_SKIP = old
+    a, b = out[True], out[False]
+    assert torch.equal(a["tok"], b["tok"])                         # the prefill's last row (first-token logits) and every decode step are unchanged
+    assert torch.allclose(a["logp"], b["logp"], atol=2e-2) and torch.allclose(a["ref"], b["ref"], atol=2e-2)
+    rel = (a["grad"] - b["grad"]).norm() / b["grad"].norm()
+    assert float(b["grad"].norm()) > 0 and float(rel) < 2e-2, float(rel)

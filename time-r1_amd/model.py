@@ -333,16 +333,23 @@ class Engine:
         pctx["stash"] = False
         return pctx
 
-    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0, bufs=None):
+    TAIL_SKIP = os.environ.get("TR1_TAIL_SKIP", "1") != "0"     # A/B switch for `tail_from` (0: every row runs the whole last layer)
+
+    def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0, bufs=None, tail_from=None):
         """Decoder stack over a packed sequence of M rows. masks = (pre, lo, hi) int32 [M] over slots == rows.
         kv_cache: optional list of (K [S_cap, kv_dim], VT [kv_dim, S_cap]) to be filled (rollout prefill).
         row0 > 0 ("continuation"): h holds only rows [row0, row0+M) of the packed sequence; their K/V are written to cache slots
         [row0, row0+M) and attention runs over slots [0, row0+M) - the prefix K/V of rows [0,row0) must already be in kv_cache.
         bufs (alloc_ctx_bufs): saved activations are written into rows [row0, row0+M) of these buffers instead of fresh tensors.
+        tail_from (packed row index): the caller reads the stack's output only at rows >= tail_from (log-probs: the last prompt row and the completion
+        rows; rollout prefill: the last prompt row).  The LAST layer's o projection and MLP then run on those rows only - the other rows' outputs feed
+        nothing (their K / V, which later rows and the decode do read, come from the layer's input) - and rows < tail_from of the returned tensor and of the
+        last layer's saved h2 / xn2 / gu / a / rstd2 are undefined; llm_bwd skips them the same way (their gradient is exactly zero).
         Returns (h_out, ctx) where ctx holds the saved activations when save=True."""
         ops, t = self.ops, self.cfg.text
         M = h.shape[0]
         S = row0 + M
+        t0 = 0 if (tail_from is None or not self.TAIL_SKIP) else max(0, min(int(tail_from) - row0, M - 1))
         pre, lo, hi = masks
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
         scale = hd ** -0.5
@@ -384,6 +391,27 @@ class Engine:
                 k_all = k
             o, lse = ops.attn_fwd(q, k_all, vt, pre, lo, hi, t.n_heads, t.n_kv_heads, S, hd, scale, need_lse=save, out=dst(i, "o"),
                                   **({"v_rows": v_rows} if v_rows is not None else {}))
+            if t0 > 0 and i == t.n_layers - 1:       # last layer: only rows >= tail_from go on (see the docstring)
+                tl = lambda x: None if x is None else x[t0:]
+                h2t = ops.gemm_nt(o[t0:], arena.w(p + "o.w"), residual=h[t0:], out=tl(dst(i, "h2")))
+                xn2t, rstd2t, _ = ops.rmsnorm_fwd(h2t, arena.w(p + "ln2"), t.rms_eps, need_rstd=save, out=tl(dst(i, "xn2")), rstd_out=tl(dst(i, "rstd2")))
+                at, gut = ops.gemm_glu(xn2t, arena.w(p + "gu.w"), a_out=tl(dst(i, "a")), gu_out=tl(dst(i, "gu")), save_gu=save)
+                h_out = ops.empty(M, t.hidden)
+                ops.gemm_nt(at, arena.w(p + "down.w"), residual=h2t, out=h_out[t0:])
+                if save:
+                    def full(x_t, key, **kw):         # [M, .] views for the backward: the shared buffers when there are some, else a tensor whose head is never read
+                        if x_t is None:
+                            return None
+                        if inplace:
+                            return bufs[i][key][row0:S]
+                        f = ops.empty(M, *x_t.shape[1:], **kw)
+                        f[t0:] = x_t
+                        return f
+                    h2, xn2, a, gu = full(h2t, "h2"), full(xn2t, "xn2"), full(at, "a"), full(gut, "gu")
+                    rstd2 = full(rstd2t, "rstd2", dtype=F32)
+                    layers.append(dict(h=h, rstd1=rstd1, xn=xn, v=v, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
+                h = h_out
+                continue
             h2 = ops.gemm_nt(o, arena.w(p + "o.w"), residual=h, out=dst(i, "h2"))
             xn2, rstd2, _ = ops.rmsnorm_fwd(h2, arena.w(p + "ln2"), t.rms_eps, need_rstd=save, out=dst(i, "xn2"), rstd_out=dst(i, "rstd2"))
             a, gu = ops.gemm_glu(xn2, arena.w(p + "gu.w"), a_out=dst(i, "a"), gu_out=dst(i, "gu"), save_gu=save)     # SwiGLU in the GEMM epilogue
@@ -391,7 +419,7 @@ class Engine:
             if save:
                 layers.append(dict(h=h, rstd1=rstd1, xn=xn, v=v, q=q, k=k, o=o, lse=lse, h2=h2, rstd2=rstd2, xn2=xn2, gu=gu, a=a))
             h = h_out
-        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin, h_last=h, bufs=bufs if inplace else None) if save else None
+        ctx = dict(layers=layers, masks=masks, cos=cos, sin=sin, h_last=h, bufs=bufs if inplace else None, tail_from=row0 + t0) if save else None
         return h, ctx
 
     @staticmethod
@@ -409,7 +437,8 @@ class Engine:
             L["k"] = kv_cache[i][0][:M]
             layers.append(L)
             ctx_a["layers"][i] = ctx_b["layers"][i] = None
-        return dict(layers=layers, masks=masks, cos=cos, sin=sin)
+        # (rows >= ctx_a's tail_from carry the last layer's MLP activations: the continuation ran all of its rows)
+        return dict(layers=layers, masks=masks, cos=cos, sin=sin, tail_from=min(int(ctx_a.get("tail_from", 0)), int(ctx_b.get("tail_from", 0))))
 
     def llm_bwd(self, ctx, dh, on_layer_done=None):
         """dh: gradient wrt the decoder stack output [M, d]. Accumulates parameter grads; returns the gradient wrt the input embeddings.
@@ -421,10 +450,18 @@ class Engine:
         scale = hd ** -0.5
         side = self._side_stream()
         pending = None
+        t0 = int(ctx.get("tail_from", 0) or 0)      # rows < t0 never went through the last layer's o projection / MLP (llm_fwd tail_from): dh is zero there
         for i in reversed(range(t.n_layers)):
             p = "l%d." % i
             L = ctx["layers"][i]
             M = dh.shape[0]
+            tail = t0 > 0 and i == t.n_layers - 1
+            if tail:
+                dh_full, Lf = dh, L
+                dh = dh[t0:]
+                L = dict(L)
+                for key in ("a", "gu", "xn2", "h2", "rstd2", "o"):
+                    L[key] = Lf[key][t0:]
             # h_out = a @ Wd^T + h2
             _sync = self.wgrad_on_main
             self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side, key=p + "down.w")
@@ -436,6 +473,10 @@ class Engine:
             # h2 = o @ Wo^T + h
             self._wgrad_async(dh2, L["o"], tr.g(p + "o.w"), None if "o" in _sync else side, key=p + "o.w")
             do = self._dgrad(dh2, tr.w(p + "o.w"), key=p + "o.w")
+            if tail:                                  # back to all rows for the attention backward (every row's K / V took part): zero gradient above the tail
+                L = Lf
+                z = ops.zeros(M, qd); z[t0:] = do; do = z
+                z = ops.zeros(M, t.hidden); z[t0:] = dh2; dh2 = z
             dqkv = ops.empty(M, t.qkv_dim)
             # attention backward writes dq | dk | dv straight into the columns of dqkv, dq and dk already rotated back (M-RoPE backward in the
             # kernels' epilogues); the bias gradient is summed by the transpose that feeds the weight gradient
