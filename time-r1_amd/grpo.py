@@ -186,7 +186,7 @@ class GRPOCore:
             st.prefill = None
         else:
             h0 = eng.embed(tr, st.ids_packed, st.vid_embeds, st.vid_rows)
-            hL, st.llm_ctx = eng.llm_fwd(tr, h0, st.cos, st.sin, st.masks, save=True, tail_from=st.P - 1)    # the head reads rows >= P - 1 only (pred_rows)
+            hL, st.llm_ctx = eng.llm_fwd(tr, h0, st.cos, st.sin, st.masks, save=True, tail_from=eng.tail_rows_from(st.P, st.layout.M))    # the head reads rows >= P - 1 only (pred_rows)
         logp, ent, st.head_ctx = eng.head_fwd(tr, hL, st.pred_rows, st.targets, save=True)
         st.logp = self._to_gc(st, logp).contiguous()
         st.entropy = self._to_gc(st, ent).contiguous()
@@ -195,7 +195,7 @@ class GRPOCore:
             ra = self.ref_arena
             ref_vid, _ = eng.merger_fwd(ra, st.feats, save=False, perm=st.vis_perm)
             h0r = eng.embed(ra, st.ids_packed, ref_vid, st.vid_rows)
-            hLr, _ = eng.llm_fwd(ra, h0r, st.cos, st.sin, st.masks, save=False, tail_from=st.P - 1)
+            hLr, _ = eng.llm_fwd(ra, h0r, st.cos, st.sin, st.masks, save=False, tail_from=eng.tail_rows_from(st.P, st.layout.M))
             rlogp, _, _ = eng.head_fwd(ra, hLr, st.pred_rows, st.targets, save=False)
             st.ref_logp = self._to_gc(st, rlogp).contiguous()
 

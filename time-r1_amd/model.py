@@ -335,6 +335,15 @@ class Engine:
 
     TAIL_SKIP = os.environ.get("TR1_TAIL_SKIP", "1") != "0"     # A/B switch for `tail_from` (0: every row runs the whole last layer)
 
+    def tail_rows_from(self, P, M):
+        """The `tail_from` a caller should pass for a packed sequence of P prompt rows in M rows, or None: the saving is the prompt's share of ONE layer, and
+        the last layer's shorter tensors are sizes of their own in the caching allocator (~3 GB of blocks the other layers cannot reuse at config 4, where
+        the prompt is a sixth of the rows and HBM is nearly full: allocator retries, backward 0.64 -> 2.2 s) - so only where the prompt dominates and the
+        sequence is not in the stashed-prefill regime.  Prefill, update forward and backward of one sequence must all use this one answer."""
+        if not self.TAIL_SKIP or P < 2 or (P - 1) < 0.4 * M or self.ctx_bytes(M) > self.CTX_STASH_GB * 1e9:
+            return None
+        return P - 1
+
     def llm_fwd(self, arena: Arena, h, cos, sin, masks, save, kv_cache=None, row0=0, bufs=None, tail_from=None):
         """Decoder stack over a packed sequence of M rows. masks = (pre, lo, hi) int32 [M] over slots == rows.
         kv_cache: optional list of (K [S_cap, kv_dim], VT [kv_dim, S_cap]) to be filled (rollout prefill).
@@ -450,6 +459,7 @@ class Engine:
         scale = hd ** -0.5
         side = self._side_stream()
         pending = None
+        big_seq = self.ctx_bytes(dh.shape[0]) > self.CTX_STASH_GB * 1e9
         t0 = int(ctx.get("tail_from", 0) or 0)      # rows < t0 never went through the last layer's o projection / MLP (llm_fwd tail_from): dh is zero there
         for i in reversed(range(t.n_layers)):
             p = "l%d." % i
@@ -466,7 +476,9 @@ class Engine:
             _sync = self.wgrad_on_main
             self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side, key=p + "down.w")
             # down-projection dgrad with the SwiGLU backward in its epilogue, which also leaves dgu^T (the gate/up weight gradient's operand) from its LDS staging
-            dgu, dgut = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"], want_t=True)
+            # (not in the large-sequence regime: dgu^T is allocated on this stream and consumed on the side stream, so the caching allocator holds its blocks
+            # longer - +3 GB at config 4, where that tips a 250 GB step into allocator retries; there the side stream builds the transpose as before)
+            dgu, dgut = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"], want_t=True) if not big_seq else (ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"]), None)
             self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side, key=p + "gu.w", dyt=dgut)
             dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"), key=p + "gu.w")
             dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))

@@ -119,7 +119,7 @@ class Rollout:
             # save_prefill: the prompt rows' activations go straight into [P + G*C, .] buffers that the update's continuation forward completes
             bufs, is_stash = eng.alloc_ctx_bufs(lay.M, slot=b, prefill_rows=P) if save_prefill else (None, False)
             # (only the last prompt row's output is read: first-token logits here, the first prediction row of the update later)
-            hL, pctx = eng.llm_fwd(arena, h, cos, sin, masks, save=save_prefill, kv_cache=kv_views, bufs=bufs, tail_from=P - 1)
+            hL, pctx = eng.llm_fwd(arena, h, cos, sin, masks, save=save_prefill, kv_cache=kv_views, bufs=bufs, tail_from=eng.tail_rows_from(P, lay.M))
             if is_stash:
                 pctx["stash"] = True
             hn, _, _ = ops.rmsnorm_fwd(hL[P - 1:P], arena.w("norm"), t.rms_eps, need_rstd=False)
