@@ -33,6 +33,13 @@ for n, (i0, i1) in enumerate(slices):
     for s_, e_, _, st_ in seg:
         per[st_] += e_ - s_
     print("   per stream/queue busy ms:", {k: round(v / 1e6, 2) for k, v in per.items()})
+    gaps, cur, prev = [], t0, rows[i0][2]
+    for s_, e_, k_, st_ in sorted(seg):
+        if s_ > cur:
+            gaps.append((s_ - cur, prev, k_))
+        if e_ > cur:
+            cur, prev = e_, k_
+    print("   largest idle gaps (us, after kernel -> before kernel):", [(round(g / 1e3, 1), a_[:28], b_[:28]) for g, a_, b_ in sorted(gaps, reverse=True)[:14]])
     print("slice %d: wall %.2f ms, some kernel running %.2f ms, idle %.2f ms, %d launches" % (n, (t1 - t0) / 1e6, busy / 1e6, (t1 - t0 - busy) / 1e6, len(seg)))
     for (k, st), (c, d) in sorted(tot.items(), key=lambda x: -x[1][1])[:int(sys.argv[4]) if len(sys.argv) > 4 else 14]:
         print("   %-70s %-6s %5d x %9.1f us = %8.2f ms" % (k, st, c, d / c / 1e3, d / 1e6))
