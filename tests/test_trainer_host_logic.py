@@ -358,3 +358,22 @@ def test_rollout_drift_metric_and_importance_cap_flag():
     w = m / m.sum(1, keepdim=True) / fx["G"]
     want = outs["plain"][0] + float(((1 - seen["w"]) * seen["adv"][:, None] * w).sum())
     assert abs(loss - want) < 1e-5 and abs(tr._metrics["rollout_logp_drift"][0] - 0.5) < 1e-3
+
+
+def test_tail_row_skip_is_chosen_per_layout_and_consistently():
+    """Engine.tail_rows_from: the last layer runs its o projection / MLP on the rows the head reads only where the prompt dominates the packed sequence and the
+    sequence is not in the stashed-prefill regime (config 3: yes; config 4, 19 650 rows of which a sixth is prompt: no - there the extra tensor sizes cost more in the
+    caching allocator than the skipped rows save).  Prefill, update forward and backward ask the same function, so they cannot disagree."""
+    from time_r1_amd.config import PRESETS
+    from time_r1_amd.model import Engine
+    eng = Engine.__new__(Engine)
+    eng.cfg = PRESETS["qwen2-vl-7b"]()
+    assert eng.tail_rows_from(3474, 3474 + 8 * 200) == 3473            # config 3
+    assert eng.tail_rows_from(3266, 3266 + 16 * 1024) is None          # config 4: prompt share 17 %
+    assert eng.tail_rows_from(1, 9) is None and eng.tail_rows_from(100, 1000) is None
+    old = Engine.TAIL_SKIP
+    try:
+        Engine.TAIL_SKIP = False
+        assert eng.tail_rows_from(3474, 5074) is None
+    finally:
+        Engine.TAIL_SKIP = old
