@@ -154,6 +154,14 @@ int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, 
  * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */
 int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
 int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch);
+/* Optional merged form (TR1_DEC_MERGE=1 / tr1_attn_dec_merge(1); OFF by default: measured slower than the two launches): plan_mode 2 launches at
+ * head dim 128 whose whole grid fits the GPU at once (n_batch * n_kv * query tiles * nsplit <= CUs: model.generate's step at BASELINE config 3) merge the split
+ * partials inside the attention kernel (the nsplit blocks of a row group meet at a counter; same operations in the same order as the separate merge launch,
+ * bit-identical O).  The wait is bounded: a block that gave up raises a flag - this returns 1 if that happened since the last call (the step's output is then
+ * wrong: raise), else 0.  Synchronous (4-byte device-to-host copy). */
+int tr1_attn_merge_error(void);
+/* on = 1 / 0: merged form on / off from now on (default: TR1_DEC_MERGE, 0); on < 0: query only.  Returns the previous setting. */
+int tr1_attn_dec_merge(int on);
 /* Backward of the above (recompute based): needs K, V row-major.  KT / kt_ld are kept for ABI stability and ignored (may be NULL / 0): the dQ
  * kernel reads its K^T fragments from the K rows with ds_read_b64_tr_b16.  QT / dOT (tr1_pack_transpose copies) only for head dims padded to
  * 32 or 96 (may be NULL for 64 / 128: the 8-wave dK/dV kernel transposes in its LDS reads the same way).

@@ -707,6 +707,45 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
 
+@pytest.mark.parametrize("B,G,nh,nkv,nsplit", [(2, 8, 28, 4, 28), (3, 8, 14, 2, 12), (1, 16, 14, 2, 28), (2, 5, 12, 4, 7), (1, 8, 4, 4, 64)])
+def test_attention_decode_merged_in_kernel_equals_the_two_launch_form(hip_ops, B, G, nh, nkv, nsplit):
+    """Plan-reading decode attention whose grid fits the GPU at once merges the split partials inside the kernel (the blocks of a row group meet at a
+    counter pair): bit-identical to partials + attn_combine_kernel (same merge operations in the same order), launch after launch (the pair re-arms itself),
+    with one and with two query tiles, with and without the LSE; no time-out flag."""
+    hd, C, step = 128, 12, 5
+    Ps = [300, 170, 420][:B]
+    s_cap = 576
+    k, v = rnd(B * s_cap, nkv * hd, seed=1).cuda(), rnd(B * s_cap, nkv * hd, seed=2)
+    pre = torch.cat([torch.full((G,), P, dtype=torch.int32) for P in Ps]).cuda()
+    lo = torch.cat([(P + torch.arange(G) * C).int() for P in Ps]).cuda()
+    hi = (lo + step).int()
+    vt = torch.zeros(nkv * hd, B * s_cap, dtype=BF16, device="cuda:0")
+    for b in range(B):
+        vt[:, b * s_cap:(b + 1) * s_cap] = hip_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].cuda(), nkv, nkv, hd)
+    plan = hip_ops.attn_plan(G, nh, nkv, B)
+    q0 = rnd(B * G, nh * hd, seed=3).cuda()
+    hip_ops.attn_fwd(q0, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=1)
+    raw = hip_ops.L.raw("tr1_attn_dec_merge")
+    prev = raw(-1)
+    try:
+        for rep in range(3):                                     # "layers" of a step: new q every time, same masks and plan
+            q = rnd(B * G, nh * hd, seed=10 + rep).cuda()
+            for lse in (False, True):
+                outs = []
+                for on in (0, 1, 1):
+                    raw(on)
+                    o, l = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=lse, n_batch=B,
+                                            kv_batch_slots=s_cap, plan=plan, plan_mode=2)
+                    outs.append((o.clone(), None if l is None else l.clone()))
+                for o, l in outs[1:]:
+                    assert torch.equal(o, outs[0][0]), "merged decode attention differs from partials + combine"
+                    assert (l is None) == (outs[0][1] is None) and (l is None or torch.equal(l, outs[0][1]))
+    finally:
+        raw(prev)
+    assert hip_ops.L.raw("tr1_attn_merge_error")() == 0
+    hip_ops.attn_merge_check()
+
+
 def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):
     """A reader block holds one plan entry per thread: with few splits and many relevant tiles (n_rel > 256 * nsplit) the publishing launch stores
     count -1 and the reading launches take the full path - the same result."""

@@ -52,10 +52,34 @@ struct AttnParams {
     // backward only: when set, dQ and dK leave the kernels already multiplied by the TRANSPOSED rotary matrix (the backward of M-RoPE, TF:212-222):
     // fp32 cos / sin tables [T, d / 2]; row t of dQ and slot t of dK use row t
     const float* rope_cos; const float* rope_sin;
+    // split-KV decode, merged form (attn_dec32_kernel): when set, the nsplit blocks of a (batch entry, kv head, query tile) meet at a counter pair
+    // [arrived, done] per group and merge their partials themselves (no attn_combine launch); merge_err receives 1 if a block gave up waiting
+    int* merge_cnt; int* merge_err;
 };
 
 #define ATT_KV 64          // keys per tile
 #define NEG_INF (-INFINITY)
+
+// ---- merge of split-KV partials: attn_combine_kernel and the merged tail of attn_dec32_kernel run THESE operations in this order (bit-identical results)
+TR1_DEV void att_merge_stats(const float* m_row, const float* l_row, int nsplit, float& M, float& Ms, float& L) {
+    M = NEG_INF;
+    for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, m_row[sp]);
+    Ms = (M == NEG_INF) ? 0.f : M;
+    L = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) L = __builtin_fmaf(exp2f(m_row[sp] - Ms), l_row[sp], L);
+}
+// the share of split group sg (splits sg, sg + 4, ...) in one row's weighted sum; ov[i] = the partial row of split sg + 4 i (anything when that split does not exist)
+TR1_DEV f32x4_t att_merge_weighted(const f32x4_t (&ov)[16], const float* m_row, float Ms, int sg, int nsplit) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int sp = sg + 4 * i;
+        const float w = sp < nsplit ? exp2f(m_row[sp < 64 ? sp : 0] - Ms) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(w, ov[i][j], acc[j]);
+    }
+    return acc;
+}
 
 TR1_DEV bf16x8_t make_frag(u32x2_t a, u32x2_t b) {
     u32x4_t w = {a[0], a[1], b[0], b[1]};

@@ -361,19 +361,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
         sm_l[r][sp] = (Rr < nR) ? p.lpart[slot] : 0.f;
     }
     __syncthreads();
-    float M = NEG_INF;
-    for (int sp = 0; sp < p.nsplit; ++sp) M = fmaxf(M, sm_m[rl][sp]);
-    const float Ms = (M == NEG_INF) ? 0.f : M;
-    float L = 0.f;
-    for (int sp = 0; sp < p.nsplit; ++sp) L += exp2f(sm_m[rl][sp] - Ms) * sm_l[rl][sp];
+    float M, Ms, L;
+    att_merge_stats(sm_m[rl], sm_l[rl], p.nsplit, M, Ms, L);
     const float inv = L > 0.f ? 1.f / L : 0.f;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int sp = sg + 4 * i;
-        const float w = sp < p.nsplit ? exp2f(sm_m[rl][sp < 64 ? sp : 0] - Ms) : 0.f;
-        acc += w * ov[i];
-    }
+    f32x4_t acc = att_merge_weighted(ov, sm_m[rl], Ms, sg, p.nsplit);
     part[rl][sg][c] = acc;
     __syncthreads();
     if (!act || sg != 0) return;
@@ -453,7 +444,7 @@ __global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_
     }
 }
 
-bool tr1_launch_attn_dec32(const AttnParams& p, dim3 grid, hipStream_t s);      // attn_fwd32.hip
+int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s);      // attn_fwd32.hip: 0 not launched, 1 launched (partials: combine follows), 2 launched and merged
 
 template <int D, int CB, int PF>
 static void launch_fwd(dim3 grid, hipStream_t s, const AttnParams& p) {
@@ -517,7 +508,8 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
         grid = dim3((unsigned)p.xcd_pad, 1, 1);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (decode && tr1_launch_attn_dec32(p, grid, s)) {
+    const int dec32 = decode ? tr1_launch_attn_dec32(p, grid, s) : 0;
+    if (dec32) {
         // head dim 128 reading the per-step plan: the LDS-DMA kernel of attn_fwd32.hip (all of a block's tiles in flight at once)
     } else if (decode) {
         switch (d_pad) {
@@ -534,7 +526,7 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
             default: launch_fwd<128, 2, 1>(grid, s, p); break;
         }
     }
-    if (nsplit > 1) {
+    if (nsplit > 1 && dec32 != 2) {
         dim3 cg((unsigned)((nR + ATT_COMBINE_ROWS - 1) / ATT_COMBINE_ROWS), (unsigned)(n_kv * n_batch));
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;

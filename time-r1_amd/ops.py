@@ -58,6 +58,12 @@ class HipOps:
             torch.cuda.set_stream(self._main_stream)
         return self._main_stream
 
+    def attn_merge_check(self):
+        """Call where the host already waits for a rollout (the sampled tokens' device-to-host copy): raises if a merged decode attention launch gave up
+        waiting for a partner block (tr1_attn_merge_error) - the tokens drawn after that point are not the model's."""
+        if self.L.raw("tr1_attn_merge_error")() != 0:
+            raise RuntimeError("decode attention (merged split-KV form): a block timed out waiting for its partner blocks; rerun with TR1_DEC_MERGE=0")
+
     def probe_hbm_read(self, buf, sink):
         """Measurement helper: one streaming read of `buf` (bench.py times it)."""
         self.L.call("tr1_probe_hbm_read", _p(buf), buf.numel() * buf.element_size(), _p(sink), self._s())
