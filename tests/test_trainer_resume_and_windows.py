@@ -164,4 +164,17 @@ def test_stashed_prefill_window_equals_full_slot_window(monkeypatch):
         pool = tr.engine._ctx_pool
         assert (("stash", 1) in pool) == (gb == 0.0) and ((1 in pool) == (gb != 0.0))
         grads.append(tr.params.train.grad.clone())
-    assert float(grads[0].abs().max()) > 0 and torch.equal(grads[0], grads[1])
+    # (the large-sequence regime also runs every row through the last layer - Engine.tail_rows_from - so the two windows differ in fp32 summation
+    # order there, not in what is summed)
+    diff = float((grads[0] - grads[1]).abs().max())
+    assert float(grads[0].abs().max()) > 0 and diff < 1e-6 * max(1.0, float(grads[0].abs().max()) * 1e3), diff
+    monkeypatch.setattr(Engine, "TAIL_SKIP", False)      # with the row skip off in both, the stash is a pure memory scheme: bit-identical
+    g2 = []
+    for gb in (40.0, 0.0):
+        monkeypatch.setattr(Engine, "CTX_STASH_GB", gb)
+        cfg, tr = make_trainer(fx, ga=2, rollout_batching=True)
+        tr.train_dataset = _dataset(fx, 2)
+        tr.train_dataset.rows[1]["video_frames"] = torch.randint(0, 256, (4, 3, 84, 112), generator=torch.Generator().manual_seed(9), dtype=torch.uint8).float()
+        tr.accumulation_window([[tr.train_dataset[0]], [tr.train_dataset[1]]])
+        g2.append(tr.params.train.grad.clone())
+    assert torch.equal(g2[0], g2[1])
