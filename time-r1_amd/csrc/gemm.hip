@@ -222,6 +222,15 @@ TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, co
 #ifndef TR1_EPI_LDS
 #define TR1_EPI_LDS 1
 #endif
+// TR1_EPI_NT=1 (measurement builds): the epilogue's C stores carry the non-temporal hint
+#ifndef TR1_EPI_NT
+#define TR1_EPI_NT 0
+#endif
+#if TR1_EPI_NT
+#define TR1_EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define TR1_EPI_STORE(ptr, val) (*(ptr) = (val))
+#endif
 // EPI = 1 ("lm_head -> log-prob / entropy"): nothing is stored to C.  The wave's 64 columns of a row are rounded to bf16 (the logits the
 // reference materialises are bf16) and reduced to the online-softmax triple (max, sum e^(x-max), sum x e^(x-max)); lane c8 = 0 of a row writes it to
 // part[row][ncol0 / 64] (Cv = float4 partials, ldc = column blocks per row, +1 slot per row for the target's logit), and the lane that holds
@@ -262,7 +271,7 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                         }
                         float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
                         if (ACCUM) v += *reinterpret_cast<const f32x4_t*>(cp);
-                        *reinterpret_cast<f32x4_t*>(cp) = v;
+                        TR1_EPI_STORE(reinterpret_cast<f32x4_t*>(cp), v);
                         ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     }
                 }
@@ -321,7 +330,7 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                         u32x4_t o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-                        *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(Cv) + m * ldc + n) = o;
+                        TR1_EPI_STORE(reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(Cv) + m * ldc + n), o);
                     }
                 }
             }
@@ -893,6 +902,9 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 #undef COMPUTE
 #undef STAGE_A
 #undef STAGE_B
+#ifdef TR1_PROBE_NO_EPI      // measurement build (tools/build_variant.py noepi -DTR1_PROBE_NO_EPI=1): the tile ends here, nothing is stored - what the epilogue costs
+    if (K > 0) return;
+#endif
 #if TR1_EPI_LDS
     // every wave is past its last LDS read (the realignment barrier above): the operand buffers become 8 private staging slices
     if (EPI == 2 || EPI == 7 || (EPI == 4 && n0 < (int64_t)ep.i0 + ep.i1))
