@@ -101,6 +101,7 @@ class HipOps:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _workspace(self, key, numel, dtype):
+        key = (key, self._s())            # one scratch buffer per (purpose, stream): launches on different streams may overlap
         t = self._ws.get(key)
         if t is None or t.numel() < numel or t.dtype != dtype:
             t = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
