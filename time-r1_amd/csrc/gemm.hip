@@ -1097,6 +1097,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* _
                 for (int ks = 0; ks < 4; ++ks)
                     t[ks] = __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v = ((t[0] + t[1]) + t[2]) + t[3];
+            } else if (gridDim.y <= 16) {   // up to 16 slabs: every load in flight before the first add, summed in slab order (what the loop below computes)
+                float t[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    t[ks] = ks < (int)gridDim.y ? __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                v = t[0];
+#pragma unroll
+                for (int ks = 1; ks < 16; ++ks) if (ks < (int)gridDim.y) v += t[ks];
             } else {
                 for (int ks = 0; ks < (int)gridDim.y; ++ks)
                     v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2607,6 +2615,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
             for (int ks = 0; ks < 4; ++ks)
                 t[ks] = __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v = ((t[0] + t[1]) + t[2]) + t[3];
+        } else if (gridDim.y <= 16) {       // up to 16 slabs: every load in flight before the first add, summed in slab order (what the loop below computes)
+            float t[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                t[ks] = ks < (int)gridDim.y ? __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            v = t[0];
+#pragma unroll
+            for (int ks = 1; ks < 16; ++ks) if (ks < (int)gridDim.y) v += t[ks];
         } else {
             for (int ks = 0; ks < (int)gridDim.y; ++ks)
                 v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2628,7 +2644,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
 static int skinny_fix_cfg(int64_t M, int64_t N, int64_t K, int* ncol, int* mg) {
     *mg = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     *ncol = (K >= 8192 && *mg <= 2) ? 4 : 2;
-    return K >= 2048 ? 4 : 1;
+    int ks = K >= 2048 ? 4 : 1;
+    // Few column groups (a narrow output over a long K - the Qwen2-VL-2B down projection: 1536 / 64 = 24 groups x 4 slabs = 96 blocks on 256 CUs, 2.1 TB/s): as
+    // many K slabs (<= 16, whole 64-k stages each) as still give at most one block per CU - 24 x 10 = 240 blocks there.  TR1_DOWN_KS=4 keeps the four slabs.
+    static int ks_max = -1;
+    if (ks_max < 0) { const char* e = getenv("TR1_DOWN_KS"); ks_max = e ? atoi(e) : 16; }
+    const int64_t groups = (N + 16 * *ncol - 1) / (16 * *ncol);
+    if (ks == 4 && *mg == 1 && groups * 4 < 192)
+        for (int cand = 5; cand <= ks_max && cand <= 16; ++cand)
+            if (K % ((int64_t)cand * 64) == 0 && groups * cand <= 256) ks = cand;
+    return ks;
 }
 
 // 56-column blocks for the LDS-streamed <= 16-row form when that is what fills the chip: N % 56 == 0 and N/56 x ks <= 256 < more blocks than N/64 x ks
