@@ -191,7 +191,6 @@ class Workload:
             core.rollout_many(states)
             for st in states:
                 st.completion_ids_host = st.completion_ids.cpu().numpy()     # one wait for the decode loop, ahead of every update
-                getattr(self.ops, "attn_merge_check", lambda: None)()
             for si, st in enumerate(states):
                 self._finish(st, si == n - 1, n)
         self.opt.step()

@@ -67,10 +67,6 @@ int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void
 /* Weight gradient without the X^T copy: C[M,N] fp32 (+)= A[M,K] B[K,N], B K-major with only its first b_rows rows valid (A = dY^T zero-padded to
  * K = tokens rounded up to 64, B = the saved activation as stored).  ref: autograd of nn.Linear inside HF Trainer.training_step (TF trainer.py:1892-1961). */
 int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int64_t b_rows, void* stream);
-/* Weight gradient with BOTH operands as the backward pass holds them (no dY^T, no X^T): C[N,K] fp32 (+)= dY[T,N]^T X[T,K], dY / X row-major bf16
- * (token = row).  N, K multiples of 256; T * ld * 2 < 4 GiB.  ref: grad_weight = grad_output^T @ input of every nn.Linear under loss.backward()
- * (src/time_r1/rl/timer1_trainer.py:709 -> HF Trainer.training_step, TF trainer.py:1892-1961). */
-int tr1_gemm_tn_acc_f32(const void* dY, const void* X, void* C_f32, int64_t T, int64_t N, int64_t K, int64_t ldp, int64_t ldq, int64_t ldc, int accumulate, void* stream);
 /* Decode-step fusion (M <= 64 rows): out = rmsnorm(x; lnw, eps) @ W[N,K]^T (+ bias), the norm folded into the GEMM's operand load
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
  * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */
@@ -79,10 +75,6 @@ int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const vo
  * roped q -> q_out[M, n_heads*hd]; roped k -> kcache[slots[m], :]; v -> vtcache[:, slots[m]].  Wqkv: [(n_heads + 2 n_kv)*hd, K] (q | k | v rows).
  * ref: Qwen2VLAttention.forward TF:521-556 + DynamicCache.update inside generate (timer1_trainer.py:568-573).  head_dim % 32 == 0. */
 int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* stream);
-/* The same launch for <= 16 decode rows on twice the blocks (two per rotate-half column-group pair, split over K, ticketed in-kernel fixup):
- * bit-identical results, all 256 CUs streaming.  ws_f32: tr1_norm_gemm_qkv_split_workspace_floats() floats, zero-initialised once by the caller. */
-int tr1_norm_gemm_qkv_split(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* ws_f32, int64_t ws_floats, void* stream);
-int64_t tr1_norm_gemm_qkv_split_workspace_floats(int64_t n_heads, int64_t n_kv, int64_t head_dim);
 /* Narrow decode projections (o_proj / down_proj at M <= 64 rows): C = A B^T (+bias)(+residual) with cross-block split-K and an in-kernel
  * fixup (the last block of a column group sums the fp32 partial tiles).  ws_f32: tr1_gemm_skinny_fixup_workspace_floats() floats whose
  * trailing ticket counters must be ZERO before the first call (the kernel re-arms them).  Same call sites as tr1_gemm_nt_bf16 in generate. */
@@ -154,14 +146,6 @@ int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, 
  * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */
 int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
 int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch);
-/* Optional merged form (TR1_DEC_MERGE=1 / tr1_attn_dec_merge(1); OFF by default: measured slower than the two launches): plan_mode 2 launches at
- * head dim 128 whose whole grid fits the GPU at once (n_batch * n_kv * query tiles * nsplit <= CUs: model.generate's step at BASELINE config 3) merge the split
- * partials inside the attention kernel (the nsplit blocks of a row group meet at a counter; same operations in the same order as the separate merge launch,
- * bit-identical O).  The wait is bounded: a block that gave up raises a flag - this returns 1 if that happened since the last call (the step's output is then
- * wrong: raise), else 0.  Synchronous (4-byte device-to-host copy). */
-int tr1_attn_merge_error(void);
-/* on = 1 / 0: merged form on / off from now on (default: TR1_DEC_MERGE, 0); on < 0: query only.  Returns the previous setting. */
-int tr1_attn_dec_merge(int on);
 /* Backward of the above (recompute based): needs K, V row-major.  KT / kt_ld are kept for ABI stability and ignored (may be NULL / 0): the dQ
  * kernel reads its K^T fragments from the K rows with ds_read_b64_tr_b16.  QT / dOT (tr1_pack_transpose copies) only for head dims padded to
  * 32 or 96 (may be NULL for 64 / 128: the 8-wave dK/dV kernel transposes in its LDS reads the same way).

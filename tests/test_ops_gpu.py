@@ -706,46 +706,6 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             cnt = plan.view(B, -1, 1025)[:, :, 1024]
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
-
-@pytest.mark.parametrize("B,G,nh,nkv,nsplit", [(2, 8, 28, 4, 28), (3, 8, 14, 2, 12), (1, 16, 14, 2, 28), (2, 5, 12, 4, 7), (1, 8, 4, 4, 64)])
-def test_attention_decode_merged_in_kernel_equals_the_two_launch_form(hip_ops, B, G, nh, nkv, nsplit):
-    """Plan-reading decode attention whose grid fits the GPU at once merges the split partials inside the kernel (the blocks of a row group meet at a
-    counter pair): bit-identical to partials + attn_combine_kernel (same merge operations in the same order), launch after launch (the pair re-arms itself),
-    with one and with two query tiles, with and without the LSE; no time-out flag."""
-    hd, C, step = 128, 12, 5
-    Ps = [300, 170, 420][:B]
-    s_cap = 576
-    k, v = rnd(B * s_cap, nkv * hd, seed=1).cuda(), rnd(B * s_cap, nkv * hd, seed=2)
-    pre = torch.cat([torch.full((G,), P, dtype=torch.int32) for P in Ps]).cuda()
-    lo = torch.cat([(P + torch.arange(G) * C).int() for P in Ps]).cuda()
-    hi = (lo + step).int()
-    vt = torch.zeros(nkv * hd, B * s_cap, dtype=BF16, device="cuda:0")
-    for b in range(B):
-        vt[:, b * s_cap:(b + 1) * s_cap] = hip_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].cuda(), nkv, nkv, hd)
-    plan = hip_ops.attn_plan(G, nh, nkv, B)
-    q0 = rnd(B * G, nh * hd, seed=3).cuda()
-    hip_ops.attn_fwd(q0, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=1)
-    raw = hip_ops.L.raw("tr1_attn_dec_merge")
-    prev = raw(-1)
-    try:
-        for rep in range(3):                                     # "layers" of a step: new q every time, same masks and plan
-            q = rnd(B * G, nh * hd, seed=10 + rep).cuda()
-            for lse in (False, True):
-                outs = []
-                for on in (0, 1, 1):
-                    raw(on)
-                    o, l = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=lse, n_batch=B,
-                                            kv_batch_slots=s_cap, plan=plan, plan_mode=2)
-                    outs.append((o.clone(), None if l is None else l.clone()))
-                for o, l in outs[1:]:
-                    assert torch.equal(o, outs[0][0]), "merged decode attention differs from partials + combine"
-                    assert (l is None) == (outs[0][1] is None) and (l is None or torch.equal(l, outs[0][1]))
-    finally:
-        raw(prev)
-    assert hip_ops.L.raw("tr1_attn_merge_error")() == 0
-    hip_ops.attn_merge_check()
-
-
 def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):
     """A reader block holds one plan entry per thread: with few splits and many relevant tiles (n_rel > 256 * nsplit) the publishing launch stores
     count -1 and the reading launches take the full path - the same result."""
@@ -900,19 +860,6 @@ def test_norm_gemm_qkv_fused(hip_ops, ref_ops, R, nh, nkv, hd, K):
     slots = torch.randperm(S, generator=torch.Generator().manual_seed(6))[:R].int()
     kc0, vt0 = rnd(S, nkv * hd, seed=7), rnd(nkv * hd, S, seed=8)
     outs = []
-    if R <= 16 and K >= 512:      # the two-blocks-per-pair form with the ticket fixup (TR1_QKV_SPLIT=1): bit-identical to the one-block launch, twice in a row
-        import os                 # (the second launch runs on the re-armed ticket counters)
-        plain = []
-        for flag in ("0", "1", "1"):
-            os.environ["TR1_QKV_SPLIT"] = flag
-            try:
-                kc, vt = kc0.clone().cuda(), vt0.clone().cuda()
-                q = hip_ops.norm_gemm_qkv(x.cuda(), lnw.cuda(), 1e-6, w.cuda(), b.cuda(), cos, sin, kc, vt, slots.cuda(), nh, nkv, hd)
-                plain.append((q.cpu(), kc.cpu(), vt.cpu()))
-            finally:
-                os.environ.pop("TR1_QKV_SPLIT", None)
-        for other in plain[1:]:
-            assert all(torch.equal(a, b_) for a, b_ in zip(plain[0], other)), "split-K fused QKV must equal the one-block form bit for bit"
     for fused in (True, False):
         kc, vt = kc0.clone().cuda(), vt0.clone().cuda()
         if fused:
@@ -940,39 +887,6 @@ def test_gemm_nn(hip_ops, M, N, K):
     close(got, ref.cpu(), 0.03, rtol=0.02, what="gemm_nn")
     nt = hip_ops.gemm_nt(a, b.t().contiguous())
     assert torch.equal(got, nt), "NN and NT forms accumulate in the same order"
-
-
-@pytest.mark.parametrize("T", [5, 32, 77, 160])
-@pytest.mark.parametrize("nbt", ["2", "4"])
-def test_wgrad_tn_matches_fp32_reference(T, nbt):
-    """csrc/gemm_tn.hip (opt-in TR1_WGRAD_TN=1): dY^T X with both operands as stored against an fp32 matmul of the same bf16 inputs (tolerance 2e-5 of
-    the largest entry: fp32 accumulation order only), overwrite and accumulate, partial last token tile, strided operand views, refusal of uncovered shapes.
-    The wave layout (TR1_TN_NBT) is read once per process, hence the subprocess."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import torch, sys
-        sys.path.insert(0, %r)
-        import time_r1_amd
-        from time_r1_amd.ops import HipOps
-        ops = HipOps("cuda:0")
-        T = %d
-        g = torch.Generator().manual_seed(T)
-        big = (torch.randn(T, 1024 + 512, generator=g) * 0.1).bfloat16()
-        ref = big[:, :512].float().t() @ big[:, 512:1280].float()
-        big = big.cuda()
-        dy, x = big[:, :512], big[:, 512:1280]                    # strided views, N = 512, K = 768
-        gw = torch.full((512, 768), 7.0, device="cuda")
-        assert ops.wgrad_tn(dy, x, gw, False)
-        tol = 2e-5 * ref.abs().max().item() + 1e-12
-        assert (gw.cpu() - ref).abs().max().item() <= tol, (gw.cpu() - ref).abs().max().item()
-        assert ops.wgrad_tn(dy, x, gw, True)
-        assert (gw.cpu() - 2 * ref).abs().max().item() <= 2 * tol
-        assert not ops.wgrad_tn(dy[:, :384], x, gw[:384], False)      # N not a multiple of 256: the caller falls back
-        print("ok")
-    """) % (root, T)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TR1_TN_NBT=nbt), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_down_projection_56_column_blocks_bit_identical(tmp_path):

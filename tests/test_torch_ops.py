@@ -201,3 +201,7 @@ def test_hf_attention_seam_honours_is_causal_cu_seqlens_and_kv_cache():
     pad = tri.clone(); pad[..., :4] = float("-inf")
     with pytest.raises(NotImplementedError):
         T.hf_attention_forward(mod, q, k, v, pad, scaling=D ** -0.5)
+    # (5) ADVICE r4: an explicit ALL-KEEP mask over T > 1 queries replaces is_causal in transformers' sdpa path = bidirectional attention
+    allkeep = torch.zeros(1, 1, 32, 32, device="cuda")
+    o, _ = T.hf_attention_forward(mod, q, k, v, allkeep, scaling=D ** -0.5)
+    _close(o[0], ref(q, k, v, torch.ones(32, 32, dtype=torch.bool, device="cuda")), 0.02, "explicit all-keep mask")

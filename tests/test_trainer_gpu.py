@@ -271,3 +271,29 @@ def test_grad_norm_from_weight_gradient_epilogues(hip_ops):
     # (the norm / embedding gradients use fp32 atomics and are not bit-reproducible between two runs; the GEMM outputs are)
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), "the sum-of-squares epilogue must not change the gradient: " + n
+
+
+def test_grad_norm_sink_is_dropped_when_another_backward_follows_the_armed_one(hip_ops):
+    """accumulation_window([b]) arms the weight-gradient sink; a further compute_loss(b2) accumulates into the arena WITHOUT the sink, so step()
+    must fall back to the full pass over the gradient arena (the sink only describes the older backward)."""
+    from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig
+    from time_r1_amd import rewards as R
+    from time_r1_amd.config import tiny_test, TextConfig
+    from time_r1_amd.params import ModelParams
+    from oracle.text import FakeProcessor
+    cfg = tiny_test()
+    cfg.text = TextConfig(vocab_size=512, hidden=512, intermediate=1024, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, mrope_section=(16, 24, 24))
+    cfg.vision.out_hidden = 512
+    args = GRPOConfig(output_dir="/tmp/tr1_gpu_sink2", num_generations=4, max_completion_length=8, beta=0.04, use_grpo=True, temperature=1.0,
+                      save_strategy="no", disable_log_print=True, gradient_accumulation_steps=1)
+    tr = TimeR1_Trainer(ModelParams(cfg, hip_ops, seed=1), [R.format_reward], [], args=args, processing_class=FakeProcessor(cfg), ops=hip_ops)
+    rows = []
+    for i in range(2):
+        frames = torch.randint(0, 256, (4, 3, 84, 112), generator=torch.Generator().manual_seed(30 + i), dtype=torch.uint8)
+        rows.append([{"problem": "event %d" % i, "video_path": "x.mp4", "video_frames": frames, "solution": (2.0, 12.0), "durations": 30.0}])
+    tr.accumulation_window(rows[:1])          # arms the sink (last micro-step of its window)
+    tr.compute_loss(tr.model, rows[1])        # a second backward, not armed
+    want = float(tr.params.train.grad.double().norm())
+    gn = float(tr.optimizer.step())
+    assert not tr.optimizer.norm_from_sink, "a stale sink must not be used"
+    assert abs(gn - want) < 2e-4 * want, (gn, want)

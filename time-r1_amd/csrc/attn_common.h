@@ -52,9 +52,6 @@ struct AttnParams {
     // backward only: when set, dQ and dK leave the kernels already multiplied by the TRANSPOSED rotary matrix (the backward of M-RoPE, TF:212-222):
     // fp32 cos / sin tables [T, d / 2]; row t of dQ and slot t of dK use row t
     const float* rope_cos; const float* rope_sin;
-    // split-KV decode, merged form (attn_dec32_kernel): when set, the nsplit blocks of a (batch entry, kv head, query tile) meet at a counter pair
-    // [arrived, done] per group and merge their partials themselves (no attn_combine launch); merge_err receives 1 if a block gave up waiting
-    int* merge_cnt; int* merge_err;
 };
 
 #define ATT_KV 64          // keys per tile

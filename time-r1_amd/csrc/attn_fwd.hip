@@ -444,7 +444,7 @@ __global__ void scatter_slots_kernel(const bf16_t* __restrict__ src, int64_t ld_
     }
 }
 
-int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s);      // attn_fwd32.hip: 0 not launched, 1 launched (partials: combine follows), 2 launched and merged
+int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s);      // attn_fwd32.hip: 0 not launched, 1 launched (partials: combine follows)
 
 template <int D, int CB, int PF>
 static void launch_fwd(dim3 grid, hipStream_t s, const AttnParams& p) {
@@ -526,7 +526,7 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
             default: launch_fwd<128, 2, 1>(grid, s, p); break;
         }
     }
-    if (nsplit > 1 && dec32 != 2) {
+    if (nsplit > 1) {
         dim3 cg((unsigned)((nR + ATT_COMBINE_ROWS - 1) / ATT_COMBINE_ROWS), (unsigned)(n_kv * n_batch));
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;

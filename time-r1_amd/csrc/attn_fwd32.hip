@@ -604,150 +604,27 @@ __global__ __launch_bounds__(512) void attn_dec32_kernel(AttnParams p) {
                 f32x4_t v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[db][4 * i + j] * w1 + o2[j] * w2;
-                if (p.merge_cnt) {      // merged form: device-scope write-through stores, visible to the partner blocks on other XCDs without an L2 flush
-                    // (16 bytes per instruction with the agent-scope cache policy the compiler gives a relaxed device-scope atomic store: `sc1`; 4-byte
-                    // write-through pieces made the launch 24 us slower)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(op + db * 32 + 8 * i + 4 * h), "v"(v) : "memory");
-                } else
-                    *reinterpret_cast<f32x4_t*>(op + db * 32 + 8 * i + 4 * h) = v;
+                *reinterpret_cast<f32x4_t*>(op + db * 32 + 8 * i + 4 * h) = v;
             }
-        if (h == 0) {
-            if (p.merge_cnt) {
-                __hip_atomic_store(p.mpart + slot, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.lpart + slot, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else { p.mpart[slot] = M; p.lpart[slot] = L; }
-        }
+        if (h == 0) { p.mpart[slot] = M; p.lpart[slot] = L; }
     }
     DEC_STAMP(10);
-    if (p.merge_cnt) {
-        // ---- merged form: the nsplit blocks of this (batch entry, kv head, query tile) meet at a counter and merge the partials themselves - split s takes
-        // rows s, s + nsplit, ... of the tile - with the operations of attn_combine_kernel in the same order (att_merge_*: bit-identical output).  All blocks
-        // of the grid are co-resident (the launcher checks grid <= CUs, one block per CU); partials travel by device-scope stores / loads (no L2 flush: fences here cost
-        // 80 us per launch), so a waiting block never keeps the blocks it waits for off the
-        // GPU; the wait is bounded anyway (10 ms of the 100 MHz clock): a block that gives up raises merge_err (read by tr1_attn_merge_error) and goes on.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's partial stores have reached the device-coherent level
-        __syncthreads();
-        int* cnt = p.merge_cnt + 2 * ((int)by * gx + qtile);
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.nsplit) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 1000000ull) { __hip_atomic_store(p.merge_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
-        float* sm_m = reinterpret_cast<float*>(dyn_lds);              // [4][64] (the tile buffers are dead)
-        float* sm_l = sm_m + 256;
-        f32x4_t* part = reinterpret_cast<f32x4_t*>(dyn_lds + 2048);   // [4 rows][4 split groups][32]
-        const int tid = (int)threadIdx.x, c = tid & 31, sg = (tid >> 5) & 3, rl = tid >> 7;
-        const int64_t nRpad = (int64_t)gx * 64;
-        bf16_t* Ob = p.O + (int64_t)b * p.T * p.o_ld;
-        float* lse_b = p.lse ? p.lse + (int64_t)b * p.n_kv * p.group * p.T : nullptr;
-        for (int j0 = 0; split + j0 * p.nsplit < 64; j0 += 4) {       // (block-uniform trip count)
-            const int row = split + (j0 + rl) * p.nsplit;
-            const int64_t Rq = (int64_t)qtile * 64 + row;
-            const bool act = row < 64 && Rq < (int64_t)nR;
-            const int64_t Rc = act ? Rq : (int64_t)qtile * 64;
-            f32x4_t ov[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int sp = sg + 4 * i;
-                const float* src = p.Opart + (((int64_t)(sp < p.nsplit ? sp : 0) * gy + by) * nRpad + Rc) * D + c * 4;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(ov[i]) : "v"(src) : "memory");      // device-scope loads: the partner blocks' stores
-            }
-            for (int i = tid; i < 4 * p.nsplit; i += 512) {
-                const int r = i / p.nsplit, sp = i - r * p.nsplit;
-                const int rowr = split + (j0 + r) * p.nsplit;
-                const int64_t Rr = (int64_t)qtile * 64 + rowr;
-                const bool okr = rowr < 64 && Rr < (int64_t)nR;
-                const int64_t slot = ((int64_t)sp * gy + by) * nRpad + (okr ? Rr : (int64_t)qtile * 64);
-                sm_m[r * 64 + sp] = okr ? __hip_atomic_load(p.mpart + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NEG_INF;
-                sm_l[r * 64 + sp] = okr ? __hip_atomic_load(p.lpart + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-            }
-            // one wait for the sixteen loads; the registers pass through it as in/out operands, so nothing the compiler copied earlier is used afterwards
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(ov[4]), "+v"(ov[5]), "+v"(ov[6]), "+v"(ov[7]),
-                                                "+v"(ov[8]), "+v"(ov[9]), "+v"(ov[10]), "+v"(ov[11]), "+v"(ov[12]), "+v"(ov[13]), "+v"(ov[14]), "+v"(ov[15]) :: "memory");
-            __syncthreads();
-            float M, Ms, L;
-            att_merge_stats(sm_m + rl * 64, sm_l + rl * 64, p.nsplit, M, Ms, L);
-            const float inv = L > 0.f ? 1.f / L : 0.f;
-            f32x4_t acc = att_merge_weighted(ov, sm_m + rl * 64, Ms, sg, p.nsplit);
-            part[(rl * 4 + sg) * 32 + c] = acc;
-            __syncthreads();
-            if (act && sg == 0) {
-                acc = (part[(rl * 4 + 0) * 32 + c] + part[(rl * 4 + 1) * 32 + c]) + (part[(rl * 4 + 2) * 32 + c] + part[(rl * 4 + 3) * 32 + c]);
-                int t, hq2;
-                att_split_row(p, (unsigned)Rq, t, hq2);
-                bf16_t* orow = Ob + (int64_t)t * p.o_ld + (int64_t)(kvh * p.group + hq2) * D;
-                u32x2_t w = {pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv)};
-                *reinterpret_cast<u32x2_t*>(orow + c * 4) = w;
-                if (c == 0 && lse_b) lse_b[(int64_t)(kvh * p.group + hq2) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {                                        // the last block through re-arms the pair for the next launch
-            const int dn = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (dn == p.nsplit - 1) {
-                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
     DEC_FLUSH();
 }
 
-// launched by attn_fwd_impl (attn_fwd.hip) for plan_mode 2 launches at head dim 128; returns false when the shape does not qualify
-// Counter pairs of the merged form (one per (batch entry, kv head, query tile)) + the error word behind them: owned by the library, zeroed once, re-armed by
-// the kernel itself.  ONE decode attention in flight per process at a time (launches on one stream serialise; the rollout never decodes on two streams).
-#define DEC32_MERGE_GROUPS 4096
-static int* dec32_merge_buf() {
-    static int* buf = nullptr;
-    if (!buf) {
-        if (hipMalloc(reinterpret_cast<void**>(&buf), (2 * DEC32_MERGE_GROUPS + 16) * sizeof(int)) != hipSuccess) { buf = nullptr; return nullptr; }
-        hipMemset(buf, 0, (2 * DEC32_MERGE_GROUPS + 16) * sizeof(int));
-    }
-    return buf;
-}
-// -> 1 if a merged decode attention gave up waiting for a partner block since the last call (its output is then wrong), and clears the flag.  Synchronous.
-extern "C" int tr1_attn_merge_error(void) {
-    int* buf = dec32_merge_buf();
-    if (!buf) return 0;
-    int v = 0;
-    if (hipMemcpy(&v, buf + 2 * DEC32_MERGE_GROUPS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v) hipMemset(buf, 0, (2 * DEC32_MERGE_GROUPS + 16) * sizeof(int));
-    return v;
-}
-static int g_dec_merge = -1;                                             // TR1_DEC_MERGE (default 0: measured 9.6 us per layer SLOWER than partials + combine at config 3), or the last tr1_attn_dec_merge() argument
-// Switch the merged form on / off at run time (A/B runs and the bit-identity test); returns the previous setting.
-extern "C" int tr1_attn_dec_merge(int on) {
-    if (g_dec_merge < 0) { const char* e = getenv("TR1_DEC_MERGE"); g_dec_merge = e ? atoi(e) : 0; }
-    const int prev = g_dec_merge;
-    if (on >= 0) g_dec_merge = on ? 1 : 0;
-    return prev;
-}
+// launched by attn_fwd_impl (attn_fwd.hip) for plan_mode 2 launches at head dim 128; returns 0 when the shape does not qualify, 1 when launched
+// (partials written: attn_combine_kernel follows)
 int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s) {
-    static int on = -1, cus = 0;
-    const int merge = tr1_attn_dec_merge(-1);
-    if (on < 0) {
-        const char* e = getenv("TR1_DEC32"); on = e ? atoi(e) : 1;
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
-    }
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("TR1_DEC32"); on = e ? atoi(e) : 1; }
     if (!on || p.d_real != 128 || p.plan_mode != 2 || !p.plan || p.n_slots % 64 != 0) return 0;
     const uint64_t kbytes = (uint64_t)p.kv_batch_slots * (uint64_t)p.k_ld * 2ull, vbytes = (uint64_t)128 * (uint64_t)p.vt_ld * 2ull;
     if (kbytes >= 0xffffffffull || vbytes >= 0xffffffffull || (uint64_t)p.n_slots * (uint64_t)p.k_ld * 2ull >= 0xffffffffull) return 0;
     const size_t dyn = 4 * (64 * 256 + 128 * 128) + 64 * 256 + 768 + 64;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); attr = true; }
-    // merged form: every block must be resident at once (145 KB of LDS: one block per CU) and the split count must fit the merge's 64-entry rows
-    const uint64_t blocks = (uint64_t)grid.x * grid.y * grid.z, groups = (uint64_t)grid.x * grid.y;
-    p.merge_cnt = nullptr; p.merge_err = nullptr;
-    if (merge && cus > 0 && blocks <= (uint64_t)cus && groups <= DEC32_MERGE_GROUPS && p.nsplit >= 2 && p.nsplit <= 64) {
-        if (int* buf = dec32_merge_buf()) { p.merge_cnt = buf; p.merge_err = buf + 2 * DEC32_MERGE_GROUPS; }
-    }
     hipLaunchKernelGGL(attn_dec32_kernel, grid, dim3(512), dyn, s, p);
-    return p.merge_cnt ? 2 : 1;
+    return 1;
 }
 
 // Q/O: [T, n_heads*128]; K, V: [n_slots, n_kv*128] row-major (any leading dims that are multiples of 8); lse (optional): fp32 [n_heads, T].

@@ -51,8 +51,7 @@ static int64_t decode_ws_bytes(const int64_t* d) {
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     const int64_t fix = tr1_gemm_skinny_fixup_workspace_floats(R, hid, d[D_INTER]);
     const int64_t plan = tr1_attn_plan_ints(T, d[D_HEADS], d[D_KV], d[D_BATCH]);
-    const int64_t qsp = tr1_norm_gemm_qkv_split_workspace_floats(d[D_HEADS], d[D_KV], d[D_HEAD_DIM]);
-    return al(qsp * 4) + al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
 }
 
 extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
@@ -81,15 +80,7 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     static int use_plan = -1;
     if (use_plan < 0) { const char* e = getenv("TR1_ATTN_PLAN"); use_plan = e ? atoi(e) : 1; }
     void* plan = c.take(tr1_attn_plan_ints(T, nh, nkv, B) * 4);
-    // <= 16 rows: the fused QKV launch on two blocks per column-group pair (bit-identical).  Measured SLOWER on MI355X (16.8 us against 15.1 us per
-    // layer, decode step 3.59 against 3.55 ms): 288 blocks on 256 CUs leave 32 CUs with two blocks and the fixup adds a dependent L2 round trip -
-    // the 144-block form is bound by the per-CU request rate, which the second block on a CU does not raise.  Kept behind TR1_QKV_SPLIT=1.
-    static int qkv_split = -1;
-    if (qkv_split < 0) { const char* e = getenv("TR1_QKV_SPLIT"); qkv_split = e ? atoi(e) : 0; }
-    const int64_t qsp_floats = tr1_norm_gemm_qkv_split_workspace_floats(nh, nkv, hd);
-    void* qsp = c.take(qsp_floats * 4);
     const int qm = w8 ? (int)(dims[D_QMASK] & QM_ALL) : 0;                     // fp8 matrices of this step
-    const bool use_qsp = qkv_split && !(qm & QM_QKV) && R <= 16 && hd % 32 == 0 && hid >= 512;
     const bool planned = use_plan && nsplit > 1 && L > 1;
     const bool down_fixup = !(qm & QM_DOWN) && R >= 16 && inter >= 8192;
     const bool down_fixup8 = w8 == 2 && (qm & QM_DOWN) && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
@@ -106,10 +97,6 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
         if (qm & QM_QKV) {
             CK(gemm8(h, w[0], w[1], w[9], w[2], nullptr, qkv, R, qkvd, hid, hid, hid, qkvd, 0, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
-        } else if (use_qsp) {
-            ProfScope ps(0, stream);
-            CK(tr1_norm_gemm_qkv_split(h, w[0], w[1], w[2], cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, hid, hid, hid,
-                                       eps, qsp, qsp_floats, stream));
         } else if (hd % 32 == 0) {      // norm + q/k/v projection + M-RoPE + KV append in one launch
             ProfScope ps(0, stream);
             CK(tr1_norm_gemm_qkv(h, w[0], w[1], w[2], cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, hid, hid, hid,

@@ -1334,137 +1334,6 @@ __global__ __launch_bounds__(WAVES * 64) void norm_gemm_skinny_kernel(const bf16
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fused rmsnorm + QKV projection + M-RoPE + KV append at <= 16 decode rows, split over TWO blocks per column-group pair (round 3).
-// The one-block form above has heads * hd/32 = 144 blocks for 256 CUs (7B) and runs at the per-CU request rate of those 144 (14.7 us for
-// 33 MB).  Here block (pair, half) runs waves 4*half .. 4*half+3 of the SAME 8-way K decomposition - each wave streams exactly the K slice
-// and accumulates in exactly the order it has in the one-block kernel - and parks its four per-wave partial tiles (+ partial sums of x^2) in
-// an L2-resident workspace with device-scope stores; the block that draws the second ticket adds all eight per-wave partials in wave order
-// and runs the RoPE / cache-append epilogue.  Same summands in the same order: the result is bit-identical to the one-block kernel.
-// Each block reads half of x, so the x re-read of the extra blocks costs nothing.
-// ------------------------------------------------------------------------------------------------------------------
-#define QKVS_TILE (4 * 2 * 256 + 4 * 16)      // floats a block parks: [4 waves][2 column groups][16 x 16] + [4 waves][16] sums of squares
-template <int UNROLL>
-__global__ __launch_bounds__(256) void norm_qkv_split_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
-                                                             const bf16_t* __restrict__ bias, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
-                                                             float eps, QkvEpi qe, float* __restrict__ ws, int* __restrict__ cnt) {
-    constexpr int WAVES = 4, NCOL = 2;
-    __shared__ __attribute__((aligned(16))) float red[WAVES][NCOL][16][17];
-    __shared__ float ssred[WAVES][16];
-    __shared__ int s_ticket;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u = lane & 15, g = lane >> 4;
-    const int pair = (int)blockIdx.x >> 1, half = (int)blockIdx.x & 1;
-    const int gph = qe.hd >> 5;                                              // 16-column group pairs per head
-    const int qh = pair / gph, qj = pair % gph;
-    const int64_t n0 = (int64_t)qh * qe.hd + qj * 16;
-    const bf16_t* wp[NCOL];
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) {
-        int64_t wrow = n0 + c * (qe.hd >> 1) + u;
-        if (wrow >= N) wrow = N - 1;
-        wp[c] = W + wrow * ldw + g * 8;
-    }
-    const bf16_t* xp = X + (int64_t)(u < M ? u : (M - 1)) * ldx + g * 8;      // rows >= M re-read row M-1; their outputs are never stored
-    const bf16_t* lp = lnw + g * 8;
-    const int64_t nsteps = K / 64;
-    const int64_t s_per = (nsteps + 7) / 8;                                    // the 8-way K decomposition of the one-block kernel
-    const int64_t s0 = (half * 4 + wave) * s_per;
-    int64_t s1 = s0 + s_per; if (s1 > nsteps) s1 = nsteps;
-    f32x4_t acc[NCOL][2];
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCOL; ++c) { acc[c][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-    bf16x8_t wa[UNROLL][NCOL][2], xa[UNROLL][2], la[UNROLL][2];
-#define QS_LOAD(q, st)                                                                                   \
-    do {                                                                                                 \
-        const int64_t k__ = (st) * 64;                                                                   \
-        _Pragma("unroll") for (int c = 0; c < NCOL; ++c) {                                               \
-            wa[q][c][0] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__);                               \
-            wa[q][c][1] = *reinterpret_cast<const bf16x8_t*>(wp[c] + k__ + 32);                          \
-        }                                                                                                \
-        xa[q][0] = *reinterpret_cast<const bf16x8_t*>(xp + k__);                                         \
-        xa[q][1] = *reinterpret_cast<const bf16x8_t*>(xp + k__ + 32);                                    \
-        la[q][0] = *reinterpret_cast<const bf16x8_t*>(lp + k__);                                         \
-        la[q][1] = *reinterpret_cast<const bf16x8_t*>(lp + k__ + 32);                                    \
-    } while (0)
-#define QS_MFMA(q)                                                                                                    \
-    do {                                                                                                              \
-        const bf16x8_t x0__ = scale_frag_sumsq(xa[q][0], la[q][0], ss);                                               \
-        const bf16x8_t x1__ = scale_frag_sumsq(xa[q][1], la[q][1], ss);                                               \
-        _Pragma("unroll") for (int c = 0; c < NCOL; ++c) {                                                            \
-            acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][0], x0__, acc[c][0], 0, 0, 0);               \
-            acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][c][1], x1__, acc[c][1], 0, 0, 0);               \
-        }                                                                                                             \
-    } while (0)
-    int64_t s = s0;
-#pragma unroll
-    for (int q = 0; q < UNROLL; ++q)
-        if (s0 + q < s1) QS_LOAD(q, s0 + q);
-    for (; s + 2 * UNROLL <= s1; s += UNROLL) {
-#pragma unroll
-        for (int q = 0; q < UNROLL; ++q) { QS_MFMA(q); QS_LOAD(q, s + q + UNROLL); }
-    }
-#pragma unroll
-    for (int q = 0; q < UNROLL; ++q)
-        if (s + q < s1) { QS_MFMA(q); if (s + q + UNROLL < s1) QS_LOAD(q, s + q + UNROLL); }
-    s += UNROLL;
-#pragma unroll
-    for (int q = 0; q < UNROLL; ++q)
-        if (s + q < s1) QS_MFMA(q);
-#undef QS_LOAD
-#undef QS_MFMA
-    {
-        float v = ss;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (g == 0) ssred[wave][u] = v;
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][c][u][g * 4 + r] = acc[c][0][r] + acc[c][1][r];
-    }
-    __syncthreads();
-    // park the four per-wave partials (device-scope write-through stores: visible across XCDs without an L2 flush), then draw a ticket
-    float* mine = ws + ((int64_t)pair * 2 + half) * QKVS_TILE;
-    const int mm = (threadIdx.x >> 4) & 15, nn = threadIdx.x & 15;             // this thread's output (row mm, column nn of the 16 x 16 tile)
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w)
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c)
-            __hip_atomic_store(mine + (w * 2 + c) * 256 + threadIdx.x, red[w][c][mm][nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 64) __hip_atomic_store(mine + 2048 + threadIdx.x, ssred[threadIdx.x >> 4][threadIdx.x & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&cnt[pair], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != 1) return;
-    // second arriver: all eight per-wave partials in wave order (half 0's four, then half 1's four), exactly the one-block kernel's sum
-    const float* h0 = ws + ((int64_t)pair * 2 + 0) * QKVS_TILE;
-    const float* h1 = ws + ((int64_t)pair * 2 + 1) * QKVS_TILE;
-    float sq = 0.f, v = 0.f, v2 = 0.f;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const float* hp = hf ? h1 : h0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            sq += __hip_atomic_load(hp + 2048 + w * 16 + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v += __hip_atomic_load(hp + (w * 2 + 0) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v2 += __hip_atomic_load(hp + (w * 2 + 1) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (threadIdx.x == 0) cnt[pair] = 0;                                       // re-armed for the next launch (ordered by the kernel boundary)
-    const int64_t n = n0 + nn;
-    if (mm < M && n < N) {
-        const float rstd = rsqrtf(sq * (1.f / (float)K) + eps);
-        v = __fmul_rn(v, rstd);
-        const int64_t nb = n + (qe.hd >> 1);
-        float vb = __fmul_rn(v2, rstd);
-        if (bias) { v = __fadd_rn(v, bf2f(bias[n])); vb = __fadd_rn(vb, bf2f(bias[nb])); }
-        qkv_epilogue_store(qe, mm, qh, qj * 16 + nn, bf2f(f2bf(v)), bf2f(f2bf(vb)));
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // LDS-streamed form of the fused rmsnorm + gate/up + SwiGLU decode GEMM (M <= 16 rows).
 // The register-fragment stream of norm_gemm_skinny_kernel reads 64-byte pieces of 16 weight rows per wave instruction and tops out at
 // ~4.8 TB/s (a pure load kernel with that shape: 5.5 TB/s; with row-contiguous requests: 6.1 TB/s, tools/probe_stream.hip).  Here the
@@ -1916,29 +1785,6 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
     }
     else if (M <= 16) NGQ(8, 2, 1); else if (M <= 32) { const int c = ng32_cfg(); if (c == 1) NGQ(8, 2, 2); else if (c == 2) NGQ(8, 1, 2); else if (c == 3) NGQ(4, 1, 2); else NGQ(4, 2, 2); } else NGQ(4, 2, 4);
 #undef NGQ
-    TR1_LAUNCH_CHECK();
-}
-
-// <= 16 decode rows, two blocks per column-group pair (norm_qkv_split_kernel).  ws_f32: tr1_norm_gemm_qkv_split_workspace_floats() floats, zero-
-// initialised ONCE by the caller (the ticket counters live behind the tiles; the kernel re-arms them).  Bit-identical to tr1_norm_gemm_qkv.
-extern "C" int64_t tr1_norm_gemm_qkv_split_workspace_floats(int64_t n_heads, int64_t n_kv, int64_t head_dim) {
-    const int64_t pairs = (n_heads + 2 * n_kv) * (head_dim / 32);
-    return pairs * 2 * QKVS_TILE + pairs;
-}
-extern "C" int tr1_norm_gemm_qkv_split(const void* x, const void* lnw, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out,
-                                       int64_t ld_q, void* kcache, int64_t k_ld, void* vtcache, int64_t vt_ld, const void* slots, int64_t M,
-                                       int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, float eps, void* ws_f32,
-                                       int64_t ws_floats, void* stream) {
-    TR1_CHECK_ARG(K % BK == 0 && K >= 8 * BK, "norm_gemm_qkv_split: K must be a multiple of 64 and >= 512");
-    TR1_CHECK_ARG(M >= 1 && M <= 16, "norm_gemm_qkv_split: 1 <= M <= 16 (decode rows)");
-    TR1_CHECK_ARG(head_dim % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "norm_gemm_qkv_split: head_dim % 32, ldx % 8, ldw % 8 required");
-    const int64_t heads = n_heads + 2 * n_kv, N = heads * head_dim, pairs = heads * (head_dim / 32);
-    TR1_CHECK_ARG(ws_f32 && ws_floats >= pairs * 2 * QKVS_TILE + pairs, "norm_gemm_qkv_split: workspace too small");
-    QkvEpi qe{(const float*)cosb, (const float*)sinb, (bf16_t*)q_out, ld_q, (bf16_t*)kcache, k_ld, (bf16_t*)vtcache, vt_ld, (const int*)slots,
-              (int)n_heads, (int)n_kv, (int)head_dim};
-    float* tiles = (float*)ws_f32;
-    hipLaunchKernelGGL((norm_qkv_split_kernel<2>), dim3((unsigned)(pairs * 2)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)lnw,
-                       (const bf16_t*)Wqkv, (const bf16_t*)bias, (int)M, N, K, ldx, ldw, eps, qe, tiles, (int*)(tiles + pairs * 2 * QKVS_TILE));
     TR1_LAUNCH_CHECK();
 }
 

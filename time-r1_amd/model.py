@@ -35,11 +35,11 @@ class Engine:
         self._gw_ver = {}
         self.fused_head = os.environ.get("TR1_FUSED_HEAD", "1") != "0"    # lm_head -> logp / entropy in the GEMM epilogue where the logits are not kept
         self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
-        self.wgrad_tn = os.environ.get("TR1_WGRAD_TN", "0") == "1"      # ... and dy as stored too (round 3, csrc/gemm_tn.hip): measured, NOT adopted
         self._side = None
         # set (by the owner of the optimizer) for the backward of a window's LAST micro-step: the weight-gradient epilogues of the decoder layers' large
         # matrices then also leave the squared norm of the final gradient (AdamWFlat.norm_sink_begin / step)
         self.norm_sink = None
+        self.bwd_count = 0                   # decoder backward passes run so far: a sink is only valid if its backward was the LAST one before the step
         assert cfg.vision.variant in ("qwen2_vl", "qwen2_5_vl"), cfg.vision.variant
 
     # ================================================================================================= gradient helpers
@@ -54,14 +54,6 @@ class Engine:
             if ver is not None and self._gw_ver.get(key) != ver:
                 self._gw_ver[key] = ver
                 acc = False
-        # TR1_WGRAD_TN=1: both operands as stored (round 3, csrc/gemm_tn.hip) - no dy^T / x^T copies at all where N and K are multiples of 256.
-        # Off by default: the transposing LDS reads on BOTH operands hold that GEMM at 0.83-0.9 x the NT kernel's rate, and the copies it saves
-        # cost 7 ms of the 154 ms backward (measured with stale non-zero copies), so the backward came out 6 ms SLOWER.
-        tn = getattr(ops, "wgrad_tn", None)
-        if tn is not None and self.wgrad_tn and tn(dy, x, gw, acc):
-            if bias_g is not None:
-                ops.colsum_accum(dy, bias_g)
-            return
         # bias_g: the Linear's bias gradient (column sums of dy) rides on the pass that builds dy^T
         if dyt is None:                                  # (the fused down dgrad hands over dgu^T from its epilogue)
             dyt = ops.transpose(dy, colsum=bias_g) if bias_g is not None else ops.transpose(dy)      # [N, Mp], zero-padded columns
@@ -453,6 +445,7 @@ class Engine:
         """dh: gradient wrt the decoder stack output [M, d]. Accumulates parameter grads; returns the gradient wrt the input embeddings.
         on_layer_done(i): called right after layer i's gradient kernels are enqueued (data-parallel overlap hook)."""
         ops, t, tr = self.ops, self.cfg.text, self.params.train
+        self.bwd_count += 1
         pre, lo, hi = ctx["masks"]
         cos, sin = ctx["cos"], ctx["sin"]
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim

@@ -58,12 +58,6 @@ class HipOps:
             torch.cuda.set_stream(self._main_stream)
         return self._main_stream
 
-    def attn_merge_check(self):
-        """Call where the host already waits for a rollout (the sampled tokens' device-to-host copy): raises if a merged decode attention launch gave up
-        waiting for a partner block (tr1_attn_merge_error) - the tokens drawn after that point are not the model's."""
-        if self.L.raw("tr1_attn_merge_error")() != 0:
-            raise RuntimeError("decode attention (merged split-KV form): a block timed out waiting for its partner blocks; rerun with TR1_DEC_MERGE=0")
-
     def probe_hbm_read(self, buf, sink):
         """Measurement helper: one streaming read of `buf` (bench.py times it)."""
         self.L.call("tr1_probe_hbm_read", _p(buf), buf.numel() * buf.element_size(), _p(sink), self._s())
@@ -148,19 +142,6 @@ class HipOps:
         self._chk(dyt, x)
         assert gw.dtype == F32 and gw.shape == (N, K)
         self.L.call("tr1_gemm_nn_acc_f32", _p(dyt), _p(x), _p(gw), N, K, Mp, _ld(dyt), _ld(x), _ld(gw), int(accumulate), M, self._s())
-        return True
-
-    def wgrad_tn(self, dy, x, gw, accumulate):
-        """gw[N,K] fp32 (+)= dy[T,N]^T @ x[T,K], both operands as stored (csrc/gemm_tn.hip).  Returns False when the shape is not covered (the caller
-        then falls back to the transposed-copy forms)."""
-        T, N = dy.shape
-        K = x.shape[1]
-        if not (x.shape[0] == T and N % 256 == 0 and K % 256 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
-                and T * max(dy.stride(0), x.stride(0)) * 2 < 0xffffffff and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
-            return False
-        self._chk(dy, x)
-        assert gw.dtype == F32 and gw.shape == (N, K) and gw.stride(1) == 1
-        self.L.call("tr1_gemm_tn_acc_f32", _p(dy), _p(x), _p(gw), T, N, K, _ld(dy), _ld(x), _ld(gw), int(accumulate), self._s())
         return True
 
     def gemm_nt(self, a, b, bias=None, residual=None, out_f32=False, out=None, accumulate=False):
@@ -283,15 +264,6 @@ class HipOps:
         assert slots.dtype == I32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (R, head_dim // 2) and cos.dtype == F32
         assert wqkv.shape == ((n_heads + 2 * n_kv) * head_dim, K) and x.stride(1) == 1 and wqkv.stride(1) == 1
         q = self.empty(R, n_heads * head_dim)
-        if R <= 16 and K >= 512 and os.environ.get("TR1_QKV_SPLIT", "0") == "1":      # two blocks per column-group pair (bit-identical; measured slower, see csrc/decode.hip)
-            nws = self.L.raw("tr1_norm_gemm_qkv_split_workspace_floats")(n_heads, n_kv, head_dim)
-            key = ("qkv_split", n_heads, n_kv, head_dim)
-            ws = self._ws.get(key)
-            if ws is None:
-                ws = self._ws[key] = torch.zeros(nws, dtype=F32, device=self.device)      # zero ONCE: the ticket counters start disarmed
-            self.L.call("tr1_norm_gemm_qkv_split", _p(x), _p(lnw), _p(wqkv), _p(bias), _p(cos), _p(sin), _p(q), _ld(q), _p(kcache), _ld(kcache), _p(vtcache),
-                        _ld(vtcache), _p(slots), R, n_heads, n_kv, head_dim, K, x.stride(0), wqkv.stride(0), float(eps), _p(ws), nws, self._s())
-            return q
         self.L.call("tr1_norm_gemm_qkv", _p(x), _p(lnw), _p(wqkv), _p(bias), _p(cos), _p(sin), _p(q), _ld(q), _p(kcache), _ld(kcache), _p(vtcache),
                     _ld(vtcache), _p(slots), R, n_heads, n_kv, head_dim, K, x.stride(0), wqkv.stride(0), float(eps), self._s())
         return q
@@ -755,12 +727,19 @@ class HipOps:
         K = b.shape[1] if b_kmajor else b.shape[0]
         if not (self.FUSE_EPI and N >= 512 and K >= 256 and K % 8 == 0 and Mp % 64 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and _ld(a) % 8 == 0 and _ld(b) % 8 == 0):
             return -1
+        if self.wgrad_sumsq_partials(N, K) > partials.numel() - int(offset) - 256:
+            return -1                     # partials buffer too small for this matrix: the caller runs the plain GEMM and step() takes the full-arena norm
         self._chk(a, b)
         assert gw.dtype == F32 and gw.shape == (N, K) and partials.dtype == F32 and partials.is_contiguous()
         n = ctypes.c_int64(0)
         self.L.call("tr1_wgrad_f32_sumsq", _p(a), _p(b), _p(gw), N, K, Mp, _ld(a), _ld(b), _ld(gw), int(accumulate), int(b_kmajor), int(b_rows),
                     partials.data_ptr() + 4 * int(offset), partials.numel() - int(offset) - 256, ctypes.byref(n), self._s())
         return int(n.value)
+
+    @staticmethod
+    def wgrad_sumsq_partials(N, K):
+        """Upper bound of the partial sums one tr1_wgrad_f32_sumsq launch on an [N, K] gradient leaves: 8 per tile block, tiles >= 224 rows x 256 columns."""
+        return 8 * ((int(N) + 223) // 224) * ((int(K) + 255) // 256)
 
     def sumsq_partials_accum(self, partials, n, out_scalar):
         assert partials.dtype == F32 and out_scalar.dtype == F32 and partials.numel() >= int(n) + 256

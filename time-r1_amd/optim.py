@@ -40,9 +40,13 @@ class AdamWFlat:
         if self.dp.enabled or not lz or engine is None:
             return None
         if getattr(self, "_partials", None) is None:
-            self._partials = torch.empty(1 << 21, dtype=torch.float32, device=self.params.train.grad.device)
+            # one slot per wave of every tile block of the covered matrices (7B: 0.72 M floats), sized from the layout instead of a fixed guess
+            a, bound = self.params.train, getattr(self.ops, "wgrad_sumsq_partials", None)
+            need = sum(bound(*a.offsets["l%d.%s" % (i, nm)][1]) for i in range(lz["count"]) for nm in type(engine).OVERWRITTEN) if bound else (1 << 21)
+            self._partials = torch.empty(need + 512, dtype=torch.float32, device=a.grad.device)
         self._sink = dict(partials=self._partials, n=0, covered=set(),
-                          want={"l%d.%s" % (i, nm) for i in range(lz["count"]) for nm in type(engine).OVERWRITTEN}, gver=getattr(self.params.train, "version", 0))
+                          want={"l%d.%s" % (i, nm) for i in range(lz["count"]) for nm in type(engine).OVERWRITTEN}, gver=getattr(self.params.train, "version", 0),
+                          engine=engine, bwd=getattr(engine, "bwd_count", 0) + 1)      # valid only if the armed backward is the engine's LAST one before step()
         return self._sink
 
     def _norm_from_sink(self):
@@ -51,6 +55,8 @@ class AdamWFlat:
         self._sink = None
         if not sink or not lz or sink["covered"] != sink["want"] or sink["gver"] != getattr(a, "version", 0):
             return False
+        if getattr(sink["engine"], "bwd_count", sink["bwd"]) != sink["bwd"] or not getattr(sink["engine"], "wgrad_overwrite_first", True):
+            return False      # another backward accumulated into the arena after the armed one (compute_loss / training_step between window and step): full pass
         ops = self.ops
         lo, hi = lz["base"], lz["base"] + lz["stride"] * lz["count"]
         ops.sumsq_partials_accum(sink["partials"], sink["n"], self._sumsq)

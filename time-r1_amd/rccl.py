@@ -13,6 +13,8 @@ import torch
 from . import hip
 
 _DT = {torch.bfloat16: 0, torch.float32: 1, torch.int32: 2}
+_PROC_START = time.time()
+_STALE_S = 300.0      # ranks of one job start within minutes of each other: an id file older than that belongs to an earlier (crashed) job
 
 
 def version():
@@ -40,20 +42,54 @@ class RcclComm:
     def from_env(cls, device=None, timeout_s=120.0):
         """RANK / WORLD_SIZE as torchrun sets them; rank 0 writes the id to TR1_RCCL_ID_FILE, the others wait for it."""
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-        path = os.environ.get("TR1_RCCL_ID_FILE", "/tmp/tr1_rccl_id.%s" % os.environ.get("MASTER_PORT", "0"))
+        # The id travels through a 0600 file in a 0700 directory owned by this user (not a predictable world-writable path), tagged with the job's
+        # nonce (torchrun's run id + master port); rank 0 removes what an earlier job left before it writes, and removes its own file after the
+        # communicator is up.  Readers refuse symlinks, other users' files, another job's tag and files older than their own start.
+        path = os.environ.get("TR1_RCCL_ID_FILE")
+        if path is None:
+            d = os.path.join(os.environ.get("XDG_RUNTIME_DIR") or "/tmp", "tr1_rccl.%d" % os.getuid())
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            st = os.lstat(d)
+            if not os.path.isdir(d) or os.path.islink(d) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                raise RuntimeError("%s must be a private directory of this user (set TR1_RCCL_ID_FILE to choose another place)" % d)
+            path = os.path.join(d, "id.%s" % os.environ.get("MASTER_PORT", "0"))
+        nonce = ("%s|%s|" % (os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("MASTER_PORT", ""))).encode()
+        t_start = _PROC_START
         if rank == 0:
+            for p in (path, path + ".tmp"):
+                try:
+                    os.unlink(p)
+                except FileNotFoundError:
+                    pass
             uid = unique_id()
-            with open(path + ".tmp", "wb") as f:
-                f.write(uid)
+            fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "wb") as f:
+                f.write(nonce + uid)
             os.replace(path + ".tmp", path)
         else:
             t0 = time.time()
-            while not os.path.exists(path):
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError("no RCCL unique id at %s after %.0f s" % (path, timeout_s))
-                time.sleep(0.05)
-            uid = open(path, "rb").read()
-        return cls(uid, world, rank, device)
+            uid = None
+            while uid is None:
+                try:
+                    fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                    with os.fdopen(fd, "rb") as f:
+                        st = os.fstat(f.fileno())
+                        blob = f.read()
+                    if st.st_uid == os.getuid() and st.st_mtime >= t_start - _STALE_S and blob.startswith(nonce) and len(blob) > len(nonce):
+                        uid = blob[len(nonce):]
+                except (FileNotFoundError, OSError):
+                    pass
+                if uid is None:
+                    if time.time() - t0 > timeout_s:
+                        raise TimeoutError("no fresh RCCL unique id at %s after %.0f s" % (path, timeout_s))
+                    time.sleep(0.05)
+        comm = cls(uid, world, rank, device)      # ncclCommInitRank returns once every rank has joined, i.e. has read the file
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
+        return comm
 
     def _s(self):
         return torch.cuda.current_stream().cuda_stream

@@ -418,11 +418,14 @@ def hf_attention_forward(module, query, key, value, attention_mask=None, dropout
     if attention_mask is not None:
         # transformers builds the plain causal triangle for sdpa-like backends, as an additive float mask (0 = keep) or as a bool mask
         # (True = keep); anything else (left padding, sliding windows, packed documents) cannot be expressed by one (pre, lo, hi) interval per
-        # query here.  An all-keep mask is trivial for either setting of `causal`.
+        # query here.  An explicit mask REPLACES is_causal in transformers' sdpa path, so an all-keep mask over T > 1 queries means bidirectional
+        # attention even when the module is causal: it is honoured as such (it equals the triangle only for T == 1).
         keep = attention_mask if attention_mask.dtype == torch.bool else (attention_mask == 0)
         keep = keep.expand(B, -1, T, S).reshape(-1, T, S) if keep.dim() == 4 else keep.reshape(-1, T, S)
         tri = torch.ones(T, S, dtype=torch.bool, device=query.device).tril(S - T) if causal else torch.ones(T, S, dtype=torch.bool, device=query.device)
-        full = bool((keep == tri).all()) or bool(keep.all())
+        full = bool((keep == tri).all())
+        if not full and bool(keep.all()):
+            full, causal = True, False
     else:
         full = True
     if not full:
