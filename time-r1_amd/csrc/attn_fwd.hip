@@ -473,7 +473,7 @@ extern "C" int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, 
 static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
                          void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
                          int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
-                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
+                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream, bool combine = true) {
     AttnParams p; memset(&p, 0, sizeof(p));
     TR1_CHECK_ARG(plan_mode == 0 || (plan && nsplit > 1 && (plan_mode == 1 || plan_mode == 2)), "attention: plan_mode 1 / 2 needs a plan buffer and nsplit > 1");
     p.plan = (int*)plan; p.plan_mode = plan_mode;
@@ -526,7 +526,7 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
             default: launch_fwd<128, 2, 1>(grid, s, p); break;
         }
     }
-    if (nsplit > 1) {
+    if (nsplit > 1 && combine) {
         dim3 cg((unsigned)((nR + ATT_COMBINE_ROWS - 1) / ATT_COMBINE_ROWS), (unsigned)(n_kv * n_batch));
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;
@@ -555,6 +555,16 @@ extern "C" int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, 
                                     int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
     return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32, ws_floats,
                          n_batch, kv_batch_slots, plan, plan_mode, stream);
+}
+
+// tr1_attn_fwd_planned WITHOUT the merge launch: the split partials stay in ws_f32 (Opart [nsplit][n_batch * n_kv][rows padded to 64][128], then the
+// running maxima and sums) for tr1_attn_combine_oproj, which merges them inside the output projection (csrc/oproj_fused.hip).  nsplit > 1 only.
+extern "C" int tr1_attn_fwd_partials(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, const void* pre, const void* lo,
+                                     const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit,
+                                     void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
+    TR1_CHECK_ARG(nsplit > 1, "attn_fwd_partials: split-KV launches only (nsplit > 1)");
+    return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, nullptr, n_heads * head_dim, nullptr, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32,
+                         ws_floats, n_batch, kv_batch_slots, plan, plan_mode, stream, false);
 }
 
 extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit) {

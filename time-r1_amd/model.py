@@ -33,6 +33,7 @@ class Engine:
         self.wgrad_on_main = os.environ.get("TR1_WGRAD_MAIN", "d")
         self.wgrad_overwrite_first = True    # see _wgrad: relies on the optimizer zeroing the gradient arena and bumping arena.version (AdamWFlat.step)
         self._gw_ver = {}
+        self.lazy_zero_active = False        # set by the owner of the optimizer when AdamWFlat.lazy_zero is in force (see _wgrad)
         self.fused_head = os.environ.get("TR1_FUSED_HEAD", "1") != "0"    # lm_head -> logp / entropy in the GEMM epilogue where the logits are not kept
         self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
         self._side = None
@@ -49,11 +50,14 @@ class Engine:
         reading 4 bytes per parameter (33 GB per accumulation window at 7B)."""
         ops = self.ops
         acc = True
-        if key is not None and self.wgrad_overwrite_first:
+        if key is not None:
             ver = getattr(self.params.train, "version", None)
             if ver is not None and self._gw_ver.get(key) != ver:
                 self._gw_ver[key] = ver
-                acc = False
+                if self.wgrad_overwrite_first:
+                    acc = False
+                elif self.lazy_zero_active and key.split(".", 1)[-1] in self.OVERWRITTEN:
+                    gw.zero_()      # overwrite was switched off after the optimizer left this matrix un-zeroed (AdamWFlat.lazy_zero): never accumulate onto stale values
         # bias_g: the Linear's bias gradient (column sums of dy) rides on the pass that builds dy^T
         if dyt is None:                                  # (the fused down dgrad hands over dgu^T from its epilogue)
             dyt = ops.transpose(dy, colsum=bias_g) if bias_g is not None else ops.transpose(dy)      # [N, Mp], zero-padded columns

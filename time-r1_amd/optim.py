@@ -30,13 +30,19 @@ class AdamWFlat:
         # Engine.lazy_zero_plan(): the decoder layers' large matrices are overwritten by the next window's first weight gradients, so this step does
         # not zero them (set by the owner of the engine; None = zero the whole gradient arena as DeepSpeed's engine.step / optimizer.zero_grad do)
         self.lazy_zero = None
+        self.lazy_zero_ok = None      # callable -> bool, re-checked at every step (the trainer passes `lambda: engine.wgrad_overwrite_first`): the plan is only
+                                      # sound while the engine's first weight gradient of a window still OVERWRITES the matrices this step leaves un-zeroed
+
+    def _lz(self):
+        ok = self.lazy_zero_ok
+        return self.lazy_zero if (self.lazy_zero and (ok is None or ok())) else None
 
     def norm_sink_begin(self, engine):
         """Call before the backward of a window's LAST micro-step (single process): returns the sink to hang on `engine.norm_sink` for that backward, or
         None.  The weight-gradient epilogues of the decoder layers' large matrices then leave the squared norm of the final gradient values, and step()
         reads only the rest of the arena (embedding, norms, biases, lm_head, merger) for the global norm: 30 GB less to stream per step at 7B."""
         self._sink = None
-        lz = self.lazy_zero
+        lz = self._lz()
         if self.dp.enabled or not lz or engine is None:
             return None
         if getattr(self, "_partials", None) is None:
@@ -51,7 +57,7 @@ class AdamWFlat:
 
     def _norm_from_sink(self):
         """True when the global squared norm could be assembled from the sink + the uncovered parts of the arena (self._sumsq then holds it)."""
-        sink, a, lz = getattr(self, "_sink", None), self.params.train, self.lazy_zero
+        sink, a, lz = getattr(self, "_sink", None), self.params.train, self._lz()
         self._sink = None
         if not sink or not lz or sink["covered"] != sink["want"] or sink["gver"] != getattr(a, "version", 0):
             return False
@@ -70,7 +76,7 @@ class AdamWFlat:
 
     def _zero_spans(self, n):
         """[(a, b, zero_flag)] covering [0, n) for the fused AdamW launches + the periodic clean-up of the small per-layer tensors."""
-        lz = self.lazy_zero
+        lz = self._lz()
         if not lz:
             return [(0, n, True)], None
         a, b = lz["base"], lz["base"] + lz["stride"] * lz["count"]
@@ -109,7 +115,8 @@ class AdamWFlat:
             self.ops.adamw_step(a.master[x:y], a.m[x:y], a.v[x:y], a.grad[x:y], a.w16[x:y], self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps,
                                 self.weight_decay, self.step_count, sumsq=self._sumsq, max_norm=self.max_grad_norm, grad_mult=mult, zero_grad=z, **kw)
         if small:
-            self.ops.zero_ranges_periodic(a.grad, self.lazy_zero["base"], self.lazy_zero["stride"], self.lazy_zero["count"], small)
+            lz = self._lz()
+            self.ops.zero_ranges_periodic(a.grad, lz["base"], lz["stride"], lz["count"], small)
         return self._sumsq.sqrt() * mult
 
     def _step_sharded(self, lr=None):
@@ -142,7 +149,8 @@ class AdamWFlat:
             if z:
                 a.grad[x:y].zero_()
         if small:
-            ops.zero_ranges_periodic(a.grad, self.lazy_zero["base"], self.lazy_zero["stride"], self.lazy_zero["count"], small)
+            lz = self._lz()
+            ops.zero_ranges_periodic(a.grad, lz["base"], lz["stride"], lz["count"], small)
         for w in works:
             w.wait()
         return self._sumsq.sqrt() * mult

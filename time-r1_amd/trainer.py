@@ -368,6 +368,8 @@ class TimeR1_Trainer:
                                    shard_optimizer=self._wants_shard(args, self.dp))
         # the decoder layers' large gradient matrices are overwritten by the first micro-step of every window: the optimizer does not zero them
         self.optimizer.lazy_zero = self.engine.lazy_zero_plan() if getattr(args, "lazy_grad_zero", True) else None
+        self.engine.lazy_zero_active = self.optimizer.lazy_zero is not None
+        self.optimizer.lazy_zero_ok = lambda eng=self.engine: bool(eng.wgrad_overwrite_first)      # re-checked at every step (A/B attribute)
         self._metrics_store = defaultdict(list)
         self._pending = []                   # micro-steps whose device-side metric values have not been fetched yet (_flush_metrics)
         self._clock = _PhaseClock(ops)
@@ -500,6 +502,7 @@ class TimeR1_Trainer:
         comp_host = getattr(st, "completion_ids_host", None)
         if comp_host is None:
             comp_host = tokens.cpu().numpy()
+            getattr(self.ops, "grid_sync_check", lambda: None)()      # a fused decode launch that gave up waiting must not go unnoticed
         self.core.forward_logps(st)
         mask_np = eos_mask(comp_host, self.processing_class.eos_token_id)
         completions = self.processing_class.batch_decode(torch.as_tensor(comp_host), skip_special_tokens=True)
@@ -644,6 +647,7 @@ class TimeR1_Trainer:
             self.core.rollout(todo[0])
         for st in todo:
             st.completion_ids_host = st.completion_ids.cpu().numpy()        # one wait for the decode loop, ahead of every update
+            getattr(self.ops, "grid_sync_check", lambda: None)()      # a fused decode launch that gave up waiting must not go unnoticed
         clock.mark("rollout")
         return [self._step_finish(c, last_in_window=(i == len(ctxs) - 1)) for i, c in enumerate(ctxs)]
 

@@ -7,7 +7,7 @@ import time_r1_amd  # noqa
 from time_r1_amd.ops import HipOps
 ops = HipOps("cuda:0")
 P, G, C, B = (3266, 16, 1024, 2) if len(sys.argv) < 5 else map(int, sys.argv[1:5])
-nh, nkv, hd = 28, 4, 128
+nh, nkv, hd = int(os.environ.get("NH", 28)), int(os.environ.get("NKV", 4)), 128      # NH=12 NKV=2: Qwen2-VL-2B (config 2)
 S = P + G * C
 scap = (S + 63) // 64 * 64
 NC = 12
@@ -15,7 +15,7 @@ ks = [(torch.randn(B * scap, nkv * hd, device="cuda") * 0.5).bfloat16() for _ in
 vts = [(torch.randn(nkv * hd, B * scap, device="cuda") * 0.5).bfloat16() for _ in range(NC)]
 q = (torch.randn(B * G, nh * hd, device="cuda") * 0.5).bfloat16()
 nsplit = int(os.environ.get("TR1_DECODE_NSPLIT", max(1, min(28, ((P + 63) // 64 + 3) // 2))))
-for step in (1, C // 4, C // 2, C - 1):
+for step in ([int(s) for s in os.environ["STEPS"].split(",")] if os.environ.get("STEPS") else (1, C // 4, C // 2, C - 1)):
     pre = torch.full((B * G,), P, dtype=torch.int32, device="cuda")
     lo = (P + torch.arange(G) * C).int().repeat(B).cuda()
     hi = (lo + step).int()

@@ -10,11 +10,12 @@ OBJ = "/tmp/tr1_var_obj_%s" % name
 BASE = os.path.join(ROOT, "time-r1_amd", "build")
 os.makedirs(OBJ, exist_ok=True)
 macros = [f[2:].split("=")[0] for f in flags if f.startswith("-D")]
+all_files = any(not f.startswith("-D") for f in flags)      # a code-generation flag (-mllvm ...) concerns every file
 def comp(f):
     src = os.path.join(CSRC, f)
     txt = open(src).read()
     base_o = os.path.join(BASE, f[:-4] + ".o")
-    if not any(m in txt for m in macros) and os.path.exists(base_o) and os.path.getmtime(base_o) >= os.path.getmtime(src):
+    if not all_files and not any(m in txt for m in macros) and os.path.exists(base_o) and os.path.getmtime(base_o) >= os.path.getmtime(src):
         return base_o
     o = os.path.join(OBJ, f[:-4] + ".o")
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"] + flags +
