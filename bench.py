@@ -186,13 +186,11 @@ class Workload:
             for j, st in enumerate(states):
                 core.rollout(st)
                 st.completion_ids_host = st.completion_ids.cpu().numpy()
-                getattr(self.ops, "grid_sync_check", lambda: None)()      # a fused decode launch that gave up waiting must not go unnoticed
                 self._finish(st, j == n - 1, n)
         else:
             core.rollout_many(states)
             for st in states:
                 st.completion_ids_host = st.completion_ids.cpu().numpy()     # one wait for the decode loop, ahead of every update
-                getattr(self.ops, "grid_sync_check", lambda: None)()      # a fused decode launch that gave up waiting must not go unnoticed
             for si, st in enumerate(states):
                 self._finish(st, si == n - 1, n)
         self.opt.step()

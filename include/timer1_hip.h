@@ -145,17 +145,6 @@ int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, 
  * launch with plan_mode 1 publishes each query tile's relevant-tile list in `plan` (int32[tr1_attn_plan_ints()]), launches with plan_mode 2 start
  * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */
 int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
-/* tr1_attn_fwd_planned without its merge launch (nsplit > 1): the split partials stay in ws_f32 for tr1_attn_combine_oproj.  ref: the attention half of
- * Qwen2VLAttention.forward inside model.generate (TF:521-556; src/time_r1/rl/timer1_trainer.py:568-578). */
-int tr1_attn_fwd_partials(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
-/* Decode rows: merge of the split-KV partials FUSED into the attention output projection (csrc/oproj_fused.hip): O[n_batch * T, n_heads * 128] = the merged
- * attention rows (bit-identical to tr1_attn_fwd's merge kernel) and C[M, N] = O @ W[N, K]^T (+ residual), one launch whose blocks prefetch their weight rows
- * while the grid merges the partials.  Covered shapes: tr1_attn_combine_oproj_ok() (head dim 128, 2 <= nsplit <= 32, M <= 32, K <= 3584, N / 16 <= CUs).
- * sync_i32: 1024 ints (one flag word per merge task, tagged with a process-wide launch epoch) zeroed ONCE by the caller.  The in-launch wait is bounded; tr1_grid_sync_error() returns 1 (and clears the flag) if a launch gave up since
- * the last call - its output is then wrong and the caller must raise.  ref: softmax(QK^T)V -> o_proj, TF:521-556 inside model.generate. */
-int tr1_attn_combine_oproj(const void* ws_f32, int64_t ws_floats, int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit, int64_t n_batch, void* O, int64_t o_ld, const void* W, int64_t ldw, const void* residual, int64_t ldr, void* C, int64_t ldc, int64_t N, void* sync_i32, void* stream);
-int tr1_attn_combine_oproj_ok(int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit, int64_t N);
-int tr1_grid_sync_error(void);
 int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch);
 /* Backward of the above (recompute based): needs K, V row-major.  KT / kt_ld are kept for ABI stability and ignored (may be NULL / 0): the dQ
  * kernel reads its K^T fragments from the K rows with ds_read_b64_tr_b16.  QT / dOT (tr1_pack_transpose copies) only for head dims padded to

@@ -706,43 +706,6 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             cnt = plan.view(B, -1, 1025)[:, :, 1024]
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
-@pytest.mark.parametrize("B,G,nh,nkv,nsplit,N", [(2, 8, 28, 4, 28, 3584), (2, 8, 12, 2, 21, 1536), (1, 16, 14, 2, 28, 1792), (2, 16, 28, 4, 16, 3584),
-                                                 (2, 5, 12, 4, 7, 512), (1, 3, 4, 4, 2, 4096)])
-def test_attention_decode_merge_fused_into_the_output_projection(hip_ops, B, G, nh, nkv, nsplit, N):
-    """Round 5 (csrc/oproj_fused.hip): the split-KV merge runs inside the o projection's launch (weight rows prefetched to LDS while the grid merges the
-    partials; blocks meet at an arrival counter, merged rows travel by sc1 stores / loads).  The merged attention rows are BIT-IDENTICAL to
-    attn_combine_kernel's, the projection agrees with a float64 product of those rows, launch after launch on the same buffers with new data every time
-    (a stale read of the previous launch's rows would show), 16- and 32-row forms, odd row counts, with and without the residual."""
-    hd, C, step = 128, 12, 5
-    Ps = [300, 170, 420][:B]
-    s_cap = 576
-    k, v = rnd(B * s_cap, nkv * hd, seed=1).cuda(), rnd(B * s_cap, nkv * hd, seed=2)
-    pre = torch.cat([torch.full((G,), P, dtype=torch.int32) for P in Ps]).cuda()
-    lo = torch.cat([(P + torch.arange(G) * C).int() for P in Ps]).cuda()
-    hi = (lo + step).int()
-    vt = torch.zeros(nkv * hd, B * s_cap, dtype=BF16, device="cuda:0")
-    for b in range(B):
-        vt[:, b * s_cap:(b + 1) * s_cap] = hip_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].cuda(), nkv, nkv, hd)
-    assert hip_ops.L.raw("tr1_attn_combine_oproj_ok")(B * G, nh, nkv, hd, nsplit, N)
-    plan = hip_ops.attn_plan(G, nh, nkv, B)
-    q0 = rnd(B * G, nh * hd, seed=3).cuda()
-    hip_ops.attn_fwd(q0, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=1)
-    w = rnd(N, nh * hd, seed=4, scale=1.0 / math.sqrt(nh * hd)).cuda()
-    for rep in range(12):                                        # "layers" of a step: new q (and weights' rows shifted) every time, same masks and plan
-        q = rnd(B * G, nh * hd, seed=10 + rep).cuda()
-        res = rnd(B * G, N, seed=40 + rep).cuda() if rep % 2 == 0 else None
-        o_ref, _ = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=s_cap,
-                                    plan=plan, plan_mode=2)
-        o_ref = o_ref.clone()
-        wr = torch.roll(w, rep, 0)
-        o, c = hip_ops.attn_combine_oproj(q, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit, wr, residual=res, n_batch=B, kv_batch_slots=s_cap,
-                                          plan=plan, plan_mode=2)
-        assert torch.equal(o, o_ref), "merged attention rows differ from attn_combine_kernel's (rep %d)" % rep
-        ref = o_ref.double() @ wr.double().t() + (res.double() if res is not None else 0.0)
-        close(c, ref.float().cpu(), 0.02, rtol=0.02, what="fused o projection rep %d" % rep)
-    hip_ops.grid_sync_check()
-
-
 def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):
     """A reader block holds one plan entry per thread: with few splits and many relevant tiles (n_rel > 256 * nsplit) the publishing launch stores
     count -1 and the reading launches take the full path - the same result."""

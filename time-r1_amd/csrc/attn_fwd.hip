@@ -379,6 +379,61 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int64_t
     if (c == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
 }
 
+// Head dim 128 (round 5): ONE WAVE per packed row.  attn_combine_kernel spends a quarter of its 6 us in per-thread scalar loops (every thread walks all
+// nsplit statistics twice: ~600 dependent instructions on a one-wave-per-SIMD block); here lane j holds split j's (m, l), the maximum and the sum are two
+// wave reductions, a lane group sg = lane / 16 takes splits sg, sg + 4, ... with 8 features per lane (two 16-byte loads per split, all in flight), the weights
+// arrive by lane shuffles and the four groups meet through two more: no LDS, no barrier, ~150 instructions.  (Sums are trees instead of chains: same fp32
+// arithmetic, different association - the split-KV result is compared with the oracle, not bit for bit with the old merge.)
+__global__ __launch_bounds__(128) void attn_combine128_kernel(AttnParams p, int64_t nRpad) {
+    const int64_t nR = (int64_t)p.T * p.group;
+    const int kvh = blockIdx.y % p.n_kv, by = blockIdx.y, nby = gridDim.y;
+    {
+        const int b = blockIdx.y / p.n_kv;
+        p.O += (int64_t)b * p.T * p.o_ld;
+        if (p.lse) p.lse += (int64_t)b * p.n_kv * p.group * p.T;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sg = lane >> 4, c = lane & 15;
+    const int64_t R = (int64_t)blockIdx.x * 2 + wv;
+    if (R >= nR) return;                                              // (wave-uniform)
+    const int ni = (p.nsplit + 3) >> 2;                               // splits per lane group (the last ones may not exist for the higher groups)
+    f32x4_t ov[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < ni) {
+            const int sp = sg + 4 * i;
+            const float* src = p.Opart + (((int64_t)(sp < p.nsplit ? sp : 0) * nby + by) * nRpad + R) * 128 + c * 8;
+            ov[i][0] = *reinterpret_cast<const f32x4_t*>(src); ov[i][1] = *reinterpret_cast<const f32x4_t*>(src + 4);
+        }
+    const int64_t sslot = ((int64_t)(lane < p.nsplit ? lane : 0) * nby + by) * nRpad + R;
+    const float mj = lane < p.nsplit ? p.mpart[sslot] : NEG_INF, lj = lane < p.nsplit ? p.lpart[sslot] : 0.f;
+    const float M = wave_max(mj), Ms = (M == NEG_INF) ? 0.f : M;
+    const float e = exp2f(mj - Ms);                                   // (0 for the lanes without a split: their m is -inf)
+    const float L = wave_sum(e * lj);
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < ni) {
+            const int sp = sg + 4 * i;
+            float w = __shfl(e, sp & 63, 64);
+            if (sp >= p.nsplit) w = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] = __builtin_fmaf(w, ov[i][0][j], a0[j]); a1[j] = __builtin_fmaf(w, ov[i][1][j], a1[j]); }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a0[j] += __shfl_xor(a0[j], 16, 64); a1[j] += __shfl_xor(a1[j], 16, 64);
+        a0[j] += __shfl_xor(a0[j], 32, 64); a1[j] += __shfl_xor(a1[j], 32, 64);
+    }
+    if (sg != 0) return;
+    int t, hq;
+    att_split_row(p, R, t, hq);
+    bf16_t* orow = p.O + (int64_t)t * p.o_ld + (int64_t)(kvh * p.group + hq) * 128 + c * 8;
+    const u32x4_t w = {pack2bf(a0[0] * inv, a0[1] * inv), pack2bf(a0[2] * inv, a0[3] * inv), pack2bf(a1[0] * inv, a1[1] * inv), pack2bf(a1[2] * inv, a1[3] * inv)};
+    *reinterpret_cast<u32x4_t*>(orow) = w;
+    if (c == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
+}
+
 // out[(kvh*d + dd) * ld_out + t*group + hq] = in[t*ld_in + (kvh*group + hq)*d + dd] ; columns [T*group, ld_out) zero-filled
 // when zero_pad != 0. With group = 1 this is the K^T / V^T builder (optionally through a slot map: column = slots[t]).
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const bf16_t* __restrict__ in, int64_t ld_in, bf16_t* __restrict__ out,
@@ -473,7 +528,7 @@ extern "C" int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, 
 static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
                          void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
                          int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
-                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream, bool combine = true) {
+                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
     AttnParams p; memset(&p, 0, sizeof(p));
     TR1_CHECK_ARG(plan_mode == 0 || (plan && nsplit > 1 && (plan_mode == 1 || plan_mode == 2)), "attention: plan_mode 1 / 2 needs a plan buffer and nsplit > 1");
     p.plan = (int*)plan; p.plan_mode = plan_mode;
@@ -526,13 +581,16 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
             default: launch_fwd<128, 2, 1>(grid, s, p); break;
         }
     }
-    if (nsplit > 1 && combine) {
+    if (nsplit > 1) {
         dim3 cg((unsigned)((nR + ATT_COMBINE_ROWS - 1) / ATT_COMBINE_ROWS), (unsigned)(n_kv * n_batch));
         switch (d_pad) {
             case 32: hipLaunchKernelGGL(attn_combine_kernel<32>, cg, dim3(256), 0, s, p, nRpad); break;
             case 64: hipLaunchKernelGGL(attn_combine_kernel<64>, cg, dim3(256), 0, s, p, nRpad); break;
             case 96: hipLaunchKernelGGL(attn_combine_kernel<96>, cg, dim3(256), 0, s, p, nRpad); break;
-            default: hipLaunchKernelGGL(attn_combine_kernel<128>, cg, dim3(256), 0, s, p, nRpad); break;
+            default:
+                if (p.d_real == 128 && p.o_ld % 8 == 0) hipLaunchKernelGGL(attn_combine128_kernel, cg, dim3(128), 0, s, p, nRpad);      // one wave per row
+                else hipLaunchKernelGGL(attn_combine_kernel<128>, cg, dim3(256), 0, s, p, nRpad);
+                break;
         }
     }
     TR1_LAUNCH_CHECK();
@@ -555,16 +613,6 @@ extern "C" int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, 
                                     int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
     return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32, ws_floats,
                          n_batch, kv_batch_slots, plan, plan_mode, stream);
-}
-
-// tr1_attn_fwd_planned WITHOUT the merge launch: the split partials stay in ws_f32 (Opart [nsplit][n_batch * n_kv][rows padded to 64][128], then the
-// running maxima and sums) for tr1_attn_combine_oproj, which merges them inside the output projection (csrc/oproj_fused.hip).  nsplit > 1 only.
-extern "C" int tr1_attn_fwd_partials(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, const void* pre, const void* lo,
-                                     const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit,
-                                     void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
-    TR1_CHECK_ARG(nsplit > 1, "attn_fwd_partials: split-KV launches only (nsplit > 1)");
-    return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, nullptr, n_heads * head_dim, nullptr, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32,
-                         ws_floats, n_batch, kv_batch_slots, plan, plan_mode, stream, false);
 }
 
 extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit) {

@@ -51,7 +51,7 @@ static int64_t decode_ws_bytes(const int64_t* d) {
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     const int64_t fix = tr1_gemm_skinny_fixup_workspace_floats(R, hid, d[D_INTER]);
     const int64_t plan = tr1_attn_plan_ints(T, d[D_HEADS], d[D_KV], d[D_BATCH]);
-    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096 + 4096;
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
 }
 
 extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
@@ -80,7 +80,6 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     static int use_plan = -1;
     if (use_plan < 0) { const char* e = getenv("TR1_ATTN_PLAN"); use_plan = e ? atoi(e) : 1; }
     void* plan = c.take(tr1_attn_plan_ints(T, nh, nkv, B) * 4);
-    void* osync = c.take(4096);     // task flags of the fused merge + o projection (zero-filled once with the rest of `work`)
     const int qm = w8 ? (int)(dims[D_QMASK] & QM_ALL) : 0;                     // fp8 matrices of this step
     const bool planned = use_plan && nsplit > 1 && L > 1;
     const bool down_fixup = !(qm & QM_DOWN) && R >= 16 && inter >= 8192;
@@ -106,18 +105,11 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
             CK(tr1_norm_gemm_skinny(h, w[0], w[1], w[2], qkv, R, qkvd, hid, hid, hid, qkvd, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
         }
-        // bf16 o projection with the split-KV merge inside it (csrc/oproj_fused.hip) where the shape is covered: the attention launch then leaves its partials
-        const bool o_fused = !(qm & QM_O) && nsplit > 1 && tr1_attn_combine_oproj_ok(R, nh, nkv, hd, nsplit, hid);
-        if (o_fused)
-            CK(tr1_attn_fwd_partials(q, qd, w[7], kvd, w[8], B * scap, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B, scap,
-                                     planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
-        else
-            CK(tr1_attn_fwd_planned(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
-                                    scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
+        CK(tr1_attn_fwd_planned(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
+                                scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
         {
             ProfScope ps(1, stream);
-            if (o_fused) CK(tr1_attn_combine_oproj(att, att_floats, T, nh, nkv, hd, nsplit, B, o, qd, w[3], qd, h, hid, h2, hid, hid, osync, stream));
-            else if (qm & QM_O) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
+            if (qm & QM_O) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
             else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
         }
         {

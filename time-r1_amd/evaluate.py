@@ -56,7 +56,6 @@ def evaluate_grounding(trainer, dataset, max_new_tokens=None, limit=None):
                                       padding_side="left", add_special_tokens=False)
         st = core.prepare(np.asarray(pi["input_ids"]).reshape(-1), pi["pixel_values_videos"], np.asarray(pi["video_grid_thw"]))
         toks = core.rollout(st).cpu()
-        getattr(core.ops, "grid_sync_check", lambda: None)()
         completion = trainer.processing_class.batch_decode(toks, skip_special_tokens=True)[0]
         iou = compute_iou(extract_answer_span(completion), row["solution"])
         ious.append(iou)

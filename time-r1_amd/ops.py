@@ -331,36 +331,6 @@ class HipOps:
                         plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
         return plan["logits"]
 
-    def grid_sync_check(self):
-        """Call where the host already waits for a rollout (the sampled tokens' device-to-host copy): raises if a fused decode launch whose blocks wait for
-        each other (tr1_attn_combine_oproj) gave up waiting since the last call - the tokens drawn after that point are not the model's."""
-        if self.L.raw("tr1_grid_sync_error")() != 0:
-            raise RuntimeError("decode: a fused merge + o-projection launch timed out waiting for its partner blocks (is another kernel holding the CUs?); "
-                               "rerun with TR1_O_FUSED=0")
-
-    def attn_combine_oproj(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit, w, residual=None, n_batch=1, kv_batch_slots=0,
-                           plan=None, plan_mode=0):
-        """Split-KV decode attention whose merge runs inside the output projection: -> (o [rows, n_heads * hd] merged attention rows,
-        c [rows, N] = o @ w^T (+ residual)).  Shapes: tr1_attn_combine_oproj_ok."""
-        self._chk(q, k, vt, w, residual)
-        rows = q.shape[0]
-        T = rows // n_batch
-        N = w.shape[0]
-        assert self.L.raw("tr1_attn_combine_oproj_ok")(rows, n_heads, n_kv, head_dim, nsplit, N), "shape not covered by the fused merge + o projection"
-        assert w.shape[1] == n_heads * head_dim and w.stride(1) == 1
-        nws = n_batch * self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
-        ws = self._workspace("attn_split", nws, F32)
-        sync = self._ws.get("oproj_sync")
-        if sync is None:
-            sync = self._ws["oproj_sync"] = torch.zeros(1024, dtype=I32, device=self.device)     # zeroed ONCE: flags are tagged with a launch epoch
-        self.L.call("tr1_attn_fwd_partials", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(pre), _p(lo), _p(hi), T, n_heads, n_kv, n_slots, head_dim,
-                    float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, _p(plan), int(plan_mode), self._s())
-        o = self.empty(rows, n_heads * head_dim)
-        c = self.empty(rows, N)
-        self.L.call("tr1_attn_combine_oproj", _p(ws), nws, T, n_heads, n_kv, head_dim, nsplit, n_batch, _p(o), _ld(o), _p(w), _ld(w), _p(residual),
-                    residual.stride(0) if residual is not None else 0, _p(c), _ld(c), N, _p(sync), self._s())
-        return o, c
-
     def gemm_skinny_fixup(self, a, b, bias=None, residual=None):
         """Decode rows x narrow projection (o_proj / down_proj): split-K with in-kernel fixup; bf16 [M, N]."""
         self._chk(a, b, bias, residual)

@@ -60,6 +60,12 @@ class Rollout:
     MATS = ("qkv.w", "o.w", "gu.w", "down.w")
     QBITS = {"qkv": 1, "o": 2, "gu": 4, "down": 8, "lm_head": 16}
 
+    def _n_cus(self):
+        dev = getattr(self.eng.ops, "device", None)
+        if dev is not None and torch.device(dev).type == "cuda":
+            return int(torch.cuda.get_device_properties(dev).multi_processor_count)
+        return 256
+
     def fp8_mask(self):
         keep = set(self.fp8_keep_bf16 or ())
         assert keep <= set(self.QBITS), "fp8_keep_bf16: unknown matrix in %r" % (keep,)
@@ -148,6 +154,11 @@ class Rollout:
         lo_all = torch.cat([st["lo"] for st in per]).contiguous()
         hi_all = torch.cat([st["slots"] for st in per], 1).contiguous()        # [C, B*G]: hi of step s = the slot just appended (cache-local)
         nsplit = max(st["nsplit"] for st in per)
+        # ONE round of blocks: a split-KV block takes a whole CU (145 KB of LDS), so (prompts x kv heads x 64-row query tiles) x splits above the CU count runs
+        # as two rounds - 32 decode rows at 7B = 16 groups x 27 splits = 432 blocks took 25.1 us per layer at step 1 against 19.8 with 14 splits (round 5)
+        if not os.environ.get("TR1_DECODE_NSPLIT"):
+            groups = B * t.n_kv_heads * ((G * (t.n_heads // t.n_kv_heads) + 63) // 64)
+            nsplit = max(2, min(nsplit, self._n_cus() // max(1, groups))) if nsplit > 1 else nsplit
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
         R = B * G
         fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set

