@@ -145,6 +145,15 @@ int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, 
  * launch with plan_mode 1 publishes each query tile's relevant-tile list in `plan` (int32[tr1_attn_plan_ints()]), launches with plan_mode 2 start
  * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */
 int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
+/* tr1_attn_fwd_planned whose merged rows leave FRAGMENT-MAJOR for tr1_gemm_oproj_frag: Ofrag holds ceil(n_batch * T / 16) * 16 x n_heads * 128 bf16, element (row m,
+ * feature k) at ((m / 16) * (n_heads * 4) + k / 32) * 512 + (m % 16) * 32 + k % 32 (the 16 rows x 64 bytes of an MFMA operand fragment are one contiguous KiB).
+ * Split-KV launches (nsplit > 1) at head dim 128.  ref: attention half of Qwen2VLAttention.forward inside model.generate (TF:521-552). */
+int tr1_attn_fwd_planned_frag(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* Ofrag, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
+/* Decode rows (M <= 32): C[M, N] = X @ W[N, K]^T (+ residual) with X fragment-major (layout above, K = n_heads * 128 <= 3584): every block keeps its whole
+ * weight slice in flight (HBM -> LDS DMA) and owns its columns over the whole K - no split-K fixup (csrc/oproj.hip).  tr1_gemm_oproj_frag_ok: shape covered?
+ * ref: o_proj of Qwen2VLAttention.forward (TF:553-556) inside model.generate (src/time_r1/rl/timer1_trainer.py:568-578). */
+int tr1_gemm_oproj_frag(const void* Xfrag, const void* W, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t ldr, int64_t ldc, void* stream);
+int tr1_gemm_oproj_frag_ok(int64_t M, int64_t N, int64_t K);
 int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch);
 /* Backward of the above (recompute based): needs K, V row-major.  KT / kt_ld are kept for ABI stability and ignored (may be NULL / 0): the dQ
  * kernel reads its K^T fragments from the K rows with ds_read_b64_tr_b16.  QT / dOT (tr1_pack_transpose copies) only for head dims padded to

@@ -706,6 +706,42 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             cnt = plan.view(B, -1, 1025)[:, :, 1024]
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
+@pytest.mark.parametrize("B,G,nh,nkv,nsplit,N", [(2, 8, 28, 4, 28, 3584), (2, 8, 12, 2, 21, 1536), (1, 16, 14, 2, 28, 1792), (2, 16, 28, 4, 16, 3584),
+                                                 (2, 5, 12, 4, 7, 512), (1, 3, 4, 4, 2, 4096)])
+def test_decode_o_projection_on_fragment_major_attention_rows(hip_ops, B, G, nh, nkv, nsplit, N):
+    """Round 5 (csrc/oproj.hip): the split-KV merge writes its rows fragment-major ([k / 32][16 rows][32 k]: the 16 rows x 64 bytes of an MFMA operand fragment
+    are one contiguous KiB) and the o projection keeps its whole weight slice in flight with no cross-block fixup.  The fragment-major rows hold exactly the
+    bits of the row-major merge; the projection agrees with a float64 product; 16- and 32-row forms, odd row counts, column blocks of 14 / 6 / 7 / 16 columns."""
+    hd, C, step = 128, 12, 5
+    Ps = [300, 170, 420][:B]
+    s_cap = 576
+    k, v = rnd(B * s_cap, nkv * hd, seed=1).cuda(), rnd(B * s_cap, nkv * hd, seed=2)
+    pre = torch.cat([torch.full((G,), P, dtype=torch.int32) for P in Ps]).cuda()
+    lo = torch.cat([(P + torch.arange(G) * C).int() for P in Ps]).cuda()
+    hi = (lo + step).int()
+    vt = torch.zeros(nkv * hd, B * s_cap, dtype=BF16, device="cuda:0")
+    for b in range(B):
+        vt[:, b * s_cap:(b + 1) * s_cap] = hip_ops.pack_transpose(v[b * s_cap:(b + 1) * s_cap].cuda(), nkv, nkv, hd)
+    M, K = B * G, nh * hd
+    assert hip_ops.L.raw("tr1_gemm_oproj_frag_ok")(M, N, K)
+    plan = hip_ops.attn_plan(G, nh, nkv, B)
+    q0 = rnd(M, K, seed=3).cuda()
+    hip_ops.attn_fwd(q0, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=1)
+    w = rnd(N, K, seed=4, scale=1.0 / math.sqrt(K)).cuda()
+    for rep in range(3):
+        q = rnd(M, K, seed=10 + rep).cuda()
+        res = rnd(M, N, seed=40 + rep).cuda() if rep % 2 == 0 else None
+        o_ref, _ = hip_ops.attn_fwd(q, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit=nsplit, need_lse=False, n_batch=B, kv_batch_slots=s_cap,
+                                    plan=plan, plan_mode=2)
+        of = hip_ops.attn_fwd_frag(q, k, vt, pre, lo, hi, nh, nkv, s_cap, hd, hd ** -0.5, nsplit, n_batch=B, kv_batch_slots=s_cap, plan=plan, plan_mode=2)
+        Mp = (M + 15) // 16 * 16
+        back = of.view(Mp // 16, K // 32, 16, 32).permute(0, 2, 1, 3).reshape(Mp, K)[:M]
+        assert torch.equal(back, o_ref), "fragment-major rows differ from the row-major merge (rep %d)" % rep
+        c = hip_ops.gemm_oproj_frag(of, w, M, residual=res)
+        ref = o_ref.double() @ w.double().t() + (res.double() if res is not None else 0.0)
+        close(c, ref.float().cpu(), 0.02, rtol=0.02, what="o projection on fragment-major rows, rep %d" % rep)
+
+
 def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):
     """A reader block holds one plan entry per thread: with few splits and many relevant tiles (n_rel > 256 * nsplit) the publishing launch stores
     count -1 and the reading launches take the full path - the same result."""

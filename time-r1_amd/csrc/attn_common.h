@@ -45,6 +45,9 @@ struct AttnParams {
     // split-KV decode: the relevant-tile lists of a decode step are the same in every layer (same pre / lo / hi), so the first layer's launch
     // (plan_mode 1) stores them - [n_batch][q tiles][ATT_LIST_CAP ids + count] - and the other layers' launches (plan_mode 2) read them
     int* plan; int plan_mode;
+    // split-KV decode at head dim 128: the merge kernel writes O FRAGMENT-MAJOR for tr1_gemm_oproj_frag (csrc/oproj.hip) - element (row m, feature k) at
+    // ((m / 16) * (n_heads * 4) + k / 32) * 512 + (m % 16) * 32 + k % 32, m = batch entry * T + token - instead of row-major [rows, n_heads * 128]
+    int o_frag;
     // nsplit == 1 (training / prefill / ViT): the (query tile, kv head) grid is launched as ONE dimension of xcd_pad blocks and re-mapped so that
     // each of the 8 XCDs (blocks are dealt to them round-robin) walks chunks of 8 CONSECUTIVE blocks of it: the query tiles that share a segment's / a
     // head's K and V tiles then meet in one L2 instead of fetching them from HBM once per XCD.  grid_x / grid_y = the logical grid.

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(128) void attn_combine128_kernel(AttnParams p, int6
     const int kvh = blockIdx.y % p.n_kv, by = blockIdx.y, nby = gridDim.y;
     {
         const int b = blockIdx.y / p.n_kv;
-        p.O += (int64_t)b * p.T * p.o_ld;
+        if (!p.o_frag) p.O += (int64_t)b * p.T * p.o_ld;
         if (p.lse) p.lse += (int64_t)b * p.n_kv * p.group * p.T;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sg = lane >> 4, c = lane & 15;
@@ -429,6 +429,10 @@ __global__ __launch_bounds__(128) void attn_combine128_kernel(AttnParams p, int6
     int t, hq;
     att_split_row(p, R, t, hq);
     bf16_t* orow = p.O + (int64_t)t * p.o_ld + (int64_t)(kvh * p.group + hq) * 128 + c * 8;
+    if (p.o_frag) {                                                   // fragment-major for the o projection (AttnParams::o_frag)
+        const int m = (int)(blockIdx.y / p.n_kv) * p.T + t, kf = (kvh * p.group + hq) * 128 + c * 8;
+        orow = p.O + ((((int64_t)(m >> 4) * (p.n_kv * p.group * 4) + (kf >> 5)) * 16 + (m & 15)) * 32 + (kf & 31));
+    }
     const u32x4_t w = {pack2bf(a0[0] * inv, a0[1] * inv), pack2bf(a0[2] * inv, a0[3] * inv), pack2bf(a1[0] * inv, a1[1] * inv), pack2bf(a1[2] * inv, a1[3] * inv)};
     *reinterpret_cast<u32x4_t*>(orow) = w;
     if (c == 0 && p.lse) p.lse[(int64_t)(kvh * p.group + hq) * p.T + t] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : NEG_INF;
@@ -528,8 +532,10 @@ extern "C" int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, 
 static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* O, int64_t o_ld,
                          void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv,
                          int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch,
-                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
+                         int64_t kv_batch_slots, void* plan, int plan_mode, void* stream, int o_frag = 0) {
     AttnParams p; memset(&p, 0, sizeof(p));
+    p.o_frag = o_frag;
+    TR1_CHECK_ARG(!o_frag || (nsplit > 1 && head_dim == 128), "attention: fragment-major output needs the split-KV merge at head dim 128");
     TR1_CHECK_ARG(plan_mode == 0 || (plan && nsplit > 1 && (plan_mode == 1 || plan_mode == 2)), "attention: plan_mode 1 / 2 needs a plan buffer and nsplit > 1");
     p.plan = (int*)plan; p.plan_mode = plan_mode;
     TR1_CHECK_ARG(n_batch >= 1, "attention: n_batch must be >= 1");
@@ -588,7 +594,7 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
             case 64: hipLaunchKernelGGL(attn_combine_kernel<64>, cg, dim3(256), 0, s, p, nRpad); break;
             case 96: hipLaunchKernelGGL(attn_combine_kernel<96>, cg, dim3(256), 0, s, p, nRpad); break;
             default:
-                if (p.d_real == 128 && p.o_ld % 8 == 0) hipLaunchKernelGGL(attn_combine128_kernel, cg, dim3(128), 0, s, p, nRpad);      // one wave per row
+                if (p.d_real == 128 && (p.o_ld % 8 == 0 || p.o_frag)) hipLaunchKernelGGL(attn_combine128_kernel, cg, dim3(128), 0, s, p, nRpad);      // one wave per row
                 else hipLaunchKernelGGL(attn_combine_kernel<128>, cg, dim3(256), 0, s, p, nRpad);
                 break;
         }
@@ -613,6 +619,15 @@ extern "C" int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, 
                                     int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
     return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32, ws_floats,
                          n_batch, kv_batch_slots, plan, plan_mode, stream);
+}
+
+// tr1_attn_fwd_planned whose merged rows leave FRAGMENT-MAJOR for tr1_gemm_oproj_frag (csrc/oproj.hip): O holds ceil(n_batch * T / 16) * 16 rows x n_heads * 128
+// bf16, element (m, k) at ((m / 16) * (n_heads * 4) + k / 32) * 512 + (m % 16) * 32 + k % 32.  Split-KV (nsplit > 1), head dim 128.
+extern "C" int tr1_attn_fwd_planned_frag(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* Ofrag, const void* pre,
+                                         const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale,
+                                         int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream) {
+    return attn_fwd_impl(Q, q_ld, K, k_ld, VT, vt_ld, Ofrag, n_heads * head_dim, nullptr, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, nsplit, ws_f32,
+                         ws_floats, n_batch, kv_batch_slots, plan, plan_mode, stream, 1);
 }
 
 extern "C" int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t nsplit) {

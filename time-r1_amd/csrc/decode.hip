@@ -51,7 +51,7 @@ static int64_t decode_ws_bytes(const int64_t* d) {
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     const int64_t fix = tr1_gemm_skinny_fixup_workspace_floats(R, hid, d[D_INTER]);
     const int64_t plan = tr1_attn_plan_ints(T, d[D_HEADS], d[D_KV], d[D_BATCH]);
-    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) * 2 + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) + al(((R + 15) / 16 * 16) * qd * 2) + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
 }
 
 extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
@@ -70,7 +70,7 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     const int64_t att_floats = B * tr1_attn_fwd_workspace_floats(T, nh, nkv, hd, nsplit);
     Carve c{(char*)work, (size_t)work_bytes};
     void* hA = c.take(R * hid * 2); void* hB = c.take(R * hid * 2);
-    void* qkv = c.take(R * qkvd * 2); void* q = c.take(R * qd * 2); void* o = c.take(R * qd * 2);
+    void* qkv = c.take(R * qkvd * 2); void* q = c.take(R * qd * 2); void* o = c.take(((R + 15) / 16 * 16) * qd * 2);
     void* a = c.take(R * inter * 2); void* att = c.take(att_floats * 4);
     // down_proj (N = hidden, K = intermediate): split-K with in-kernel fixup pays from 16 rows up (tools/microbench.py fixup:
     // 37.9 -> 34.9 us at M = 16, 54 -> 45 us at M = 32); its ticket counters live in `work`, which the caller zero-fills ONCE
@@ -105,11 +105,18 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
             CK(tr1_norm_gemm_skinny(h, w[0], w[1], w[2], qkv, R, qkvd, hid, hid, hid, qkvd, eps, 0, stream));
             CK(tr1_decode_qkv_post(qkv, qkvd, cosb, sinb, q, qd, (void*)w[7], kvd, (void*)w[8], B * scap, slots, R, nh, nkv, hd, stream));
         }
-        CK(tr1_attn_fwd_planned(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
-                                scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
+        // bf16 o projection on the all-stages-in-flight kernel (csrc/oproj.hip) where the shape is covered: the split-KV merge then writes its rows fragment-major
+        const bool o_frag = !(qm & QM_O) && nsplit > 1 && hd == 128 && tr1_gemm_oproj_frag_ok(R, hid, qd);
+        if (o_frag)
+            CK(tr1_attn_fwd_planned_frag(q, qd, w[7], kvd, w[8], B * scap, o, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B, scap,
+                                         planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
+        else
+            CK(tr1_attn_fwd_planned(q, qd, w[7], kvd, w[8], B * scap, o, qd, nullptr, pre, lo, hi, T, nh, nkv, scap, hd, scale, nsplit, att, att_floats, B,
+                                    scap, planned ? plan : nullptr, planned ? (i == 0 ? 1 : 2) : 0, stream));
         {
             ProfScope ps(1, stream);
-            if (qm & QM_O) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
+            if (o_frag) CK(tr1_gemm_oproj_frag(o, w[3], h, h2, R, hid, qd, qd, hid, hid, stream));
+            else if (qm & QM_O) CK(gemm8(o, nullptr, w[3], w[10], nullptr, h, h2, R, hid, qd, qd, qd, hid, hid, eps, 0, stream));
             else CK(tr1_gemm_nt_bf16(o, w[3], h2, nullptr, h, R, hid, qd, qd, qd, hid, hid, 0, 0, stream));          // h2 = o Wo^T + h
         }
         {

@@ -331,6 +331,29 @@ class HipOps:
                         plan["work_p"], plan["nbytes"], plan["logits_p"], float(eps), float(scale), plan["stream"])
         return plan["logits"]
 
+    def attn_fwd_frag(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit, n_batch=1, kv_batch_slots=0, plan=None, plan_mode=0):
+        """Split-KV decode attention whose merged rows leave FRAGMENT-MAJOR (tr1_attn_fwd_planned_frag): -> bf16 [ceil(rows / 16) * 16 * n_heads * hd] with element
+        (row m, feature k) at ((m // 16) * (n_heads * 4) + k // 32) * 512 + (m % 16) * 32 + k % 32 - the operand of gemm_oproj_frag."""
+        self._chk(q, k, vt)
+        rows = q.shape[0]
+        T = rows // n_batch
+        assert nsplit > 1 and head_dim == 128 and rows % n_batch == 0
+        nws = n_batch * self.L.raw("tr1_attn_fwd_workspace_floats")(T, n_heads, n_kv, head_dim, nsplit)
+        ws = self._workspace("attn_split", nws, F32)
+        of = self.zeros((rows + 15) // 16 * 16 * n_heads * head_dim)
+        self.L.call("tr1_attn_fwd_planned_frag", _p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(of), _p(pre), _p(lo), _p(hi), T, n_heads, n_kv, n_slots,
+                    head_dim, float(scale), nsplit, _p(ws), nws, n_batch, kv_batch_slots, _p(plan), int(plan_mode), self._s())
+        return of
+
+    def gemm_oproj_frag(self, xfrag, w, M, residual=None):
+        """c[M, N] = x @ w[N, K]^T (+ residual) for M <= 32 decode rows, x fragment-major (attn_fwd_frag): csrc/oproj.hip."""
+        self._chk(xfrag, w, residual)
+        N, K = w.shape
+        assert self.L.raw("tr1_gemm_oproj_frag_ok")(M, N, K) and xfrag.numel() >= (M + 15) // 16 * 16 * K and w.stride(1) == 1
+        c = self.empty(M, N)
+        self.L.call("tr1_gemm_oproj_frag", _p(xfrag), _p(w), _p(residual), _p(c), M, N, K, _ld(w), residual.stride(0) if residual is not None else 0, _ld(c), self._s())
+        return c
+
     def gemm_skinny_fixup(self, a, b, bias=None, residual=None):
         """Decode rows x narrow projection (o_proj / down_proj): split-K with in-kernel fixup; bf16 [M, N]."""
         self._chk(a, b, bias, residual)
