@@ -712,6 +712,12 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps(out))
     dp.barrier()
+    # Memory headroom is a tested property (round 5): an allocator retry inside the run means the caching allocator had to free and re-allocate its blocks in
+    # the middle of a step (config 4 once went from 0.64 to 2.2 s per backward that way, unnoticed) - the line above is then not a steady-state number.
+    retries = int(torch.cuda.memory_stats().get("num_alloc_retries", 0))
+    if retries > 0:
+        sys.stderr.write("bench.py: %d caching-allocator retries during the run (HBM headroom exhausted): the measurement is invalid\n" % retries)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -361,9 +361,8 @@ def test_rollout_drift_metric_and_importance_cap_flag():
 
 
 def test_tail_row_skip_is_chosen_per_layout_and_consistently():
-    """Engine.tail_rows_from: the last layer runs its o projection / MLP on the rows the head reads only where the prompt dominates the packed sequence and the
-    sequence is not in the stashed-prefill regime (config 3: yes; config 4, 19 650 rows of which a sixth is prompt: no - there the extra tensor sizes cost more in the
-    caching allocator than the skipped rows save).  Prefill, update forward and backward ask the same function, so they cannot disagree."""
+    """Engine.tail_rows_from: the last layer runs its o projection / MLP on the rows the head reads only where the prompt dominates the packed sequence
+    (config 3: yes; config 4, 19 650 rows of which a sixth is prompt: no - the saving is the prompt's share of one layer).  Prefill, update forward and backward ask the same function, so they cannot disagree."""
     from time_r1_amd.config import PRESETS
     from time_r1_amd.model import Engine
     eng = Engine.__new__(Engine)

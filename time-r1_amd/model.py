@@ -284,6 +284,7 @@ class Engine:
     # A full set of saved-activation buffers above this size is kept ONCE: further prompts of the accumulation window stash only their
     # prompt rows (written by the rollout prefill) and move them into the one full set when their update starts (unstash_ctx).
     CTX_STASH_GB = float(os.environ.get("TR1_CTX_STASH_GB", "40"))
+    SHARE_A = os.environ.get("TR1_SHARE_A", "1") != "0"      # A/B: one shared SwiGLU-output buffer in the large-sequence regime (recomputed in the backward)
 
     def ctx_bytes(self, rows):
         t = self.cfg.text
@@ -307,9 +308,14 @@ class Engine:
             pool[key] = None          # release the smaller set before allocating the larger one
             cap = (rows + 255) // 256 * 256
             cols = dict(h=t.hidden, xn=t.hidden, v=t.kv_dim, q=t.q_dim, o=t.q_dim, h2=t.hidden, xn2=t.hidden, gu=2 * t.intermediate, a=t.intermediate)
+            # Large sequences (the stashed-prefill regime): ONE SwiGLU-output buffer for all layers instead of one per layer - a = silu(g) u is consumed by its own
+            # layer's down projection in the forward, and the backward rebuilds it from the saved gate/up tensor right before the down projection's weight gradient
+            # (one elementwise pass, bit-identical: the fused epilogue computes a from the bf16-rounded g / u).  Config 4: 27 x 0.74 GB = 20 GB less on a
+            # 250 GB step, which is what lets the tail-row and dgu^T fast paths stay on there without allocator retries.
+            a_shared = ops.empty(cap, t.intermediate) if (self.SHARE_A and self.ctx_bytes(total_rows) > self.CTX_STASH_GB * 1e9 and t.n_layers > 1) else None
             full = []
             for _ in range(t.n_layers):
-                L = {k: ops.empty(cap, c) for k, c in cols.items()}
+                L = {k: (a_shared if (k == "a" and a_shared is not None) else ops.empty(cap, c)) for k, c in cols.items()}
                 L["rstd1"] = ops.empty(cap, dtype=F32)
                 L["rstd2"] = ops.empty(cap, dtype=F32)
                 full.append(L)
@@ -322,8 +328,11 @@ class Engine:
         been enqueued on this stream, so the set is free.  ~1 read + 1 write of the prompt rows (config 4: 15 GB, 6 ms on a 3.4 s micro-step)."""
         full = self.alloc_ctx_bufs(total_rows, slot=0)
         P = prefill_rows
+        shared_a = len(full) > 1 and full[0]["a"].data_ptr() == full[1]["a"].data_ptr()
         for dst, src in zip(full, pctx["bufs"]):
             for k, v in src.items():
+                if k == "a" and shared_a:
+                    continue              # rebuilt from gu in the backward (alloc_ctx_bufs)
                 dst[k][:P].copy_(v[:P])
         pctx["bufs"] = full
         pctx["stash"] = False
@@ -332,11 +341,11 @@ class Engine:
     TAIL_SKIP = os.environ.get("TR1_TAIL_SKIP", "1") != "0"     # A/B switch for `tail_from` (0: every row runs the whole last layer)
 
     def tail_rows_from(self, P, M):
-        """The `tail_from` a caller should pass for a packed sequence of P prompt rows in M rows, or None: the saving is the prompt's share of ONE layer, and
-        the last layer's shorter tensors are sizes of their own in the caching allocator (~3 GB of blocks the other layers cannot reuse at config 4, where
-        the prompt is a sixth of the rows and HBM is nearly full: allocator retries, backward 0.64 -> 2.2 s) - so only where the prompt dominates and the
-        sequence is not in the stashed-prefill regime.  Prefill, update forward and backward of one sequence must all use this one answer."""
-        if not self.TAIL_SKIP or P < 2 or (P - 1) < 0.4 * M or self.ctx_bytes(M) > self.CTX_STASH_GB * 1e9:
+        """The `tail_from` a caller should pass for a packed sequence of P prompt rows in M rows, or None: the saving is the prompt's share of ONE layer, so
+        only where the prompt dominates (config 3: 3 474 of 5 074 rows; config 4's prompt is a sixth of the rows).  Prefill, update forward and backward of one
+        sequence must all use this one answer.  (Round 4 also switched it off in the large-sequence regime for allocator reasons; round 5 found the cause -
+        blocks held across the two backward streams, see llm_bwd - and the memory gate is gone.)"""
+        if not self.TAIL_SKIP or P < 2 or (P - 1) < 0.4 * M:
             return None
         return P - 1
 
@@ -454,9 +463,14 @@ class Engine:
         cos, sin = ctx["cos"], ctx["sin"]
         qd, kvd, hd = t.q_dim, t.kv_dim, t.head_dim
         scale = hd ** -0.5
-        side = self._side_stream()
+        # Large sequences (the stashed-prefill regime, config 4): weight gradients stay on the MAIN stream.  A tensor produced on one stream and consumed on the
+        # other (dgu^T, the transposes) keeps its caching-allocator block until the consumer's event has passed; with 1.5 GB tensors per layer and the side
+        # stream a few layers behind, the allocator grew to 300 GB reserved for 250 GB allocated and went into retries (backward 0.65 -> 2.2 s) as soon as anything
+        # else was added.  On one stream reserved == allocated (231 GB at config 4), and the second stream buys nothing there anyway (the backward is a
+        # serial sum of its kernels).
+        side = None if self.ctx_bytes(dh.shape[0]) > self.CTX_STASH_GB * 1e9 else self._side_stream()
         pending = None
-        big_seq = self.ctx_bytes(dh.shape[0]) > self.CTX_STASH_GB * 1e9
+        a_shared = t.n_layers > 1 and ctx["layers"][0]["a"].data_ptr() == ctx["layers"][1]["a"].data_ptr()
         t0 = int(ctx.get("tail_from", 0) or 0)      # rows < t0 never went through the last layer's o projection / MLP (llm_fwd tail_from): dh is zero there
         for i in reversed(range(t.n_layers)):
             p = "l%d." % i
@@ -471,11 +485,11 @@ class Engine:
                     L[key] = Lf[key][t0:]
             # h_out = a @ Wd^T + h2
             _sync = self.wgrad_on_main
-            self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if "d" in _sync else side, key=p + "down.w")
+            if a_shared:                  # one SwiGLU-output buffer for all layers (alloc_ctx_bufs): rebuild this layer's rows from its gate/up tensor, main stream
+                ops.swiglu_fwd(L["gu"], out=L["a"])
+            self._wgrad_async(dh, L["a"], tr.g(p + "down.w"), None if ("d" in _sync or a_shared) else side, key=p + "down.w")
             # down-projection dgrad with the SwiGLU backward in its epilogue, which also leaves dgu^T (the gate/up weight gradient's operand) from its LDS staging
-            # (not in the large-sequence regime: dgu^T is allocated on this stream and consumed on the side stream, so the caching allocator holds its blocks
-            # longer - +3 GB at config 4, where that tips a 250 GB step into allocator retries; there the side stream builds the transpose as before)
-            dgu, dgut = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"], want_t=True) if not big_seq else (ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"]), None)
+            dgu, dgut = ops.dgrad_glu_bwd(dh, tr.w(p + "down.w"), L["gu"], want_t=True)
             self._wgrad_async(dgu, L["xn2"], tr.g(p + "gu.w"), None if "g" in _sync else side, key=p + "gu.w", dyt=dgut)
             dxn2 = self._dgrad(dgu, tr.w(p + "gu.w"), key=p + "gu.w")
             dh2 = ops.rmsnorm_bwd(dxn2, L["h2"], tr.w(p + "ln2"), L["rstd2"], dres=dh, dw=tr.g(p + "ln2"))
