@@ -250,8 +250,8 @@ int tr1_adamw_step_g16(void* p_f32, void* m_f32, void* v_f32, void* g_f32, const
  * DeepSpeed gradient_clipping, scripts/zero3.json:35).  tr1_wgrad_f32_sumsq is the weight-gradient GEMM (NT or K-major B form, bit-identical C) whose epilogue
  * also leaves one sum of squares per wave of what it stored - in the LAST micro-step of an accumulation window that is the final gradient; *n_partials (HOST)
  * receives the number of floats written.  tr1_sumsq_partials_accum adds them to the norm scalar in a fixed order (two levels; the buffer must have room for 256 more floats behind its n entries); tr1_sumsq_ranges_periodic adds the small
- * per-layer tensors (same range description as tr1_zero_ranges_periodic). */
-int tr1_wgrad_f32_sumsq(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int b_kmajor, int64_t b_rows, void* sumsq_partials, int64_t partials_capacity, int64_t* n_partials, void* stream);
+ * per-layer tensors (same range description as tr1_zero_ranges_periodic).  wire_bf16 (optional, [M, N] bf16, leading dimension ld_wire): the stored value rounded to bf16 as well - the data-parallel gradient exchange's wire copy (dist.GradSync / ShardSync) without its staging pass. */
+int tr1_wgrad_f32_sumsq(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int b_kmajor, int64_t b_rows, void* sumsq_partials, int64_t partials_capacity, int64_t* n_partials, void* wire_bf16, int64_t ld_wire, void* stream);
 int tr1_sumsq_partials_accum(const void* partials_f32, int64_t n, void* out_scalar, void* stream);
 int tr1_sumsq_ranges_periodic(const void* g_f32, int64_t base, int64_t stride, int64_t count, const int64_t* rel_ranges, int64_t n_ranges, void* out_scalar, void* stream);
 /* g[base + l*stride + r] = 0 for l < count, r in the <= 8 half-open ranges (rel_ranges = HOST array of 2*n_ranges offsets inside one period): clears the small

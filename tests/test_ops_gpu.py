@@ -1040,3 +1040,25 @@ def test_w8a8_decode_projections_x_through_lds_bit_identical(tmp_path):
         res.append(torch.load(f))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kmajor", [False, True])
+def test_weight_gradient_epilogue_also_writes_the_bf16_wire_copy(hip_ops, kmajor):
+    """Round 5 (data-parallel per-rank tax): tr1_wgrad_f32_sumsq can also leave bf16(final gradient) in the gradient exchange's staging arena, so
+    GradSync / ShardSync skip their 6-byte-per-parameter staging pass for the large matrices.  The wire copy equals gw.to(bf16) bit for bit (overwrite and
+    accumulate, NT and K-major operand forms), gw and the sums of squares are unchanged."""
+    N, K, T = 1024, 768, 640
+    dy = rnd(T, N, seed=1, scale=0.1).cuda()
+    x = rnd(T, K, seed=2, scale=0.5).cuda()
+    dyt = hip_ops.transpose(dy)
+    b = x if kmajor else hip_ops.transpose(x)
+    part = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
+    for acc in (False, True):
+        gw0 = (rnd(N, K, seed=3).float().cuda() if acc else torch.full((N, K), 7.0, device="cuda"))
+        gw_a, gw_b = gw0.clone(), gw0.clone()
+        wire = torch.full((N, K), 3.0, dtype=BF16, device="cuda")
+        n1 = hip_ops.wgrad_sumsq(dyt, b, gw_a, acc, part, 0, b_kmajor=kmajor, b_rows=T)
+        s1 = part[:n1].clone()
+        n2 = hip_ops.wgrad_sumsq(dyt, b, gw_b, acc, part, 0, b_kmajor=kmajor, b_rows=T, wire=wire)
+        assert n1 == n2 and n1 > 0 and torch.equal(gw_a, gw_b) and torch.equal(s1, part[:n2])
+        assert torch.equal(wire, gw_b.to(BF16)), "the wire copy must be the bf16 rounding of the stored gradient"

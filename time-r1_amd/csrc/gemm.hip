@@ -238,7 +238,9 @@ TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, co
 template <bool OUT_F32, bool ACCUM, int RT, int EPI = 0>
 TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wave_lds, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
                               const bf16_t* __restrict__ residual, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int64_t mrow0, int64_t ncol0,
-                              int lane, float* __restrict__ sumsq_slot = nullptr) {
+                              int lane, float* __restrict__ sumsq_slot = nullptr, bf16_t* __restrict__ wire16 = nullptr, int64_t ldw16 = 0) {
+    // wire16 (fp32 output only): the value stored is ALSO written, rounded to bf16, at the same (row, column) of a second matrix - the gradient exchange's
+    // wire-format copy of a weight gradient, taken from the epilogue that produces the final fp32 value instead of a 6-byte-per-parameter staging pass
     constexpr int CH = (RT % 2 == 0) ? 4 : 3;                             // 16-row tiles per pass: 8 waves x CH x 4 KiB fit the operand buffers
     const int u = lane & 15, g = lane >> 4;
     float ssq = 0.f;                                                      // fp32 output only: sum of squares of what this wave stores (gradient norm)
@@ -272,6 +274,7 @@ TR1_DEV void store_acc256_lds(const f32x4_t (&acc)[RT][4], char* __restrict__ wa
                         float* cp = reinterpret_cast<float*>(Cv) + m * ldc + n;
                         if (ACCUM) v += *reinterpret_cast<const f32x4_t*>(cp);
                         TR1_EPI_STORE(reinterpret_cast<f32x4_t*>(cp), v);
+                        if (wire16) *reinterpret_cast<u32x2_t*>(wire16 + m * ldw16 + n) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
                         ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     }
                 }
@@ -919,7 +922,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
     else
     store_acc256_lds<OUT_F32, ACCUM, RT, EPI>(acc, smem2 + wave * (((RT % 2 == 0) ? 4 : 3) * 4096), Cv, bias, residual, M, N, ldc, ldr,
                                               m0 + wm * (RT * 16), n0 + wn * 64, lane,
-                                              (OUT_F32 && EPI == 0 && ep.p0) ? reinterpret_cast<float*>(ep.p0) + (int64_t)blockIdx.x * 8 + wave : nullptr);
+                                              (OUT_F32 && EPI == 0 && ep.p0) ? reinterpret_cast<float*>(ep.p0) + (int64_t)blockIdx.x * 8 + wave : nullptr,
+                                              (OUT_F32 && EPI == 0 && ep.p0) ? reinterpret_cast<bf16_t*>(ep.p1) : nullptr, ep.ld1);
 #else
     store_acc256<OUT_F32, ACCUM, RT>(acc, Cv, bias, residual, M, N, ldc, ldr, m0 + wm * (RT * 16), n0 + wn * 64, u, g);
 #endif
@@ -2011,7 +2015,8 @@ static int epi_pick_rt(int64_t M, int64_t Ntiles);
 // the count) - in the last micro-step of an accumulation window that is the squared norm of the final gradient, so the optimizer's grad-norm pass does not
 // have to read these matrices again.  Same kernel, k order and (for shapes the NT dispatch gives to the 8-wave tiles) tile choice as tr1_gemm_nt_bf16(out_f32) / tr1_gemm_nn_acc_f32: bit-identical C.
 extern "C" int tr1_wgrad_f32_sumsq(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate,
-                                   int b_kmajor, int64_t b_rows, void* sumsq_partials, int64_t partials_capacity, int64_t* n_partials, void* stream) {
+                                   int b_kmajor, int64_t b_rows, void* sumsq_partials, int64_t partials_capacity, int64_t* n_partials, void* wire_bf16, int64_t ld_wire,
+                                   void* stream) {
     TR1_CHECK_ARG(K % BK == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "wgrad_f32_sumsq: K%64, N%8, lda%8, ldb%8, ldc%4 required");
     TR1_CHECK_ARG(M >= 512 && N >= 256, "wgrad_f32_sumsq: M >= 512 and N >= 256 required (smaller gradients: plain GEMM + tr1_sumsq_accum)");
     TR1_CHECK_ARG(!b_kmajor || (b_rows >= 1 && b_rows <= K), "wgrad_f32_sumsq: 1 <= b_rows <= K");
@@ -2042,7 +2047,8 @@ extern "C" int tr1_wgrad_f32_sumsq(const void* A, const void* B, void* C, int64_
             set_ = true;
         }
     }
-    GemmEpi ep{}; ep.p0 = sumsq_partials;
+    TR1_CHECK_ARG(!wire_bf16 || ld_wire % 4 == 0, "wgrad_f32_sumsq: ld_wire % 4 required");
+    GemmEpi ep{}; ep.p0 = sumsq_partials; ep.p1 = wire_bf16; ep.ld1 = ld_wire;
 #define LW(AC, R, KM) hipLaunchKernelGGL((gemm_nt8p_kernel<true, AC, R, KM>), dim3((unsigned)blocks), dim3(512), dyn, s, (const bf16_t*)A, (const bf16_t*)B, C, \
                                          (const bf16_t*)nullptr, (const bf16_t*)nullptr, M, N, K, lda, ldb, ldc, (int64_t)(KM ? b_rows : 0), (int)t2m, (int)t2n, ep)
 #define LWR(R) do { if (b_kmajor) { if (accumulate) LW(true, R, true); else LW(false, R, true); } else { if (accumulate) LW(true, R, false); else LW(false, R, false); } } while (0)

@@ -84,9 +84,34 @@ class GradSync:
 
     def begin(self):
         self.pending, self.done = [], []
+        self.wired = []                       # [lo, hi) element ranges whose wire-format copy the producing kernel already wrote (mark_wire)
         self.active = self.dp.enabled
         if self.active and self.wire_dtype != self.g.dtype and self.stage is None:
             self.stage = torch.empty(self.g.numel(), dtype=self.wire_dtype, device=self.g.device)
+
+    def wire_view(self, off, shape):
+        """The wire-format twin of the gradient tensor at arena offset `off` (None without a staging arena): a weight-gradient GEMM whose epilogue
+        produces the FINAL fp32 value writes its bf16 rounding there as well (Engine._wgrad in the window's last micro-step) and calls mark_wire."""
+        if not self.active or self.stage is None:
+            return None
+        n = 1
+        for s in shape:
+            n *= int(s)
+        return self.stage[off:off + n].view(*shape)
+
+    def mark_wire(self, lo, hi):
+        self.wired.append((int(lo), int(hi)))
+
+    def _stage_gaps(self, x, y):
+        """fp32 -> bf16 staging copy of [x, y) minus the ranges the producers already wrote in wire format (45 GB of traffic per window at 7B when
+        everything is copied; the four large matrices of a decoder layer are 99 % of it)."""
+        pos = x
+        for lo, hi in sorted(w for w in self.wired if w[1] > x and w[0] < y):
+            if lo > pos:
+                self.stage[pos:lo].copy_(self.g[pos:lo])
+            pos = max(pos, min(hi, y))
+        if pos < y:
+            self.stage[pos:y].copy_(self.g[pos:y])
 
     def ready(self, a, b):
         """Elements [a, b) of the gradient arena are final on this rank: start their all-reduce (asynchronous)."""
@@ -96,7 +121,7 @@ class GradSync:
             y = min(b, x + self.bucket)
             if self.stage is not None:
                 buf = self.stage[x:y]
-                buf.copy_(self.g[x:y])            # fp32 -> bf16 wire format (staging copy on the compute stream)
+                self._stage_gaps(x, y)            # fp32 -> bf16 wire format (staging copy on the compute stream) of what no epilogue wrote
             else:
                 buf = self.g[x:y]
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
@@ -173,8 +198,11 @@ class ShardSync:
         self.active = False
         self._seg_at = {a: (a, b) for _, a, b in arena.segments}
 
+    wire_view, mark_wire, _stage_gaps = GradSync.wire_view, GradSync.mark_wire, GradSync._stage_gaps
+
     def begin(self):
         self.pending, self.done = [], set()
+        self.wired = []
         self.active = self.dp.enabled
         if not self.active:
             return
@@ -199,7 +227,7 @@ class ShardSync:
                 self.done.add(x)
                 if self.stage is not None:
                     src = self.stage[x:y]
-                    src.copy_(self.g[x:y])            # fp32 -> bf16 wire format (staging copy on the compute stream)
+                    self._stage_gaps(x, y)            # fp32 -> bf16 wire format (staging copy on the compute stream) of what no epilogue wrote
                     dst = self.recv[x // W: y // W]
                 else:
                     src = self.g[x:y]

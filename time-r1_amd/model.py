@@ -65,10 +65,15 @@ class Engine:
         if sink is not None and key is not None and key.split(".", 1)[-1] in self.OVERWRITTEN and hasattr(ops, "wgrad_sumsq"):
             # last micro-step of the window: same GEMM, and its epilogue also leaves the sum of squares of the FINAL gradient values it stores
             kmaj = self.wgrad_nn and x.shape[1] >= 2 * dy.shape[1]
-            n = ops.wgrad_sumsq(dyt, x if kmaj else ops.transpose(x), gw, acc, sink["partials"], sink["n"], b_kmajor=kmaj, b_rows=x.shape[0])
+            sync = sink.get("sync")
+            off = self.params.train.offsets[key][0]
+            wire = sync.wire_view(off, gw.shape) if sync is not None else None      # data-parallel: the exchange's bf16 copy comes out of this epilogue too
+            n = ops.wgrad_sumsq(dyt, x if kmaj else ops.transpose(x), gw, acc, sink["partials"], sink["n"], b_kmajor=kmaj, b_rows=x.shape[0], wire=wire)
             if n >= 0:
                 sink["n"] += n
                 sink["covered"].add(key)
+                if wire is not None:
+                    sync.mark_wire(off, off + gw.numel())
                 return
         # K-major form: x is read as stored (no x^T copy; the padded token columns of dy^T are zero, so the rows re-read past M drop out).
         # Its transposing LDS reads cost 8-17 % of the GEMM rate (tools/bench_wgrad.py: 1060 against 1244 TFLOP/s at the down-projection

@@ -742,7 +742,7 @@ class HipOps:
         assert g.dtype in (F32, BF16) and out_scalar.dtype == F32
         self.L.call("tr1_sumsq_accum" if g.dtype == F32 else "tr1_sumsq_accum_bf16", _p(g), g.numel(), _p(out_scalar), self._s())
 
-    def wgrad_sumsq(self, a, b, gw, accumulate, partials, offset, b_kmajor=False, b_rows=0):
+    def wgrad_sumsq(self, a, b, gw, accumulate, partials, offset, b_kmajor=False, b_rows=0, wire=None):
         """gw[N, K] fp32 (+)= a[N, Mp] @ b^T (b = X^T [K, Mp]) or a @ b (b_kmajor: b = X [>= b_rows, K] as stored), and partials[offset : offset + n] receives
         the per-wave sums of squares of the values stored (n returned; -1 when the shape is not covered and nothing was launched)."""
         import ctypes
@@ -754,9 +754,10 @@ class HipOps:
             return -1                     # partials buffer too small for this matrix: the caller runs the plain GEMM and step() takes the full-arena norm
         self._chk(a, b)
         assert gw.dtype == F32 and gw.shape == (N, K) and partials.dtype == F32 and partials.is_contiguous()
+        assert wire is None or (wire.dtype == torch.bfloat16 and wire.shape == (N, K) and wire.stride(1) == 1)      # the gradient exchange's bf16 copy of gw
         n = ctypes.c_int64(0)
         self.L.call("tr1_wgrad_f32_sumsq", _p(a), _p(b), _p(gw), N, K, Mp, _ld(a), _ld(b), _ld(gw), int(accumulate), int(b_kmajor), int(b_rows),
-                    partials.data_ptr() + 4 * int(offset), partials.numel() - int(offset) - 256, ctypes.byref(n), self._s())
+                    partials.data_ptr() + 4 * int(offset), partials.numel() - int(offset) - 256, ctypes.byref(n), _p(wire), _ld(wire) if wire is not None else 0, self._s())
         return int(n.value)
 
     @staticmethod

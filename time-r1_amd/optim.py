@@ -43,7 +43,12 @@ class AdamWFlat:
         reads only the rest of the arena (embedding, norms, biases, lm_head, merger) for the global norm: 30 GB less to stream per step at 7B."""
         self._sink = None
         lz = self._lz()
-        if self.dp.enabled or not lz or engine is None:
+        if not lz or engine is None:
+            return None
+        # under a process group the epilogues still serve the exchange: they write the bf16 wire copy of the final gradient (no staging pass for the large
+        # matrices).  Their sums of squares are the LOCAL gradient's, which is the clipped norm only for a group of one rank (norm of the sum != sum of norms).
+        sync = self.sync if (self.dp.enabled and getattr(self.sync, "active", False) and getattr(self.sync, "stage", None) is not None) else None
+        if self.dp.enabled and sync is None:
             return None
         if getattr(self, "_partials", None) is None:
             # one slot per wave of every tile block of the covered matrices (7B: 0.72 M floats), sized from the layout instead of a fixed guess
@@ -52,14 +57,15 @@ class AdamWFlat:
             self._partials = torch.empty(need + 512, dtype=torch.float32, device=a.grad.device)
         self._sink = dict(partials=self._partials, n=0, covered=set(),
                           want={"l%d.%s" % (i, nm) for i in range(lz["count"]) for nm in type(engine).OVERWRITTEN}, gver=getattr(self.params.train, "version", 0),
-                          engine=engine, bwd=getattr(engine, "bwd_count", 0) + 1)      # valid only if the armed backward is the engine's LAST one before step()
+                          engine=engine, bwd=getattr(engine, "bwd_count", 0) + 1,      # valid only if the armed backward is the engine's LAST one before step()
+                          sync=sync, norm_ok=(not self.dp.enabled) or self.dp.world == 1)
         return self._sink
 
     def _norm_from_sink(self):
         """True when the global squared norm could be assembled from the sink + the uncovered parts of the arena (self._sumsq then holds it)."""
         sink, a, lz = getattr(self, "_sink", None), self.params.train, self._lz()
         self._sink = None
-        if not sink or not lz or sink["covered"] != sink["want"] or sink["gver"] != getattr(a, "version", 0):
+        if not sink or not lz or not sink.get("norm_ok", True) or sink["covered"] != sink["want"] or sink["gver"] != getattr(a, "version", 0):
             return False
         if getattr(sink["engine"], "bwd_count", sink["bwd"]) != sink["bwd"] or not getattr(sink["engine"], "wgrad_overwrite_first", True):
             return False      # another backward accumulated into the arena after the armed one (compute_loss / training_step between window and step): full pass
@@ -104,7 +110,9 @@ class AdamWFlat:
         self.sync.finish(copy_back=g16 is None)
         mult = 1.0 / self.dp.world
         self._sumsq.zero_()
-        self.norm_from_sink = g16 is None and self._norm_from_sink()      # (diagnostic: did the weight-gradient epilogues supply the large matrices' norm?)
+        # (diagnostic: did the weight-gradient epilogues supply the large matrices' norm?  With a group of ONE rank the summed wire gradient is this rank's own,
+        # so the epilogue sums are the clipped norm there too - the single-rank-group run of tools/ab_dp_single_rank.sh; with N > 1 the norm is taken from g16)
+        self.norm_from_sink = (g16 is None or self.dp.world == 1) and self._norm_from_sink()
         if not self.norm_from_sink:
             self.ops.sumsq_accum(a.grad if g16 is None else g16, self._sumsq)
         self.step_count += 1
