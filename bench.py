@@ -659,33 +659,33 @@ def main(argv=None):
         mfma = {"kernel": "gemm_nt_kernel+gemm_nt8p_kernel", "bound": "mfma", "achieved": big_fl / (big_ms * 1e-3) / 1e12 if big_ms else 0.0, "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "launches": big_n, "avg_launch_us": 1000.0 * big_ms / max(big_n, 1), "ms_per_step": big_ms / nstep, "traffic": None}
         mfma["frac"] = mfma["achieved"] / PEAK_BF16_TFLOPS
-        hbm = {"kernel": "decode GEMM family: gemm_skinny + norm_gemm_skinny + norm_glu_lds + gemm_skinny_lds_fix kernels", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
+        hbm = {"kernel": "decode GEMM family: gemm_skinny + norm_gemm_skinny + norm_glu_lds + gemm_skinny_lds_fix + oproj_frag kernels (fp8 runs: their _w8 / _f8 twins)", "bound": "hbm", "achieved": sk_by / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "peak": PEAK_HBM_GBS,
                "unit": "GB/s", "launches": sk_n, "avg_launch_us": 1000.0 * sk_ms / max(sk_n, 1), "ms_per_step": sk_ms / nstep, "traffic": None}
         hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
         # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, gfx950 x2 read
         # correction; same workload shapes) - PMC counters cannot be collected inside this un-profiled run
         try:
-            pmc_name = [f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            fp8_run = bool(args.rollout_fp8 or args.rollout_fp8_w8a16)
+            # (round 5: the fp8 sampling policy has a PMC pass of its own - its decode kernels stream other bytes than the bf16 family's)
+            cands = ("r05_pmc_traffic_fp8.json",) if fp8_run else ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc_name = [f for f in cands if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             # guard: the counters are only quoted while the kernels they were collected on are the kernels that just ran - the PMC pass records
             # a fingerprint of the GEMM sources (tools/pmc_to_json.py); any edit since then detaches `traffic` until the pass is re-run
             import hashlib
             csrc = os.path.join(ROOT, "time-r1_amd", "csrc")
-            now = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in ("gemm.hip", "decode.hip")}
+            now = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in (pmc.get("_source_sha16") or {"gemm.hip": 0, "decode.hip": 0})}
             fresh = pmc.get("_source_sha16") == now
-            fp8_run = bool(args.rollout_fp8 or args.rollout_fp8_w8a16)
-            if fp8_run:       # the committed PMC pass measured the bf16 decode kernels: never quote it against the fp8 family's algorithmic bytes
-                fresh = False
             for r_ in (hbm, mfma):
                 r_["traffic_source"] = "profiles/" + pmc_name
                 r_["traffic_guard"] = ("kernel sources unchanged since the PMC pass" if fresh else
-                                       "withheld: the PMC pass measured the bf16 decode kernels, this run streams fp8 weights (csrc/gemm_w8.hip)" if fp8_run else
                                        "STALE: csrc/gemm.hip or decode.hip changed since the PMC pass (or the file predates the guard) - traffic withheld")
             if fresh and args.model == "qwen2-vl-7b" and args.G == 8 and args.ga == 2:
                 def fam(*names):      # launch-weighted mean over the kernel families that make up one roofline entry
                     n = sum(pmc[k]["launches"] for k in names if k in pmc)
                     return sum(pmc[k]["launches"] * pmc[k]["fetch_bytes_per_launch_corrected"] for k in names if k in pmc) / max(n, 1)
-                hbm["traffic"] = fam("gemm_skinny_kernel", "norm_gemm_skinny_kernel", "norm_glu_lds_kernel", "gemm_skinny_lds_fix_kernel")
+                hbm["traffic"] = fam("gemm_skinny_kernel", "norm_gemm_skinny_kernel", "norm_glu_lds_kernel", "gemm_skinny_lds_fix_kernel", "oproj_frag_kernel",
+                                     "gemm_skinny_w8_kernel", "gemm_skinny_w8a8_kernel", "norm_glu_lds_f8_kernel", "gemm_skinny_lds_fix_f8_kernel")
                 mfma["traffic"] = fam("gemm_nt_kernel", "gemm_nt8p_kernel", "gemm_nt256_kernel")
             hbm["algorithmic_bytes_per_launch"] = sk_by / max(sk_n, 1)
             mfma["algorithmic_flops_per_launch"] = big_fl / max(big_n, 1)

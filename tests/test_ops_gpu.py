@@ -442,7 +442,7 @@ def test_attention_fwd_rows_strided_views_and_continuation(hip_ops, ref_ops, nam
     close(o_w, o_r, 0.02, what=name + " O")
     close(lse_w, lse_r, 2e-3, rtol=1e-3, what=name + " lse")
     assert float(obuf[:, qd:].abs().max()) == 0.0 and (r0 == 0 or float(obuf[:r0].abs().max()) == 0.0), "writes outside the output view"
-    # and against the V^T kernel (the path taken without v_rows / with TR1_FWD32=0) on contiguous copies of the same operands
+    # and against the V^T kernel (the path taken without v_rows) on contiguous copies of the same operands
     vt = hip_ops.pack_transpose(v_view.contiguous(), nkv, nkv, hd)
     o_t, lse_t = hip_ops.attn_fwd(q.contiguous(), k_view.contiguous(), vt, pre[r0:].cuda(), lo[r0:].cuda(), hi[r0:].cuda(), nh, nkv, S, hd, hd ** -0.5)
     close(o_w, o_t.float().cpu(), 0.02, what=name + " O rows vs V^T kernel")
@@ -923,123 +923,6 @@ def test_gemm_nn(hip_ops, M, N, K):
     close(got, ref.cpu(), 0.03, rtol=0.02, what="gemm_nn")
     nt = hip_ops.gemm_nt(a, b.t().contiguous())
     assert torch.equal(got, nt), "NN and NT forms accumulate in the same order"
-
-
-def test_down_projection_56_column_blocks_bit_identical(tmp_path):
-    """Round 3: the LDS-streamed split-K down projection on 56-column blocks (64 x 4 = 256 blocks at N = 3584: every CU) stores exactly the bits of the
-    64-column form (TR1_DOWN_COLS=64: 224 blocks) - same K-slabs, same per-wave stage order, same ordered fixup; also with residual and < 16 rows.
-    The block shape is read once per process, hence the subprocesses."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import torch, sys
-        sys.path.insert(0, %r)
-        import time_r1_amd
-        from time_r1_amd.ops import HipOps
-        ops = HipOps("cuda:0")
-        g = torch.Generator().manual_seed(11)
-        w = (torch.randn(3584, 18944, generator=g) * 0.02).bfloat16().cuda()
-        outs = []
-        for M in (16, 9, 1):
-            a = (torch.randn(M, 18944, generator=g) * 0.5).bfloat16().cuda()
-            h = torch.randn(M, 3584, generator=g).bfloat16().cuda()
-            for _ in range(2):                                   # second call: the ticket counters were re-armed by the first
-                outs.append(ops.gemm_skinny_fixup(a, w, residual=h).cpu())
-            outs.append(ops.gemm_skinny_fixup(a, w).cpu())
-            ref = (a.float() @ w.float().t() + h.float()).cpu()
-            assert (outs[-3].float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
-        torch.save(outs, sys.argv[1])
-        print("ok")
-    """) % root
-    files = []
-    for cols in ("56", "64"):
-        f = str(tmp_path / ("down_%s.pt" % cols))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, TR1_DOWN_COLS=cols), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
-        files.append(torch.load(f))
-    for a, b in zip(*files):
-        assert torch.equal(a, b)
-
-
-def test_decode_projections_x_through_lds_bit_identical(tmp_path):
-    """Round 3: the <= 16-row fused QKV kernel and the o projection take the activation rows through ONE DMA copy into LDS per block instead of per-wave
-    vector loads (TR1_QKV_XLDS / TR1_SKINNY_XLDS, default on), and the QKV weights can stream through LDS rings (TR1_QKV_LDS=1): same values, same
-    order of operations - q, the appended K / V^T cache rows and the projection output must be bit-identical in every form (7B and 2B widths, 16 / 5 rows)."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import torch, sys
-        sys.path.insert(0, %r)
-        import time_r1_amd
-        from time_r1_amd.ops import HipOps
-        ops = HipOps("cuda:0")
-        g = torch.Generator().manual_seed(5)
-        outs = []
-        for K, nh, nkv in ((3584, 28, 4), (1536, 12, 2)):
-            hd = 128
-            for M in (16, 5):
-                x = torch.randn(M, K, generator=g).bfloat16().cuda()
-                lnw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
-                w = (torch.randn((nh + 2 * nkv) * hd, K, generator=g) * 0.02).bfloat16().cuda()
-                b = torch.randn((nh + 2 * nkv) * hd, generator=g).bfloat16().cuda()
-                cos, sin = torch.randn(M, hd // 2, generator=g).cuda(), torch.randn(M, hd // 2, generator=g).cuda()
-                kc = torch.zeros(256, nkv * hd, dtype=torch.bfloat16, device="cuda"); vt = torch.zeros(nkv * hd, 256, dtype=torch.bfloat16, device="cuda")
-                slots = (torch.arange(M, dtype=torch.int32) * 7 + 3).cuda()
-                q = ops.norm_gemm_qkv(x, lnw, 1e-6, w, b, cos, sin, kc, vt, slots, nh, nkv, hd)
-                wo = (torch.randn(K, K, generator=g) * 0.02).bfloat16().cuda()
-                res = torch.randn(M, K, generator=g).bfloat16().cuda()
-                o = ops.gemm_nt(x, wo, residual=res)
-                assert torch.isfinite(q.float()).all() and torch.isfinite(o.float()).all()
-                outs += [q.cpu(), kc.cpu(), vt.cpu(), o.cpu()]
-        torch.save(outs, sys.argv[1])
-        print("ok")
-    """) % root
-    res = []
-    for i, env in enumerate((dict(TR1_QKV_XLDS="0", TR1_SKINNY_XLDS="0", TR1_QKV_LDS="0"), dict(), dict(TR1_QKV_LDS="1"))):
-        f = str(tmp_path / ("proj_%d.pt" % i))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
-        res.append(torch.load(f))
-    for other in res[1:]:
-        for a, b in zip(res[0], other):
-            assert torch.equal(a, b)
-
-
-def test_w8a8_decode_projections_x_through_lds_bit_identical(tmp_path):
-    """Round 3, fp8 sampling policy: the W8A8 register kernel with the activation rows / norm weight through one LDS copy per block (TR1_W8A8_XLDS, default
-    on) returns the bits of the vector-load form - norm + projection (qkv / lm_head shape), plain projection with residual (o), 7B and 2B widths, ragged rows."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import torch, sys
-        sys.path.insert(0, %r)
-        import time_r1_amd
-        from time_r1_amd.ops import HipOps
-        ops = HipOps("cuda:0")
-        g = torch.Generator().manual_seed(9)
-        outs = []
-        for K, N in ((3584, 4608), (1536, 2048), (3584, 3584)):
-            w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
-            q, sc = ops.quantize_fp8_rows(w)
-            for M in (16, 3):
-                x = torch.randn(M, K, generator=g).bfloat16().cuda()
-                lnw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
-                b = torch.randn(N, generator=g).bfloat16().cuda()
-                res = torch.randn(M, N, generator=g).bfloat16().cuda()
-                outs.append(ops.gemm_w8(x, q, sc, lnw=lnw, eps=1e-6, bias=b, a8=True).cpu())
-                outs.append(ops.gemm_w8(x, q, sc, residual=res, a8=True).cpu())
-        assert all(torch.isfinite(o.float()).all() for o in outs)
-        torch.save(outs, sys.argv[1])
-        print("ok")
-    """) % root
-    res = []
-    for i, env in enumerate((dict(TR1_W8A8_XLDS="0"), dict())):
-        f = str(tmp_path / ("w8_%d.pt" % i))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
-        res.append(torch.load(f))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("kmajor", [False, True])

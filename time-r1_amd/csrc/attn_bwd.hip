@@ -1454,19 +1454,10 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part_k, const f
 extern "C" int tr1_rope_apply(const void* in, int64_t ld_in, void* out, int64_t ld_out, const void* cosb, const void* sinb, int64_t T, int64_t n_heads,
                               int64_t head_dim, int backward, void* stream);
 
-// wave pairs per block of the 32x32x16 kernel (TR1_DKDV32_NP = 4 | 6): 6 pairs = 12 waves = 3 per SIMD, 192 keys per block
-static int dkdv32_pairs() {
-    static int np = -1;
-    if (np < 0) { const char* e = getenv("TR1_DKDV32_NP"); np = (e && atoi(e) == 4) ? 4 : 6; }
-    return np;
-}
-static int dkdv32_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TR1_DKDV32"); v = e ? atoi(e) : 1; }
-    return v;
-}
+// wave pairs per block of the 32x32x16 kernel: 6 pairs = 12 waves = 3 per SIMD, 192 keys per block (4 pairs / 128 keys measured slower in round 3)
+static int dkdv32_pairs() { return 6; }
 static int dkdv_keys_per_block(int d_pad) {      // 8-wave blocks where 8*D/512 is integral; head dim 128: the 32x32x16 kernel's pairs x 32
-    if (d_pad == 128 && dkdv32_on()) return dkdv32_pairs() * 32;
+    if (d_pad == 128) return dkdv32_pairs() * 32;
     return (d_pad == 64 || d_pad == 128) ? 128 : 64;
 }
 
@@ -1475,11 +1466,6 @@ static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) 
     const int64_t kvblocks = ((n_slots + kb - 1) / kb) * n_kv;
     int64_t qs = (1024 + kvblocks - 1) / kvblocks;
     if (qs > 8) qs = 8;
-    {   // tuning hook (A/B runs): TR1_DKDV_QS=<n> fixes the number of query slices
-        static int force = -1;
-        if (force < 0) { const char* e = getenv("TR1_DKDV_QS"); force = e ? atoi(e) : 0; }
-        if (force > 0) qs = force;
-    }
     if (qs > n_qtiles) qs = n_qtiles;
     if (qs < 1) qs = 1;
     while ((n_qtiles + qs - 1) / qs > DKDV32_MAXT) ++qs;
@@ -1493,54 +1479,42 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     constexpr int KSTR = 2 * D + 16;
     constexpr int NW = (D == 64 || D == 128) ? 8 : 4;
     constexpr int KB = NW * 16;
-    // TR1_DKDV_KT=2 selects the 4-wave x 32-key form (half the LDS reads per MFMA, but one wave per SIMD and - at the 512-register
-    // limit - a single query tile in flight: 1.03 ms against 0.87 ms for the 8-wave form at config 3, so it stays an experiment)
-    static int kt2 = -1;
-    if (kt2 < 0) { const char* e = getenv("TR1_DKDV_KT"); kt2 = (e ? atoi(e) : 1) == 2 && NW == 8; }
     const size_t dyn_dq = 2 * (2 * ATT_KV * KSTR) + 64;
     const size_t dyn_kv = 2 * (2 * 64 * KSTR + (NW == 8 ? 0 : 2 * D * 144) + 64 * 5 * 4 + 16) + (DKDV_MAXT + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
-        if (NW == 8) hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_kv);
         attr_set = true;
     }
-    // TR1_DQ32 (default 1): the 32x32x16-MFMA dQ kernel (round 3) for head dim 128
-    static int dq32 = -1;
-    if (dq32 < 0) { const char* e = getenv("TR1_DQ32"); dq32 = e ? atoi(e) : 1; }
+    // head dim 128: the 32x32x16-MFMA dQ kernel (round 3)
     const size_t dyn_dq32 = 4 * (2 * 64 * 256) + 128;
     static bool dq32_attr = false;
     if (D == 128 && !dq32_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq32); dq32_attr = true; }
-    const bool use_dq32 = D == 128 && p.d_real == 128 && dq32 > 0 && lse2 != nullptr &&
+    const bool use_dq32 = D == 128 && p.d_real == 128 && lse2 != nullptr &&
                           (uint64_t)p.n_slots * (uint64_t)(p.k_ld > p.v_ld ? p.k_ld : p.v_ld) * 2ull < 0xffffffffull;      // 32-bit DMA byte offsets
     if (use_dq32) hipLaunchKernelGGL(attn_bwd_dq32_kernel, dim3((unsigned)((nR + 255) / 256), p.n_kv), dim3(512), dyn_dq32, s, p, lse2);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
-    // head dim 128: the LDS-DMA staged forms.  TR1_DKDV_DMA = 0: register-staged 8 waves x 16 keys; 1: DMA, 4 waves x 32 keys; 2: DMA, 8 waves x 16 keys
-    static int dma = -1;
-    if (dma < 0) { const char* e = getenv("TR1_DKDV_DMA"); dma = e ? atoi(e) : 2; }
+    // head dim 128 beyond the 32-bit DMA offsets of the 32x32x16 kernel: the LDS-DMA staged 16x16x32 form, 8 waves x 16 keys
     constexpr int DMA_NB = 4;
     const size_t dyn_dma = DMA_NB * (2 * 64 * 256 + 64 * 5 * 4) + (2 * DKDV_MAXT + 2) * 4;
     static bool dma_attr = false;
     if (D == 128 && !dma_attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dma);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dma);
         dma_attr = true;
     }
-    // TR1_DKDV32 (default 1): the 32x32x16-MFMA role-split kernel (round 3) for head dim 128; 0 = the 16x16x32 forms selected by TR1_DKDV_DMA
-    const int v32 = dkdv32_on();
+    // the 32x32x16-MFMA role-split kernel (round 3) for head dim 128
     constexpr int V32_NB = 3;
     const int v32_np = dkdv32_pairs();
     const size_t dyn_v32 = V32_NB * (2 * 64 * 256 + 64 * 5 * 4) + 2 * v32_np * (64 * 32 * 2) + (2 * DKDV32_MAXT + 2) * 4;
     static bool v32_attr = false;
     if (D == 128 && !v32_attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv32_kernel<V32_NB, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv32_kernel<V32_NB, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         v32_attr = true;
     }
-    const bool use_v32 = D == 128 && p.d_real == 128 && v32 > 0 && lse2 != nullptr &&
+    const bool use_v32 = D == 128 && p.d_real == 128 && lse2 != nullptr &&
                          (uint64_t)p.T * (uint64_t)(p.q_ld > p.do_ld ? p.q_ld : p.do_ld) * 2ull < 0xffffffffull;      // 32-bit DMA byte offsets
-    const bool use_dma = D == 128 && p.d_real == 128 && dma > 0 && lse2 != nullptr;
+    const bool use_dma = D == 128 && p.d_real == 128 && lse2 != nullptr;
     const int QS = dkdv_qsplit(p.T, p.group, p.n_kv, p.n_slots, use_v32 ? v32_np * 32 : KB);
     const int64_t kvd = (int64_t)p.n_kv * p.d_real;
     float *pk = nullptr, *pv = nullptr;
@@ -1549,11 +1523,8 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         if (!ws || ws_floats < need) { tr1_set_error_("attention bwd: workspace too small"); return 1000; }
         pk = ws; pv = ws + (int64_t)QS * p.n_slots * kvd;
     }
-    if (use_v32 && v32_np == 6) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB, 6>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 191) / 192)), dim3(768), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
-    else if (use_v32) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB, 4>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
-    else if (use_dma && dma == 2) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
-    else if (use_dma) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<4, 2, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(256), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
-    else if (kt2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, 4, (NW == 8 ? 2 : 1)>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(256), dyn_kv, s, p, n_qtiles, pk, pv);
+    if (use_v32) hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<V32_NB, 6>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 191) / 192)), dim3(768), dyn_v32, s, p, n_qtiles, lse2, pk, pv);
+    else if (use_dma) hipLaunchKernelGGL((attn_bwd_dkdv_dma_kernel<8, 1, DMA_NB>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + 127) / 128)), dim3(512), dyn_dma, s, p, n_qtiles, lse2, pk, pv);
     else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, NW>), dim3((unsigned)(p.n_kv * QS), 1, (unsigned)((p.n_slots + KB - 1) / KB)), dim3(NW * 64), dyn_kv, s, p, n_qtiles, pk, pv);
     const bool rope = p.rope_cos != nullptr;
     bool dk_rotated = false;

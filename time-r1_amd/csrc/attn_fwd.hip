@@ -561,9 +561,7 @@ static int attn_fwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
         p.Opart = (float*)ws_f32; p.mpart = p.Opart + nsplit * n_batch * n_kv * nRpad * d_pad; p.lpart = p.mpart + nsplit * n_batch * n_kv * nRpad;
     }
     dim3 grid(qtiles, (unsigned)(n_kv * n_batch), (unsigned)nsplit);
-    static int xcd_map = -1;                         // TR1_ATTN_XCD=0: plain 2-D grid for the nsplit == 1 launches (A/B measurements)
-    if (xcd_map < 0) { const char* e = getenv("TR1_ATTN_XCD"); xcd_map = e ? atoi(e) : 1; }
-    if (!decode && xcd_map) {
+    if (!decode) {      // XCD-aware block order for the nsplit == 1 launches
         p.grid_x = qtiles; p.grid_y = (int)(n_kv * n_batch);
         p.xcd_pad = (p.grid_x * p.grid_y + 63) / 64 * 64;
         grid = dim3((unsigned)p.xcd_pad, 1, 1);

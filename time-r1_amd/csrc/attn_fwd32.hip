@@ -615,9 +615,7 @@ __global__ __launch_bounds__(512) void attn_dec32_kernel(AttnParams p) {
 // launched by attn_fwd_impl (attn_fwd.hip) for plan_mode 2 launches at head dim 128; returns 0 when the shape does not qualify, 1 when launched
 // (partials written: attn_combine_kernel follows)
 int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("TR1_DEC32"); on = e ? atoi(e) : 1; }
-    if (!on || p.d_real != 128 || p.plan_mode != 2 || !p.plan || p.n_slots % 64 != 0) return 0;
+    if (p.d_real != 128 || p.plan_mode != 2 || !p.plan || p.n_slots % 64 != 0) return 0;
     const uint64_t kbytes = (uint64_t)p.kv_batch_slots * (uint64_t)p.k_ld * 2ull, vbytes = (uint64_t)128 * (uint64_t)p.vt_ld * 2ull;
     if (kbytes >= 0xffffffffull || vbytes >= 0xffffffffull || (uint64_t)p.n_slots * (uint64_t)p.k_ld * 2ull >= 0xffffffffull) return 0;
     const size_t dyn = 4 * (64 * 256 + 128 * 128) + 64 * 256 + 768 + 64;
@@ -645,10 +643,8 @@ extern "C" int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int
     if (T == 0) return 0;
     const int64_t nR = T * p.group;
     const int nqb = (int)((nR + 255) / 256);
-    static int xcd_map = -1;
-    if (xcd_map < 0) { const char* e = getenv("TR1_ATTN_XCD"); xcd_map = e ? atoi(e) : 1; }
     unsigned blocks = (unsigned)(nqb * n_kv);
-    if (xcd_map && 8 % n_kv == 0) {
+    if (8 % n_kv == 0) {
         const int per = 8 / (int)n_kv;
         p.xcd_pad = ((nqb + per - 1) / per) * 8;
         blocks = (unsigned)p.xcd_pad;

@@ -76,12 +76,10 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     // 37.9 -> 34.9 us at M = 16, 54 -> 45 us at M = 32); its ticket counters live in `work`, which the caller zero-fills ONCE
     const int64_t fix_floats = tr1_gemm_skinny_fixup_workspace_floats(R, hid, inter);
     void* fix = c.take(fix_floats * 4);
-    // relevant-tile lists of this step's split-KV attention: written by layer 0's launch, read by the others (TR1_ATTN_PLAN=0: every layer builds its own)
-    static int use_plan = -1;
-    if (use_plan < 0) { const char* e = getenv("TR1_ATTN_PLAN"); use_plan = e ? atoi(e) : 1; }
+    // relevant-tile lists of this step's split-KV attention: written by layer 0's launch, read by the others
     void* plan = c.take(tr1_attn_plan_ints(T, nh, nkv, B) * 4);
     const int qm = w8 ? (int)(dims[D_QMASK] & QM_ALL) : 0;                     // fp8 matrices of this step
-    const bool planned = use_plan && nsplit > 1 && L > 1;
+    const bool planned = nsplit > 1 && L > 1;
     const bool down_fixup = !(qm & QM_DOWN) && R >= 16 && inter >= 8192;
     const bool down_fixup8 = w8 == 2 && (qm & QM_DOWN) && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
     TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");

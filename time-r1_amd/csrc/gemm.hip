@@ -222,15 +222,7 @@ TR1_DEV void store_acc256(const f32x4_t (&acc)[RT][4], void* __restrict__ Cv, co
 #ifndef TR1_EPI_LDS
 #define TR1_EPI_LDS 1
 #endif
-// TR1_EPI_NT=1 (measurement builds): the epilogue's C stores carry the non-temporal hint
-#ifndef TR1_EPI_NT
-#define TR1_EPI_NT 0
-#endif
-#if TR1_EPI_NT
-#define TR1_EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define TR1_EPI_STORE(ptr, val) (*(ptr) = (val))
-#endif
+#define TR1_EPI_STORE(ptr, val) (*(ptr) = (val))      // (non-temporal C stores measured: -0.55 us per round of tiles in a probe, nothing in the step)
 // EPI = 1 ("lm_head -> log-prob / entropy"): nothing is stored to C.  The wave's 64 columns of a row are rounded to bf16 (the logits the
 // reference materialises are bf16) and reduced to the online-softmax triple (max, sum e^(x-max), sum x e^(x-max)); lane c8 = 0 of a row writes it to
 // part[row][ncol0 / 64] (Cv = float4 partials, ldc = column blocks per row, +1 slot per row for the target's logit), and the lane that holds
@@ -1620,7 +1612,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
 
 // TR1_NG32_CFG: A/B hook for the 17..32-row rmsnorm + projection kernels (plain and fused-QKV take the SAME form so they stay bit-identical).
 // Default 1 = 8 waves x UNROLL 2 (fused QKV at 32 rows: 19.7 -> 18.4 us; 144 blocks for 256 CUs, so the extra waves are what adds loads in flight)
-static int ng32_cfg() { static int c = -1; if (c < 0) { const char* e = getenv("TR1_NG32_CFG"); c = e ? atoi(e) : 1; } return c; }
+static int ng32_cfg() { static int c = -1; if (c < 0) { c = 1; } return c; }
 
 extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                                     int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream) {
@@ -1636,10 +1628,10 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
                        (int)M, N, K, ldx, ldw, ldc, eps, N)
     // gate/up + SwiGLU at <= 16 rows: UNROLL 2 keeps the kernel at 128 VGPRs = 4 blocks per CU (1024 slots for 1184 blocks); measured 59.2 vs 60.9 us
     static int glu_lds = -1;                         // TR1_GLU_LDS=0 selects the register-fragment form (A/B measurements)
-    if (glu_lds < 0) { const char* e = getenv("TR1_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
+    if (glu_lds < 0) { glu_lds = 1; }
     const int64_t nst = K / 512;                     // 64-wide stages per wave (8 waves split K)
     static int head_lds = -1;                        // TR1_HEAD_LDS=0: the lm_head stays on the register-fragment kernel (A/B measurements)
-    if (head_lds < 0) { const char* e = getenv("TR1_HEAD_LDS"); head_lds = e ? atoi(e) : 1; }
+    if (head_lds < 0) { head_lds = 1; }
     if (!glu && M > 16 && M <= 32 && head_lds && glu_lds && N >= 65536 && N % 32 == 0 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {
         // 17 .. 32 rows (config 4): two row groups per wave against the same LDS stage, single reduction buffer
         constexpr int RING = 3;
@@ -1745,7 +1737,7 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
     // by DMA as well the decode step measured 3 547 us with it against 3 472 us for the register-fragment form with x in LDS; with the staged x it is
     // 3 277 against 3 325 us.  0 selects the register-fragment kernel (x through LDS unless TR1_QKV_XLDS=0).
     static int qlds = -1;
-    if (qlds < 0) { const char* e = getenv("TR1_QKV_LDS"); qlds = e ? atoi(e) : 1; }
+    if (qlds < 0) { qlds = 1; }
     const int64_t nst = K / 512;
     if (M > 16 && M <= 32 && qlds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3)) {      // 17 .. 32 rows (config 4): two row groups per wave, ring of 3
         constexpr int RING2 = 3;
@@ -1780,7 +1772,7 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
         TR1_LAUNCH_CHECK();
     }
     static int xlds = -1;                            // TR1_QKV_XLDS=0: activation rows through the vector-memory path as well (A/B measurements)
-    if (xlds < 0) { const char* e = getenv("TR1_QKV_XLDS"); xlds = e ? atoi(e) : 1; }
+    if (xlds < 0) { xlds = 1; }
     if (M <= 16 && xlds && K / 64 / 8 >= 2 && K * 32 <= 120 * 1024 && (int64_t)M * ldx * 2 < 0x7fffffffLL) {
         static bool attr_x = false;
         if (!attr_x) { hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_gemm_skinny_kernel<8, 2, 1, false, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr_x = true; }
@@ -1796,7 +1788,7 @@ extern "C" int tr1_norm_gemm_qkv(const void* x, const void* lnw, const void* Wqk
 static void launch_skinny(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N, int64_t K,
                           int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int out_f32, int ksplit, hipStream_t s) {
     static int force_ncol = -1;
-    if (force_ncol < 0) { const char* e = getenv("TR1_SKINNY_NCOL"); force_ncol = e ? atoi(e) : 0; }
+    if (force_ncol < 0) { force_ncol = 0; }
 #define SK(WV, UN, NC, MGR)                                                                                                          \
     hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC, MGR>), dim3((unsigned)((N + 16 * NC - 1) / (16 * NC)), (unsigned)ksplit),    \
                        dim3(WV * 64), 0, s, (const bf16_t*)A, (const bf16_t*)B, out_f32 ? nullptr : (bf16_t*)C,                     \
@@ -1807,38 +1799,13 @@ static void launch_skinny(const void* A, const void* B, void* C, const void* bia
     //  the 3584x18944 down projection has too few column groups for NCOL > 1 and wants split-K instead)
     const int ncol = force_ncol > 0 ? force_ncol : (N >= 100000 ? 4 : (N >= 4096 && ksplit == 1 ? 2 : 1));
     const bool longk = K / ksplit >= 8192;
-#ifdef TR1_PROBE
-    {   // experiment hook (probe build only): TR1_SKINNY_CFG=<waves><unroll><ncol>, e.g. 482
-        const char* e = getenv("TR1_SKINNY_CFG");
-        const int cfg = e ? atoi(e) : 0;
-        if (M <= 16 && cfg) {
-            switch (cfg) {
-                case 482: SK(4, 8, 2, 1); return;
-                case 481: SK(4, 8, 1, 1); return;
-                case 842: SK(8, 4, 2, 1); return;
-                case 822: SK(8, 2, 2, 1); return;
-                case 422: SK(4, 2, 2, 1); return;
-                case 242: SK(2, 4, 2, 1); return;
-                case 282: SK(2, 8, 2, 1); return;
-                case 442: SK(4, 4, 2, 1); return;
-                case 444: SK(4, 4, 4, 1); return;
-                case 424: SK(4, 2, 4, 1); return;
-                case 284: SK(2, 8, 4, 1); return;
-                case 244: SK(2, 4, 4, 1); return;
-                case 144: SK(1, 4, 4, 1); return;
-                case 184: SK(1, 8, 4, 1); return;
-                default: break;
-            }
-        }
-    }
-#endif
     if (M <= 16) {
         if (longk) { if (ncol >= 2 && N >= 16384) SK(8, 2, 2, 1); else SK(8, 4, 1, 1); }
         else if (ncol == 4) SK(4, 2, 4, 1);
         else if (ncol == 2) SK(4, 4, 2, 1);
         else {
             static int xlds = -1;                    // TR1_SKINNY_XLDS=0: activation rows through the vector-memory path (A/B measurements)
-            if (xlds < 0) { const char* e = getenv("TR1_SKINNY_XLDS"); xlds = e ? atoi(e) : 1; }
+            if (xlds < 0) { xlds = 1; }
             if (xlds && ksplit == 1 && K / 64 / 4 >= 4 && K * 32 <= 120 * 1024 && (int64_t)M * lda * 2 < 0x7fffffffLL) {
                 static bool attr_x = false;
                 if (!attr_x) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<4, 4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr_x = true; }
@@ -1876,7 +1843,7 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
     {   // tile choice: CU-rounds x block area / relative efficiency of the structure (tile-count quantisation).
         // 128x128 runs 2 blocks per CU (512 slots), the phased 8-wave forms 1 block per CU at ~1.25x the MFMA rate per CU.
         static int force = -1;
-        if (force < 0) { const char* e = getenv("TR1_GEMM_TILE"); force = e ? atoi(e) : 0; }
+        if (force < 0) { force = 0; }
         auto blocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
         auto cost = [&](int64_t bm, int64_t bn, int64_t slots, double eff) {
             const int64_t t = blocks(bm, bn);
@@ -1899,7 +1866,7 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
             const int bmx = rt * 32;
             const int64_t t2m = (M + bmx - 1) / bmx, t2n = (N + BN2 - 1) / BN2;
             static int phased = -1;                    // TR1_GEMM_PHASED=0 selects the single-barrier form (A/B measurements)
-            if (phased < 0) { const char* e = getenv("TR1_GEMM_PHASED"); phased = e ? atoi(e) : 1; }
+            if (phased < 0) { phased = 1; }
             const size_t dyn = 2 * ((size_t)bmx * BK * 2 + TILE2_BYTES) + (phased ? 4096 : 0);
             static bool attr_set = false;
             if (!attr_set) {
@@ -2500,7 +2467,7 @@ static int skinny_fix_cfg(int64_t M, int64_t N, int64_t K, int* ncol, int* mg) {
     // Few column groups (a narrow output over a long K - the Qwen2-VL-2B down projection: 1536 / 64 = 24 groups x 4 slabs = 96 blocks on 256 CUs, 2.1 TB/s): as
     // many K slabs (<= 16, whole 64-k stages each) as still give at most one block per CU - 24 x 10 = 240 blocks there.  TR1_DOWN_KS=4 keeps the four slabs.
     static int ks_max = -1;
-    if (ks_max < 0) { const char* e = getenv("TR1_DOWN_KS"); ks_max = e ? atoi(e) : 16; }
+    if (ks_max < 0) { ks_max = 16; }
     const int64_t groups = (N + 16 * *ncol - 1) / (16 * *ncol);
     if (ks == 4 && *mg == 1 && groups * 4 < 192)
         for (int cand = 5; cand <= ks_max && cand <= 16; ++cand)
@@ -2512,7 +2479,7 @@ static int skinny_fix_cfg(int64_t M, int64_t N, int64_t K, int* ncol, int* mg) {
 // (7B down projection: 64 x 4 = 256 blocks instead of 56 x 4 = 224).  TR1_DOWN_COLS=64 keeps the 64-column blocks (A/B measurements).
 static bool skinny_fix_cols56(int64_t N, int ks, int ncol, int mg) {
     static int cols = -1;
-    if (cols < 0) { const char* e = getenv("TR1_DOWN_COLS"); cols = e ? atoi(e) : 56; }
+    if (cols < 0) { cols = 56; }
     return cols == 56 && mg == 1 && ncol == 4 && ks > 1 && N % 56 == 0 && (N / 56) * ks <= 256 && (N / 56) > (N + 63) / 64;
 }
 
@@ -2534,7 +2501,7 @@ extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, cons
     int ncol, mg;
     const int ks = skinny_fix_cfg(M, N, K, &ncol, &mg);
     static int down_lds = -1;                        // TR1_DOWN_LDS=0 selects the register-fragment form (A/B measurements); 6 / 7 = waves per block
-    if (down_lds < 0) { const char* e = getenv("TR1_DOWN_LDS"); down_lds = e ? atoi(e) : 7; }
+    if (down_lds < 0) { down_lds = 7; }
     const bool c56 = down_lds && (K / ks) % 64 == 0 && skinny_fix_cols56(N, ks, ncol, mg);
     const int64_t groups = c56 ? N / 56 : (N + 16 * ncol - 1) / (16 * ncol);
     TR1_CHECK_ARG(ws_f32 && ws_floats >= ks * groups * ncol * mg * 256 + groups, "gemm_skinny_fixup: workspace too small");

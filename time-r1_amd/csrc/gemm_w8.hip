@@ -789,7 +789,7 @@ extern "C" int tr1_gemm_skinny_w8(const void* x, const void* lnw, const void* W_
     do { if (mg == 1) W8(WV, UN, NC, 1, NRM, GL); else if (mg == 2) W8(WV, UN, NC, 2, NRM, GL); else W8(WV, 1, NC, 4, NRM, GL); } while (0)
     {   // tuning hook for tools/microbench.py w8: TR1_W8_CFG=<waves><unroll><ncol> (M <= 16 only)
         static int cfg = -1;
-        if (cfg < 0) { const char* e = getenv("TR1_W8_CFG"); cfg = e ? atoi(e) : 0; }
+        if (cfg < 0) { cfg = 0; }
         if (cfg && !glu && M <= 16) {
             const bool nrm = lnw != nullptr;
 #define W8C(WV, UN, NC) do { if (nrm) W8(WV, UN, NC, 1, true, false); else W8(WV, UN, NC, 1, false, false); TR1_LAUNCH_CHECK(); } while (0)
@@ -838,7 +838,7 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
     do { if (mg == 1) W8(WV, UN, NC, 1, NRM, GL); else if (mg == 2) W8(WV, UN, NC, 2, NRM, GL); else W8(WV, 1, NC, 4, NRM, GL); } while (0)
     {   // tuning hook for tools/microbench.py w8: TR1_W8A8_CFG=<waves><unroll><ncol> (M <= 16 only)
         static int cfg = -1;
-        if (cfg < 0) { const char* e = getenv("TR1_W8A8_CFG"); cfg = e ? atoi(e) : 0; }
+        if (cfg < 0) { cfg = 0; }
         if (cfg && !glu && M <= 16) {
             const bool nrm = lnw != nullptr;
 #define W8C(WV, UN, NC) do { if (nrm) W8(WV, UN, NC, 1, true, false); else W8(WV, UN, NC, 1, false, false); TR1_LAUNCH_CHECK(); } while (0)
@@ -861,7 +861,7 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
     // 2-group weight slab - 4 groups halve that traffic (measured, M = 16: lm_head 168 -> 140 us)
     {   // gate/up at <= 16 rows, hidden 3584 / 2048 / 1536: the LDS-streamed form (TR1_W8_GLU_LDS=0: register-fragment form, A/B runs)
         static int glu_lds = -1;
-        if (glu_lds < 0) { const char* e = getenv("TR1_W8_GLU_LDS"); glu_lds = e ? atoi(e) : 1; }
+        if (glu_lds < 0) { glu_lds = 1; }
         const int64_t nw = K / 512;
         if (glu && M <= 16 && glu_lds && K % 512 == 0 && (nw == 7 || nw == 4 || nw == 3) && N % 16 == 0) {
             constexpr int RING = 3;
@@ -891,7 +891,7 @@ extern "C" int tr1_gemm_skinny_w8a8(const void* x, const void* lnw, const void* 
 // x image (32 bytes per k: 16 rows of bf16) + the norm weight, which arrives in whole 1 KiB DMA instructions (the last one may run past K * 2 bytes)
 #define W8X_LDS(K_) ((int64_t)(K_) * 32 + (((int64_t)(K_) * 2 + 1023) / 1024) * 1024)
         static int xlds = -1;                        // TR1_W8A8_XLDS=0: activation rows / norm weight through the vector-memory path (A/B measurements)
-        if (xlds < 0) { const char* e = getenv("TR1_W8A8_XLDS"); xlds = e ? atoi(e) : 1; }
+        if (xlds < 0) { xlds = 1; }
         const bool x_ok = xlds && mg == 1 && K < 8192 && K % 128 == 0 && W8X_LDS(K) <= 128 * 1024 && (int64_t)M * ldx * 2 < 0x7fffffffLL;
 #define W8X(NC, NRM) do {                                                                                                                        \
             static bool attr_ = false;                                                                                                           \

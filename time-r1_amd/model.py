@@ -25,7 +25,7 @@ F32 = torch.float32
 class Engine:
     def __init__(self, cfg: ModelConfig, ops, params: ModelParams):
         self.cfg, self.ops, self.params = cfg, ops, params
-        self.overlap_wgrad = os.environ.get("TR1_WGRAD_OVERLAP", "1") != "0"      # weight gradients on a second HIP stream (A/B switch)
+        self.overlap_wgrad = True      # weight gradients on a second HIP stream (attribute for A/B runs; measured equal in rounds 4-5: the backward is a serial sum)
         # weight gradients that stay on the MAIN stream (d = down, g = gate/up, o, q = qkv); the rest runs on the side stream beside the dgrad
         # chain.  With the dgrad reading the weights as stored (NN form) the main stream has slack: keeping the down projection's weight
         # gradient there balanced the two streams best on MI355X (backward 175 ms against 180 with everything on the side stream; with the main
@@ -34,8 +34,8 @@ class Engine:
         self.wgrad_overwrite_first = True    # see _wgrad: relies on the optimizer zeroing the gradient arena and bumping arena.version (AdamWFlat.step)
         self._gw_ver = {}
         self.lazy_zero_active = False        # set by the owner of the optimizer when AdamWFlat.lazy_zero is in force (see _wgrad)
-        self.fused_head = os.environ.get("TR1_FUSED_HEAD", "1") != "0"    # lm_head -> logp / entropy in the GEMM epilogue where the logits are not kept
-        self.wgrad_nn = os.environ.get("TR1_WGRAD_NN", "1") != "0"      # weight gradients read the saved activation as stored (A/B switch)
+        self.fused_head = True    # lm_head -> logp / entropy in the GEMM epilogue where the logits are not kept
+        self.wgrad_nn = True      # weight gradients read the saved activation as stored (attribute for A/B runs)
         self._side = None
         # set (by the owner of the optimizer) for the backward of a window's LAST micro-step: the weight-gradient epilogues of the decoder layers' large
         # matrices then also leave the squared norm of the final gradient (AdamWFlat.norm_sink_begin / step)
@@ -288,8 +288,8 @@ class Engine:
 
     # A full set of saved-activation buffers above this size is kept ONCE: further prompts of the accumulation window stash only their
     # prompt rows (written by the rollout prefill) and move them into the one full set when their update starts (unstash_ctx).
-    CTX_STASH_GB = float(os.environ.get("TR1_CTX_STASH_GB", "40"))
-    SHARE_A = os.environ.get("TR1_SHARE_A", "1") != "0"      # A/B: one shared SwiGLU-output buffer in the large-sequence regime (recomputed in the backward)
+    CTX_STASH_GB = 40.0
+    SHARE_A = True      # one shared SwiGLU-output buffer in the large-sequence regime (rebuilt in the backward); class attribute for A/B runs
 
     def ctx_bytes(self, rows):
         t = self.cfg.text
@@ -343,7 +343,7 @@ class Engine:
         pctx["stash"] = False
         return pctx
 
-    TAIL_SKIP = os.environ.get("TR1_TAIL_SKIP", "1") != "0"     # A/B switch for `tail_from` (0: every row runs the whole last layer)
+    TAIL_SKIP = True     # class attribute (tests / A/B runs clear it): False = every row runs the whole last layer
 
     def tail_rows_from(self, P, M):
         """The `tail_from` a caller should pass for a packed sequence of P prompt rows in M rows, or None: the saving is the prompt's share of ONE layer, so
@@ -543,7 +543,7 @@ class Engine:
     # Logits exist at most for HEAD_CHUNK_ROWS prediction rows at a time.  Up to that many rows (config 3: G*C = 1600 rows, 0.49 GB of bf16
     # logits) the policy path keeps them for the backward; beyond it (config 4: 16 x 1024 rows = 5 GB) both passes walk the rows in chunks
     # and the backward recomputes a chunk's logits with one more lm_head GEMM (~1 ms per 1024 rows at 7B) instead of holding [G*C, V].
-    HEAD_CHUNK_ROWS = int(os.environ.get("TR1_HEAD_CHUNK_ROWS", "4096"))
+    HEAD_CHUNK_ROWS = 4096
 
     def head_fwd(self, arena: Arena, h_last, pred_rows, targets, save):
         """Final norm + lm_head on the rows that predict completion tokens only, then per-token log-prob and entropy

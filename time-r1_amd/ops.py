@@ -109,7 +109,7 @@ class HipOps:
 
     # ---- GEMM -----------------------------------------------------------------------------------------------------
     def _splitk_ok(self, M, N, K):
-        """Few 256 x 256 tiles, many K tiles: the split-K form pays (A/B switch TR1_GEMM_SPLITK)."""
+        """Few 256 x 256 tiles, many K tiles: the split-K form pays (class attribute SPLITK: A/B runs clear it)."""
         return bool(self.SPLITK and M > 64 and K >= 2048 and K % 64 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and 8 * M * N * 4 <= (1 << 31))
 
     def gemm_nn(self, a, b):
@@ -165,7 +165,7 @@ class HipOps:
         return out
 
     # ---- fused-epilogue training GEMMs (bit-identical to the compositions in their `else` branches) ---------------------
-    SPLITK = os.environ.get("TR1_GEMM_SPLITK", "1") != "0"        # A/B switch for the 2-way split-K form of thin long-K GEMMs
+    SPLITK = True        # the S-way split-K form of thin long-K GEMMs (class attribute for A/B runs)
     FUSE_EPI = os.environ.get("TR1_FUSE_EPI", "1") != "0"          # A/B switch: 0 = GEMM + separate elementwise kernels (the round-3 path)
 
     def gemm_quickgelu(self, x, w, bias=None):
@@ -229,7 +229,7 @@ class HipOps:
         self.L.call("tr1_gemm_qkv_rope_vit_bf16", _p(x), _p(w_qkv), _p(bias), _p(cos), _p(sin), _p(q128), _ld(q128), _p(k128), _ld(k128), _p(v128), _ld(v128),
                     M, n_heads, half, K, _ld(x), _ld(w_qkv), self._s())
 
-    DGU_T = os.environ.get("TR1_DGU_T", "1") != "0"        # A/B switch: dgu^T from the fused dgrad's epilogue instead of a transpose pass
+    DGU_T = True        # dgu^T from the fused dgrad's epilogue instead of a transpose pass (class attribute for A/B runs)
 
     def dgrad_glu_bwd(self, dh, w_down, gu, want_t=False):
         """dgu[M, 2I] = swiglu_bwd(dh @ w_down, gu) with w_down [H, I] as stored (K-major operand).  want_t: -> (dgu, dgu^T or None); the fused kernel can
@@ -573,7 +573,7 @@ class HipOps:
         """int32 buffer for attn_fwd(plan=..., plan_mode=1|2): the relevant-tile lists of one decode step, shared by its layers."""
         return self.zeros(self.L.raw("tr1_attn_plan_ints")(T, n_heads, n_kv, n_batch), dtype=I32)
 
-    FWD32 = os.environ.get("TR1_FWD32", "1") != "0"      # head dim 128, nsplit 1: the 32x32x16-MFMA forward over row-major K / V (A/B switch)
+    FWD32 = True      # head dim 128, nsplit 1: the 32x32x16-MFMA forward over row-major K / V (class attribute: tests / tools may clear it)
 
     def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
                  kv_batch_slots=0, plan=None, plan_mode=0, v_rows=None):

@@ -38,6 +38,7 @@ class Rollout:
         self.temperature, self.top_k, self.seed, self.stop_at_eos = float(temperature), int(top_k or 0), int(seed), bool(stop_at_eos)
         self._cache = None
         self.calls = 0
+        self.force_nsplit = 0         # > 0: fixed split count of the decode attention (A/B runs)
         self.native_decode = True     # one native call per decode step (HipOps); False = op-by-op from the host (tests compare the two)
         self.weight_dtype = "bf16"    # "fp8" / "fp8-mfma": decode GEMMs read an e4m3 copy of the decoder matrices + lm_head (row scales), re-quantised
         #                               per call; "fp8" converts the codes to bf16 in registers (W8A16), "fp8-mfma" feeds them to the fp8 matrix
@@ -145,8 +146,8 @@ class Rollout:
             slots_all = ops.tensor(np.stack([lay.completion_slots(s) for s in range(C)]), I32)       # [C, G]
             pre_d, lo_d, _ = [ops.tensor(a, I32) for a in lay.decode_masks(0)]
             nsplit = max(1, min(28, ((P + 63) // 64 + 3) // 2))
-            if os.environ.get("TR1_DECODE_NSPLIT"):          # tuning hook (A/B runs)
-                nsplit = int(os.environ["TR1_DECODE_NSPLIT"])
+            if self.force_nsplit:                            # tuning hook (A/B runs)
+                nsplit = int(self.force_nsplit)
             per.append(dict(lay=lay, kv=kv_views, prefill_ctx=pctx, seed=seed, tokens=tokens, finished=finished, slots=slots_all, pre=pre_d, lo=lo_d, nsplit=nsplit))
         cos_all = torch.cat(cos_rows, 1).contiguous()      # [C, B*G, half]
         sin_all = torch.cat(sin_rows, 1).contiguous()
@@ -156,7 +157,7 @@ class Rollout:
         nsplit = max(st["nsplit"] for st in per)
         # ONE round of blocks: a split-KV block takes a whole CU (145 KB of LDS), so (prompts x kv heads x 64-row query tiles) x splits above the CU count runs
         # as two rounds - 32 decode rows at 7B = 16 groups x 27 splits = 432 blocks took 25.1 us per layer at step 1 against 19.8 with 14 splits (round 5)
-        if not os.environ.get("TR1_DECODE_NSPLIT"):
+        if not self.force_nsplit:
             groups = B * t.n_kv_heads * ((G * (t.n_heads // t.n_kv_heads) + 63) // 64)
             nsplit = max(2, min(nsplit, self._n_cus() // max(1, groups))) if nsplit > 1 else nsplit
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
