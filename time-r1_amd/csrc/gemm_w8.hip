@@ -602,24 +602,24 @@ __global__ __launch_bounds__(NW * 64) void norm_glu_lds_f8_kernel(const bf16_t* 
 // of fp8 (8 KiB) + the 16 activation rows x 128 k of bf16 (2 x 16 x 128 bytes, quantised per lane pair right before the MFMA).  The partial
 // tiles go through the same workspace and ticket protocol (the last-arriving slab sums the tiles in slab order); the weight's row scale is
 // applied once, to the summed tile.
-template <int WAVES>
+template <int WAVES, int NWI = 8>      // NWI = weight DMA instructions (8 rows each) per stage: 8 = 64-column blocks, 7 = 56-column blocks (3584 columns: 64 groups x 4 slabs = every CU)
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(const bf16_t* __restrict__ X, const unsigned char* __restrict__ W,
                                                                             const float* __restrict__ wscale, bf16_t* __restrict__ C,
                                                                             const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int M,
                                                                             int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr,
                                                                             float* __restrict__ fix_ws, int* __restrict__ fix_cnt) {
-    constexpr int NC = 4, STAGE = NC * 2048 + 4096, TILE = NC * 256;
+    constexpr int NC = 4, STAGE = NWI * 1024 + 4096, TILE = NC * 256, COLS = NWI * 8;
     extern __shared__ __attribute__((aligned(16))) char sk8_lds[];         // [WAVES][2][STAGE]; afterwards red[WAVES][NC][16][17] f32; ticket at the end
     int* s_ticket = reinterpret_cast<int*>(sk8_lds + WAVES * 2 * STAGE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, u = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * (16 * NC);
+    const int64_t n0 = (int64_t)blockIdx.x * COLS;
     const int64_t kslab = K / gridDim.y, k0 = (int64_t)blockIdx.y * kslab;
     const int nst = (int)(kslab / 128);
     const int n_my = wave < nst ? (nst - wave + WAVES - 1) / WAVES : 0;
     char* ring = sk8_lds + wave * 2 * STAGE;
-    const unsigned char* pw[8]; const bf16_t* px[4];
+    const unsigned char* pw[NWI]; const bf16_t* px[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NWI; ++j) {
         const int r = 8 * j + (lane >> 3);
         int64_t row = n0 + r; if (row >= N) row = N - 1;
         pw[j] = W + row * ldw + k0 + (int64_t)wave * 128 + (((lane & 7) ^ keyA8(r)) << 4);
@@ -631,8 +631,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(cons
     }
 #define SK8_ISSUE(SLOT) do {                                                                                              \
         char* dst__ = ring + (SLOT) * STAGE;                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) { __builtin_amdgcn_global_load_lds((w8_gptr_t)pw[j], (w8_lptr_t)(dst__ + j * 1024), 16, 0, 2); pw[j] += WAVES * 128; } \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) { __builtin_amdgcn_global_load_lds((w8_gptr_t)px[j], (w8_lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 128; } \
+        _Pragma("unroll") for (int j = 0; j < NWI; ++j) { __builtin_amdgcn_global_load_lds((w8_gptr_t)pw[j], (w8_lptr_t)(dst__ + j * 1024), 16, 0, 2); pw[j] += WAVES * 128; } \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { __builtin_amdgcn_global_load_lds((w8_gptr_t)px[j], (w8_lptr_t)(dst__ + NWI * 1024 + j * 1024), 16, 0, 0); px[j] += WAVES * 128; } \
     } while (0)
     f32x4_t acc[NC];
 #pragma unroll
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(cons
     const int partner = lane ^ 16, src_lane = u + 16 * (2 * (g & 1));
     auto consume = [&](int slot) {
         const char* sb = ring + slot * STAGE;
-        const char* xb = sb + NC * 2048;
+        const char* xb = sb + NWI * 1024;      // (56-column stages: the MFMA's weight rows 56..63 read into this area - they feed output columns that are never stored)
         float v[2][16], am[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -683,10 +683,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(cons
     };
     if (n_my > 0) SK8_ISSUE(0);
     for (int i = 0; i < n_my; i += 2) {
-        if (i + 1 < n_my) { SK8_ISSUE(1); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i + 1 < n_my) { SK8_ISSUE(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWI + 4) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         consume(0);
         if (i + 1 < n_my) {
-            if (i + 2 < n_my) { SK8_ISSUE(0); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (i + 2 < n_my) { SK8_ISSUE(0); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWI + 4) : "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             consume(1);
         }
     }
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_f8_kernel(cons
             for (int ks = 0; ks < (int)gridDim.y; ++ks)
                 v += __hip_atomic_load(fix_ws + ((int64_t)ks * gridDim.x + blockIdx.x) * TILE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (mm < M && n < N) {
+        if (mm < M && n < N && c * 16 + nn < COLS) {
             v *= wscale[n];
             if (bias) v += bf2f(bias[n]);
             if (residual) v += bf2f(residual[(int64_t)mm * ldr + n]);
@@ -918,6 +918,22 @@ extern "C" int tr1_gemm_skinny_fixup_w8a8(const void* x, const void* W_fp8, cons
     constexpr int KS = 4, WV = 6;
     TR1_CHECK_ARG(M >= 1 && M <= 16 && K % (KS * 128) == 0 && N % 64 == 0, "gemm_skinny_fixup_w8a8: 1 <= M <= 16, K % 512 == 0, N % 64 == 0");
     TR1_CHECK_ARG(ldx % 8 == 0 && ldw % 16 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_skinny_fixup_w8a8: ldx%8, ldw%16, ldc%8");
+    // round 5: 56-column blocks where that fills the chip (N = 3584: 64 groups x 4 slabs = 256 blocks instead of 224) - the 11 KiB stages then leave room for
+    // a seventh wave (7 x 2 x 11 KiB = 154 KiB); same K slabs, same ordered fixup (what the bf16 kernel got in round 3)
+    if (N % 56 == 0 && (N / 56) * KS <= 256 && N / 56 > N / 64) {
+        constexpr int WV7 = 7;
+        const int64_t g56 = N / 56;
+        TR1_CHECK_ARG(ws_f32 && ws_floats >= KS * g56 * 4 * 256 + g56, "gemm_skinny_fixup_w8a8: workspace too small");
+        float* tiles56 = (float*)ws_f32;
+        int* cnt56 = (int*)(tiles56 + KS * g56 * 4 * 256);
+        const size_t dyn56 = WV7 * 2 * (7 * 1024 + 4096) + 16;
+        static bool attr56 = false;
+        if (!attr56) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_f8_kernel<WV7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn56); attr56 = true; }
+        hipLaunchKernelGGL((gemm_skinny_lds_fix_f8_kernel<WV7, 7>), dim3((unsigned)g56, KS), dim3(WV7 * 64), dyn56, (hipStream_t)stream, (const bf16_t*)x,
+                           (const unsigned char*)W_fp8, (const float*)wscale, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, ldx,
+                           ldw, ldc, ldr, tiles56, cnt56);
+        TR1_LAUNCH_CHECK();
+    }
     const int64_t groups = N / 64;
     TR1_CHECK_ARG(ws_f32 && ws_floats >= KS * groups * 4 * 256 + groups, "gemm_skinny_fixup_w8a8: workspace too small");
     float* tiles = (float*)ws_f32;

@@ -1,6 +1,6 @@
 """Packed shared-prefix attention forward / backward at the config-3 shape (P = 3474, G = 8, C = 200, 28 heads / 4 kv heads, head dim 128):
 per-kernel times from HIP events and relative L2 error against the masked fp32 attention on the GPU (same reference as
-tests/test_fullsize_gpu.py).  Kernel variants are selected by environment (TR1_DKDV32, TR1_DQ32, TR1_FWD32, ...), one process per variant.
+tests/test_fullsize_gpu.py).  (Rounds 3-4 selected kernel variants by environment - TR1_DKDV32, TR1_DQ32, TR1_FWD32 - one process per variant; round 5 removed those switches: the 32x32x16 kernels are the only head-dim-128 forms.  A/B runs now go through tools/build_ref_lib.sh.)
 
     python tools/bench_attn.py [--iters 20] [--no-check] [--P 3474 --G 8 --C 200]
 """

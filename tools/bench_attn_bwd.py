@@ -1,4 +1,4 @@
-"""Attention backward at the packed config-3 / config-4 shapes: time per call and parity of the selected dK/dV form (TR1_DKDV_DMA) against the
+"""Attention backward at the packed config-3 / config-4 shapes: time per call and parity of the dK/dV kernel (rounds 2-4: the form selected by TR1_DKDV_DMA, removed in round 5) against the
 register-staged form is checked by the tests; this prints the timings (HIP events around tr1_attn_bwd = delta + dQ + dK/dV + reduce)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,5 +24,5 @@ e1.record(); torch.cuda.synchronize()
 pairs = float(((torch.arange(M, device="cuda")[None] < pre[:, None]) | ((torch.arange(M, device="cuda")[None] >= lo[:, None]) & (torch.arange(M, device="cuda")[None] <= hi[:, None]))).sum())
 fl = pairs * H * HD * 2 * 5
 ms = e0.elapsed_time(e1) / 10
-print("TR1_DKDV_DMA=%s  M=%d  attn_bwd %.3f ms  (%.0f TFLOP/s algorithmic)  checksum %.6f %.6f %.6f" % (os.environ.get("TR1_DKDV_DMA", "default"), M, ms, fl / ms / 1e9,
+print("M=%d  attn_bwd %.3f ms  (%.0f TFLOP/s algorithmic)  checksum %.6f %.6f %.6f" % (M, ms, fl / ms / 1e9,
       float(out[0].float().abs().mean()), float(out[1].float().abs().mean()), float(out[2].float().abs().mean())))

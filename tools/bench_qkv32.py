@@ -37,8 +37,8 @@ xfrag = torch.randn((M + 15) // 16 * 16 * K, device="cuda").bfloat16()
 def oproj_frag():      # round 5: all weight stages in flight, fragment-major activation, no fixup (csrc/oproj.hip)
     i[0] = (i[0] + 1) % NC
     return ops.gemm_oproj_frag(xfrag, wo[i[0]], M, residual=res)
-print("cfg %s M=%d: fused qkv %6.2f us   o projection %6.2f us   o projection (fragment-major x, csrc/oproj.hip) %6.2f us" %
-      (os.environ.get("TR1_NG32_CFG", "0"), M, timeit(qkv), timeit(oproj), timeit(oproj_frag)))
+print("M=%d: fused qkv %6.2f us   o projection %6.2f us   o projection (fragment-major x, csrc/oproj.hip) %6.2f us" %
+      (M, timeit(qkv), timeit(oproj), timeit(oproj_frag)))
 
 if os.environ.get("PROBE"):      # TR1_HIP_LIB=tools/_probe_lib.so PROBE=1: block timeline of ONE fused QKV launch
     import ctypes

@@ -31,7 +31,7 @@ def main():
     # unchanged (a kernel edit that alters traffic must not keep quoting the old counters)
     import hashlib, os
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "time-r1_amd", "csrc")
-    out["_source_sha16"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in ("gemm.hip", "decode.hip", "oproj.hip", "gemm_w8.hip")}
+    out["_source_sha16"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in (("gemm.hip", "decode.hip", "oproj.hip") + (("gemm_w8.hip",) if any(("_w8" in k or "_f8" in k) for k in out) else ()))}      # (the fp8 twins only when the pass ran them)
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     for k, v in out.items():
         if not k.startswith("_"):
