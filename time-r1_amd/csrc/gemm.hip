@@ -2335,7 +2335,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
                                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int M,
                                                                          int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, int64_t ldr,
                                                                          float* __restrict__ fix_ws, int* __restrict__ fix_cnt) {
-    constexpr int NC = 4, STAGE = NC * 2048 + MG * 2048;                    // 64 weight rows + 16*MG activation rows, 128 bytes each
+    constexpr int NC = 4, XOFF = NWI * 1024, STAGE = XOFF + MG * 2048;      // NWI * 8 weight rows + 16*MG activation rows, 128 bytes each (56-column stages: the MFMA's
+                                                                            // weight rows 56..63 read into the activation area - they feed output columns that are never stored)
     constexpr int TILE = NC * MG * 256;
     extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // [WAVES][2][STAGE]; afterwards red[WAVES][NC][MG][16][17] f32; ticket at the end
     int* s_ticket = reinterpret_cast<int*>(sk_lds + WAVES * 2 * STAGE);
@@ -2364,7 +2365,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
 #define SKL_ISSUE(SLOT) do {                                                                                              \
         char* dst__ = ring + (SLOT) * STAGE;                                                                              \
         _Pragma("unroll") for (int j = 0; j < NWI; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)pw[j], (lptr_t)(dst__ + j * 1024), 16, 0, TR1_W_AUX); pw[j] += WAVES * 64; } \
-        _Pragma("unroll") for (int j = 0; j < 2 * MG; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)px[j], (lptr_t)(dst__ + NC * 2048 + j * 1024), 16, 0, 0); px[j] += WAVES * 64; } \
+        _Pragma("unroll") for (int j = 0; j < 2 * MG; ++j) { __builtin_amdgcn_global_load_lds((gptr_t)px[j], (lptr_t)(dst__ + XOFF + j * 1024), 16, 0, 0); px[j] += WAVES * 64; } \
     } while (0)
     f32x4_t acc[NC][MG][2];
 #pragma unroll
@@ -2377,7 +2378,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_lds_fix_kernel(const b
         bf16x8_t xf__[MG][2], wf__[NC][2];                                                                                \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
             const int off__ = ((ks * 4 + g) ^ kA) << 4;                                                                   \
-            _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) xf__[mg][ks] = *reinterpret_cast<const bf16x8_t*>(sb__ + (NC + mg) * 2048 + rd_w + off__); \
+            _Pragma("unroll") for (int mg = 0; mg < MG; ++mg) xf__[mg][ks] = *reinterpret_cast<const bf16x8_t*>(sb__ + XOFF + mg * 2048 + rd_w + off__); \
             _Pragma("unroll") for (int c = 0; c < NC; ++c) wf__[c][ks] = *reinterpret_cast<const bf16x8_t*>(sb__ + c * 2048 + rd_w + off__); \
         }                                                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
@@ -2480,7 +2481,7 @@ static int skinny_fix_cfg(int64_t M, int64_t N, int64_t K, int* ncol, int* mg) {
 static bool skinny_fix_cols56(int64_t N, int ks, int ncol, int mg) {
     static int cols = -1;
     if (cols < 0) { cols = 56; }
-    return cols == 56 && mg == 1 && ncol == 4 && ks > 1 && N % 56 == 0 && (N / 56) * ks <= 256 && (N / 56) > (N + 63) / 64;
+    return cols == 56 && mg <= 2 && ncol == 4 && ks > 1 && N % 56 == 0 && (N / 56) * ks <= 256 && (N / 56) > (N + 63) / 64;
 }
 
 extern "C" int64_t tr1_gemm_skinny_fixup_workspace_floats(int64_t M, int64_t N, int64_t K) {
@@ -2512,7 +2513,14 @@ extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, cons
     hipLaunchKernelGGL((gemm_skinny_kernel<WV, UN, NC, MGR>), dim3((unsigned)groups, (unsigned)ks), dim3(WV * 64), 0, s,            \
                        (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, \
                        (int)M, N, K, lda, ldb, ldc, ldr, tiles, ks > 1 ? cnt : (int*)nullptr)
-    if (mg == 2 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {       // 17 .. 32 rows: 12 KiB stages, 6 waves
+    if (c56 && mg == 2) {       // round 5, 17 .. 32 rows: 56-column blocks as well (256 blocks), whose 11 KiB stages leave room for a seventh wave
+        static bool attr562 = false;
+        constexpr int DYN = 7 * 2 * (7 * 1024 + 2 * 2048) + 16;
+        if (!attr562) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<7, 2, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN); attr562 = true; }
+        hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<7, 2, 7>), dim3((unsigned)groups, (unsigned)ks), dim3(448), DYN, s, (const bf16_t*)A, (const bf16_t*)B,
+                           (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr, tiles, cnt);
+    }
+    else if (mg == 2 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {       // 17 .. 32 rows: 12 KiB stages, 6 waves
         static bool attr2 = false;
         if (!attr2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 2 * 12288 + 16); attr2 = true; }
         hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<6, 2>), dim3((unsigned)groups, (unsigned)ks), dim3(384), 6 * 2 * 12288 + 16, s, (const bf16_t*)A, (const bf16_t*)B,
@@ -2520,8 +2528,9 @@ extern "C" int tr1_gemm_skinny_fixup(const void* A, const void* B, void* C, cons
     }
     else if (c56) {
         static bool attr56 = false;
-        if (!attr56) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<7, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2 * 10240 + 16); attr56 = true; }
-        hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<7, 1, 7>), dim3((unsigned)groups, (unsigned)ks), dim3(448), 7 * 2 * 10240 + 16, s, (const bf16_t*)A, (const bf16_t*)B,
+        constexpr int DYN = 7 * 2 * (7 * 1024 + 2048) + 16;
+        if (!attr56) { hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_lds_fix_kernel<7, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN); attr56 = true; }
+        hipLaunchKernelGGL((gemm_skinny_lds_fix_kernel<7, 1, 7>), dim3((unsigned)groups, (unsigned)ks), dim3(448), DYN, s, (const bf16_t*)A, (const bf16_t*)B,
                            (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)residual, (int)M, N, K, lda, ldb, ldc, ldr, tiles, cnt);
     }
     else if (mg == 1 && ncol == 4 && ks > 1 && down_lds && (K / ks) % 64 == 0 && N % 64 == 0) {
