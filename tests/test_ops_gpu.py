@@ -707,7 +707,8 @@ def test_attention_decode_batched_prompts(hip_ops, ref_ops):
             assert int(cnt.min()) > 0 and int(cnt.max()) <= 1024, cnt
 
 @pytest.mark.parametrize("B,G,nh,nkv,nsplit,N", [(2, 8, 28, 4, 28, 3584), (2, 8, 12, 2, 21, 1536), (1, 16, 14, 2, 28, 1792), (2, 16, 28, 4, 16, 3584),
-                                                 (2, 5, 12, 4, 7, 512), (1, 3, 4, 4, 2, 4096)])
+                                                 (2, 5, 12, 4, 7, 512), (1, 3, 4, 4, 2, 4096), (1, 1, 28, 4, 28, 3584), (1, 17, 28, 4, 8, 3584), (3, 8, 28, 4, 8, 3584),
+                                                 (1, 8, 4, 4, 64, 512)])
 def test_decode_o_projection_on_fragment_major_attention_rows(hip_ops, B, G, nh, nkv, nsplit, N):
     """Round 5 (csrc/oproj.hip): the split-KV merge writes its rows fragment-major ([k / 32][16 rows][32 k]: the 16 rows x 64 bytes of an MFMA operand fragment
     are one contiguous KiB) and the o projection keeps its whole weight slice in flight with no cross-block fixup.  The fragment-major rows hold exactly the
