@@ -376,3 +376,37 @@ def test_tail_row_skip_is_chosen_per_layout_and_consistently():
         assert eng.tail_rows_from(3474, 5074) is None
     finally:
         Engine.TAIL_SKIP = old
+
+
+def test_decode_attention_split_count_stays_within_one_round_of_blocks():
+    """Round 5: a split-KV decode block takes a whole CU, so (prompts x kv heads x 64-row query tiles) x splits must not exceed the CU count (config 4 ran
+    16 groups x 27 splits = 432 blocks in two rounds).  Configs 3 / 2 keep their split counts, config 4 drops to 16, tiny shapes never go below 2."""
+    from time_r1_amd.rollout import Rollout
+    assert Rollout.cap_nsplit(28, 2, 8, 28, 4, 256) == 28          # config 3: 8 groups x 28 = 224 blocks
+    assert Rollout.cap_nsplit(21, 2, 8, 12, 2, 256) == 21          # config 2: 4 groups x 21 = 84 blocks
+    assert Rollout.cap_nsplit(27, 2, 16, 28, 4, 256) == 16         # config 4: 16 groups -> 16 splits = 256 blocks
+    assert Rollout.cap_nsplit(28, 8, 16, 28, 4, 256) == 4          # 64 groups
+    assert Rollout.cap_nsplit(28, 64, 16, 28, 4, 256) == 2         # never below 2
+    assert Rollout.cap_nsplit(1, 2, 8, 28, 4, 256) == 1            # an unsplit launch stays unsplit
+
+
+def test_gradient_exchange_stages_only_what_no_producer_wrote():
+    """Round 5 (data-parallel per-rank tax): a weight-gradient epilogue may write the bf16 wire copy of its matrix itself (GradSync.wire_view / mark_wire); the
+    staging pass in ready() then copies only the gaps.  Pure host / tensor logic, no collective is started here."""
+    import types
+    from time_r1_amd.dist import GradSync
+    g = torch.arange(64, dtype=torch.float32) * 0.5
+    sync = GradSync(g, types.SimpleNamespace(enabled=True, world=2), wire_dtype=torch.bfloat16)
+    sync.begin()
+    assert sync.stage is not None and sync.wire_view(8, (2, 4)).shape == (2, 4)
+    sync.stage.fill_(-1.0)
+    sync.wire_view(8, (2, 4)).copy_(torch.full((2, 4), 7.0))       # "the epilogue wrote [8, 16)"
+    sync.mark_wire(8, 16)
+    sync.wire_view(40, (8,)).copy_(torch.full((8,), 9.0))
+    sync.mark_wire(40, 48)
+    sync._stage_gaps(4, 44)                                          # a bucket that starts before the first and ends inside the second written range
+    want = torch.full((64,), -1.0)
+    want[4:8] = g[4:8]; want[8:16] = 7.0; want[16:40] = g[16:40]; want[40:48] = 9.0
+    assert torch.equal(sync.stage.float(), want.to(torch.bfloat16).float())
+    sync.active = False
+    assert sync.wire_view(0, (4,)) is None                           # outside a window nothing may be written

@@ -61,6 +61,15 @@ class Rollout:
     MATS = ("qkv.w", "o.w", "gu.w", "down.w")
     QBITS = {"qkv": 1, "o": 2, "gu": 4, "down": 8, "lm_head": 16}
 
+    @staticmethod
+    def cap_nsplit(nsplit, n_prompts, G, n_heads, n_kv, n_cus):
+        """Split count of the decode attention such that (prompts x kv heads x 64-row query tiles) x splits stays within ONE round of blocks (a split-KV block
+        takes a whole CU); never below 2 (the split-KV launch is what makes a decode step), unchanged when the launch is not split."""
+        if nsplit <= 1:
+            return nsplit
+        groups = n_prompts * n_kv * ((G * (n_heads // n_kv) + 63) // 64)
+        return max(2, min(nsplit, n_cus // max(1, groups)))
+
     def _n_cus(self):
         dev = getattr(self.eng.ops, "device", None)
         if dev is not None and torch.device(dev).type == "cuda":
@@ -158,8 +167,7 @@ class Rollout:
         # ONE round of blocks: a split-KV block takes a whole CU (145 KB of LDS), so (prompts x kv heads x 64-row query tiles) x splits above the CU count runs
         # as two rounds - 32 decode rows at 7B = 16 groups x 27 splits = 432 blocks took 25.1 us per layer at step 1 against 19.8 with 14 splits (round 5)
         if not self.force_nsplit:
-            groups = B * t.n_kv_heads * ((G * (t.n_heads // t.n_kv_heads) + 63) // 64)
-            nsplit = max(2, min(nsplit, self._n_cus() // max(1, groups))) if nsplit > 1 else nsplit
+            nsplit = self.cap_nsplit(nsplit, B, G, t.n_heads, t.n_kv_heads, self._n_cus())
         abs_slots = torch.cat([st["slots"] + b * cache.s_cap for b, st in enumerate(per)], 1).contiguous()   # [C, B*G] into the unified cache
         R = B * G
         fused = R <= 64        # the fused decode kernels hold all rows of a step in one MFMA column block set
