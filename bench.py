@@ -577,10 +577,11 @@ def main(argv=None):
             "optimizer_steps": len(timed_plan), "windows": "%d x %d" % (args.steps // args.ga, args.ga) + (" + 1 x %d" % (args.steps % args.ga) if args.steps % args.ga else ""),
             "hbm_gb": {"allocated_peak": round(torch.cuda.max_memory_allocated() / 1e9, 1), "reserved_peak": round(torch.cuda.max_memory_reserved() / 1e9, 1),
                        "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0)), "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))},
-            "config": {"workload": "%s GRPO micro-step: %d frames (grid %s), prompt P=%d tokens, G=%d completions x C=%d tokens, beta=%g, "
-                                   "loss=%s, grad-accum %d, 1 prompt/GPU/step; uint8 %dx%d frames -> fused resize/normalise/patchify inside the step%s"
-                                   % (cfg.name, args.frames, str(wl.grid), wl.P or 0, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga,
-                                      wl.src_hw[0], wl.src_hw[1],
+            # (the driver keeps the first 120 characters of this string: model, frames, G, C, beta, loss, GA and P come first)
+            "config": {"workload": "%s %df G=%d C=%d beta=%g loss=%s GA=%d P=%d grid=%s; GRPO micro-step, 1 prompt/GPU/step; "
+                                   "uint8 %dx%d frames -> fused resize/normalise/patchify inside the step%s"
+                                   % (cfg.name, args.frames, args.G, args.C, args.beta, "ppo-clip" if args.clip_loss else "grpo", args.ga, wl.P or 0,
+                                      str(wl.grid).replace(" ", ""), wl.src_hw[0], wl.src_hw[1],
                                       ("; fp8 (e4m3) weights for the SAMPLING policy only (fp8: %s; bf16: %s) - prefill, log-probs, KL and the update read bf16; advantage term weighted by "
                                        "the truncated importance ratio min(p_update / p_sampling, %g)"
                                        % (",".join(n for n in ("qkv", "o", "gu", "down", "lm_head") if n not in tr.core.roll.fp8_keep_bf16),

@@ -926,12 +926,13 @@ def test_gemm_nn(hip_ops, M, N, K):
     assert torch.equal(got, nt), "NN and NT forms accumulate in the same order"
 
 
+@pytest.mark.parametrize("shape", [(1024, 768, 640), (1000, 776, 704), (552, 264, 64)])
 @pytest.mark.parametrize("kmajor", [False, True])
-def test_weight_gradient_epilogue_also_writes_the_bf16_wire_copy(hip_ops, kmajor):
+def test_weight_gradient_epilogue_also_writes_the_bf16_wire_copy(hip_ops, kmajor, shape):
     """Round 5 (data-parallel per-rank tax): tr1_wgrad_f32_sumsq can also leave bf16(final gradient) in the gradient exchange's staging arena, so
     GradSync / ShardSync skip their 6-byte-per-parameter staging pass for the large matrices.  The wire copy equals gw.to(bf16) bit for bit (overwrite and
     accumulate, NT and K-major operand forms), gw and the sums of squares are unchanged."""
-    N, K, T = 1024, 768, 640
+    N, K, T = shape       # (the second and third shapes end in partial tiles in both directions: 224 / 256-row x 256-column blocks)
     dy = rnd(T, N, seed=1, scale=0.1).cuda()
     x = rnd(T, K, seed=2, scale=0.5).cuda()
     dyt = hip_ops.transpose(dy)
@@ -946,3 +947,5 @@ def test_weight_gradient_epilogue_also_writes_the_bf16_wire_copy(hip_ops, kmajor
         n2 = hip_ops.wgrad_sumsq(dyt, b, gw_b, acc, part, 0, b_kmajor=kmajor, b_rows=T, wire=wire)
         assert n1 == n2 and n1 > 0 and torch.equal(gw_a, gw_b) and torch.equal(s1, part[:n2])
         assert torch.equal(wire, gw_b.to(BF16)), "the wire copy must be the bf16 rounding of the stored gradient"
+        want = (gw0.double() if acc else 0.0) + dy.double().t() @ x.double()
+        close(gw_b.cpu(), want.float().cpu(), 0.02, rtol=0.02, what="wgrad with wire copy")

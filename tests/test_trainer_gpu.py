@@ -297,3 +297,53 @@ def test_grad_norm_sink_is_dropped_when_another_backward_follows_the_armed_one(h
     gn = float(tr.optimizer.step())
     assert not tr.optimizer.norm_from_sink, "a stale sink must not be used"
     assert abs(gn - want) < 2e-4 * want, (gn, want)
+
+
+@pytest.mark.parametrize("shard", [False, True])
+def test_wire_copies_from_the_weight_gradient_epilogues_equal_the_staged_gradient(hip_ops, shard, monkeypatch):
+    """in a data-parallel window the weight-gradient epilogues of the last micro-step write the bf16 wire copy of the large matrices and
+    GradSync / ShardSync stage only the gaps.  With a one-rank group (TR1_DIST_FORCE=1, torch.distributed "nccl" = RCCL) the exchanged arena must then
+    equal bf16(fp32 gradient) EVERYWHERE - a wrong or unwritten wire tile shows up as a mismatch inside a marked range."""
+    import torch.distributed as dist
+    from time_r1_amd.trainer import TimeR1_Trainer, GRPOConfig
+    from time_r1_amd import rewards as R
+    from time_r1_amd.config import tiny_test, TextConfig
+    from time_r1_amd.params import ModelParams
+    from oracle.text import FakeProcessor
+    monkeypatch.setenv("TR1_DIST_FORCE", "1")
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda:0"))
+    try:
+        cfg = tiny_test()
+        cfg.text = TextConfig(vocab_size=512, hidden=512, intermediate=1024, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, mrope_section=(16, 24, 24))
+        cfg.vision.out_hidden = 512
+        args = GRPOConfig(output_dir="/tmp/tr1_gpu_wire", num_generations=4, max_completion_length=8, beta=0.04, use_grpo=True, temperature=1.0,
+                          save_strategy="no", disable_log_print=True, gradient_accumulation_steps=2, shard_optimizer=shard)
+        tr = TimeR1_Trainer(ModelParams(cfg, hip_ops, seed=1), [R.format_reward], [], args=args, processing_class=FakeProcessor(cfg), ops=hip_ops)
+        assert tr.dp.enabled and tr.dp.world == 1
+        rows = []
+        for i in range(2):
+            frames = torch.randint(0, 256, (4, 3, 84, 112), generator=torch.Generator().manual_seed(3 + i), dtype=torch.uint8)
+            rows.append([{"problem": "event %d" % i, "video_path": "x.mp4", "video_frames": frames, "solution": (2.0, 12.0), "durations": 30.0}])
+        tr.accumulation_window(rows)
+        sync = tr.optimizer.sync
+        wired = sorted(sync.wired)
+        assert len(wired) >= 8, "the four large matrices of both layers come out of their epilogues in wire format: %r" % (wired,)
+        if shard:
+            sync.finish()
+        else:
+            sync.finish(copy_back=False)
+        torch.cuda.synchronize()
+        g = tr.params.train.grad
+        want = g.to(torch.bfloat16)
+        for lo, hi in wired:
+            assert float(g[lo:hi].abs().max()) > 0.0
+            assert torch.equal(sync.stage[lo:hi], want[lo:hi]), "wire copy written by the epilogue differs from bf16(gradient) in [%d, %d)" % (lo, hi)
+        assert torch.equal(sync.stage, want), "staged gaps + epilogue-written ranges must tile the whole arena"
+        if shard:
+            assert sync.gshard.numel() == want.numel() and torch.equal(sync.gshard, want.float()), "one rank: the reduce-scattered shard is the whole (bf16-rounded) gradient"
+    finally:
+        dist.destroy_process_group()

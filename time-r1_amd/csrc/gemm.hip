@@ -1988,6 +1988,11 @@ extern "C" int tr1_wgrad_f32_sumsq(const void* A, const void* B, void* C, int64_
     TR1_CHECK_ARG(M >= 512 && N >= 256, "wgrad_f32_sumsq: M >= 512 and N >= 256 required (smaller gradients: plain GEMM + tr1_sumsq_accum)");
     TR1_CHECK_ARG(!b_kmajor || (b_rows >= 1 && b_rows <= K), "wgrad_f32_sumsq: 1 <= b_rows <= K");
     TR1_CHECK_ARG(sumsq_partials && n_partials, "wgrad_f32_sumsq: partials buffer required");
+#if !TR1_EPI_LDS
+    // the sums of squares and the bf16 wire copy leave from the LDS-staged epilogue only (store_acc256_lds); a -DTR1_EPI_LDS=0 variant build must not
+    // pretend to have written them (the caller would mark the range as exchanged-ready and all-reduce stale bytes)
+    TR1_CHECK_ARG(false, "wgrad_f32_sumsq: built with TR1_EPI_LDS=0 - the sum-of-squares / wire-copy epilogue does not exist in this build");
+#endif
     hipStream_t s = (hipStream_t)stream;
     const int64_t t2n = (N + BN2 - 1) / BN2;
     int rt;

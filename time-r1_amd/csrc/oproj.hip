@@ -101,12 +101,17 @@ __global__ __launch_bounds__(OPJ_WAVES * 64) void oproj_frag_kernel(const bf16_t
     }
 }
 
+// per-device caches (a process normally drives ONE GPU, but tools / tests may touch more: the CU count and the raised dynamic-LDS limit belong to a device)
+static int opj_dev() { int dev = 0; return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? dev : 0; }
 static int opj_cols(int64_t N) {
-    static int cus = 0;
+    static int cus_of[16] = {0};
+    const int dev = opj_dev();
+    int cus = cus_of[dev];
     if (!cus) {
-        int dev = 0; hipDeviceProp_t pr;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+        hipDeviceProp_t pr;
+        cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
         if (cus <= 0) cus = 256;
+        cus_of[dev] = cus;
     }
     for (int c = (int)((N + cus - 1) / cus); c <= 16; ++c)
         if (c >= 1 && N % c == 0) return c;
@@ -131,13 +136,13 @@ extern "C" int tr1_gemm_oproj_frag(const void* Xfrag, const void* W, const void*
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N / cols));
     if (mg == 1) {
-        static bool a1 = false;
-        if (!a1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&oproj_frag_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); a1 = true; }
+        static bool a1[16] = {false};
+        if (!a1[opj_dev()]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&oproj_frag_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); a1[opj_dev()] = true; }
         hipLaunchKernelGGL((oproj_frag_kernel<1>), grid, dim3(OPJ_WAVES * 64), dyn, s, (const bf16_t*)Xfrag, (const bf16_t*)W, (const bf16_t*)residual, (bf16_t*)C, (int)M, N, K,
                            ldw, ldr, ldc, cols);
     } else {
-        static bool a2 = false;
-        if (!a2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&oproj_frag_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); a2 = true; }
+        static bool a2[16] = {false};
+        if (!a2[opj_dev()]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&oproj_frag_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); a2[opj_dev()] = true; }
         hipLaunchKernelGGL((oproj_frag_kernel<2>), grid, dim3(OPJ_WAVES * 64), dyn, s, (const bf16_t*)Xfrag, (const bf16_t*)W, (const bf16_t*)residual, (bf16_t*)C, (int)M, N, K,
                            ldw, ldr, ldc, cols);
     }

@@ -5,7 +5,6 @@ sequence -> loss gradient -> hand-written backward.  Restates the tensor algebra
 Host-side pieces that the reference also runs on the host (text decode, reward callbacks, group statistics on G floats)
 stay in trainer.py; everything with a FLOP count lives here and goes through ops (HIP kernels).
 """
-import os
 
 import numpy as np
 import torch

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--probe-fwd", action="store_true", help="needs TR1_HIP_LIB=tools/_probe_lib.so: s_memtime stamps of the heaviest forward block (tile top, after barrier, after S, after softmax, after PV, end)")
     ap.add_argument("--probe", action="store_true", help="needs TR1_HIP_LIB=tools/_probe_lib.so: dump the s_memtime stamps of one dK/dV block")
+    ap.add_argument("--yardstick", action="store_true", help="also time torch's scaled_dot_product_attention (vendor flash backend) fwd / bwd on the same head geometry")
     ap.add_argument("--P", type=int, default=3474)
     ap.add_argument("--G", type=int, default=8)
     ap.add_argument("--C", type=int, default=200)
@@ -62,6 +63,36 @@ def main():
     t_b = timed(lambda: ops.attn_bwd(q, k, v, o, do, lse, pre, lo, hi, H, NKV, M, HD, scale))
     out["fwd_ms"], out["fwd_TFLOPs_visible"] = round(t_f, 4), round(fl_fwd / t_f / 1e9, 1)
     out["bwd_ms"], out["bwd_TFLOPs_2p5x"] = round(t_b, 4), round(2.5 * fl_fwd / t_b / 1e9, 1)
+    if a.yardstick:
+        # Vendor yardstick (checker only, never product): torch's scaled_dot_product_attention (the ROCm flash backend) on the same head geometry.
+        # (a) one causal sequence of M tokens (the packed call's nearest dense-mask relative: rate compared in TFLOP/s over VISIBLE pairs);
+        # (b) what the reference executes for this step: G sequences of P + C tokens, causal (flash_attn_varlen semantics, the prefix G times).
+        import torch.nn.functional as F
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        ys = {}
+        for name, B, L in (("causal_1xM", 1, M), ("reference_GxPC", a.G, a.P + a.C)):
+            qy = torch.randn(B, H, L, HD, generator=g, device="cuda").to(BF16).requires_grad_(True)
+            ky = torch.randn(B, NKV, L, HD, generator=g, device="cuda").to(BF16).requires_grad_(True)
+            vy = torch.randn(B, NKV, L, HD, generator=g, device="cuda").to(BF16).requires_grad_(True)
+            doy = (torch.randn(B, H, L, HD, generator=g, device="cuda") * 0.1).to(BF16)
+            fl = 4.0 * B * (L * (L + 1) / 2) * HD * H
+            for backend in ("FLASH_ATTENTION", "EFFICIENT_ATTENTION"):
+                try:
+                    with sdpa_kernel(getattr(SDPBackend, backend)):
+                        fwd = lambda: F.scaled_dot_product_attention(qy, ky, vy, is_causal=True, enable_gqa=True)
+                        with torch.no_grad():
+                            t_fy = timed(fwd)
+
+                        def fb():
+                            o_ = fwd()
+                            o_.backward(doy)
+                            qy.grad = ky.grad = vy.grad = None
+                        t_fb = timed(fb)
+                    ys["%s/%s" % (name, backend)] = dict(fwd_ms=round(t_fy, 4), fwd_TFLOPs_visible=round(fl / t_fy / 1e9, 1), bwd_ms=round(t_fb - t_fy, 4),
+                                                         bwd_TFLOPs_2p5x=round(2.5 * fl / max(t_fb - t_fy, 1e-6) / 1e9, 1))
+                except Exception as e:      # a backend that refuses the shape is part of the answer
+                    ys["%s/%s" % (name, backend)] = "unavailable: %s" % (str(e).splitlines()[0][:160],)
+        out["yardstick_sdpa"] = ys
     if not a.no_check:
         T, S = M, M
         kvi = torch.arange(S, device="cuda")[None, :]
