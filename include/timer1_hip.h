@@ -57,7 +57,8 @@ int tr1_gemm_bias_quickgelu_bf16(const void* x, const void* W, const void* bias,
 int tr1_gemm_qkv_rope_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q_out, int64_t ldq, void* k_out, int64_t ldk, void* v_out, int64_t ldv, int64_t M, int64_t n_heads, int64_t n_kv, int64_t head_dim, int64_t K, int64_t ldx, int64_t ldw, void* stream);
 /* tr1_gemm_qkv_rope_vit_bf16: the vision blocks' q|k|v projection + bias + 2-D rotary embedding (TF:225-248 apply_rotary_pos_emb_vision inside VisionAttention
  *   TF:322-360; Qwen2.5-VL modeling_qwen2_5_vl.py:160-230) for head dim 2 * half = 80, written as 128-wide zero-padded heads (d < half at column d, d + half at
- *   64 + d; the caller zero-fills q128 / k128 / v128 once) so that the head-dim-128 attention kernel (tr1_attn_fwd_rows) runs the tower.  cos / sin fp32 [M, half]. */
+ *   48 + d when half <= 48 - 64 + d otherwise; the caller zero-fills q128 / k128 / v128 once) so that the head-dim-128 attention kernel runs the tower
+ *   (tr1_attn_fwd_rows_live96 when half <= 48: every head's live features end at 96).  cos / sin fp32 [M, half]. */
 int tr1_gemm_qkv_rope_vit_bf16(const void* x, const void* Wqkv, const void* bias, const void* cosb, const void* sinb, void* q128, int64_t ldq, void* k128, int64_t ldk, void* v128, int64_t ldv, int64_t M, int64_t n_heads, int64_t half, int64_t K, int64_t ldx, int64_t ldw, void* stream);
 /* tr1_gemm_nn_glubwd_bf16: dgu[M, 2I] = SwiGLU backward of da = dh[M, H] Wd[H, I] (the down projection as stored) with the saved gu[M, 2I]; da is never
  *   written (autograd of TF:459-466 under accelerator.backward, src/time_r1/rl/timer1_trainer.py:709-737).  dgu_t (optional): the same values once more as
@@ -69,7 +70,10 @@ int tr1_gemm_nn_glubwd_bf16(const void* dh, const void* Wd, const void* gu, void
 int tr1_gemm_nn_acc_f32(const void* A, const void* B, void* C_f32, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int accumulate, int64_t b_rows, void* stream);
 /* Decode-step fusion (M <= 64 rows): out = rmsnorm(x; lnw, eps) @ W[N,K]^T (+ bias), the norm folded into the GEMM's operand load
  * (ref: input_layernorm -> q/k/v_proj TF:559-580 and post_attention_layernorm -> gate/up_proj TF:600-610 inside generate).
- * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate. */
+ * glu != 0: W is [2N, K] (gate rows, then up rows) and out[M, N] = silu(gate) * up (Qwen2MLP TF:459-466) - no [M, 2N] intermediate.
+ * glu == 2 (M <= 16, tr1_norm_gemm_glu_frag_ok): the same values leave FRAGMENT-MAJOR - element (m, n) at (n / 32) * 512 + m * 32 + n % 32 of `out`
+ * (16 x N bf16) - the operand layout of tr1_gemm_oproj_frag, which then runs the down projection with its whole weight slice in flight (2B shapes). */
+int tr1_norm_gemm_glu_frag_ok(int64_t M, int64_t N, int64_t K);
 int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream);
 /* Decode rows: input_layernorm -> fused q/k/v projection -> M-RoPE -> KV-cache append in ONE launch (tr1_norm_gemm_skinny + tr1_decode_qkv_post):
  * roped q -> q_out[M, n_heads*hd]; roped k -> kcache[slots[m], :]; v -> vtcache[:, slots[m]].  Wqkv: [(n_heads + 2 n_kv)*hd, K] (q | k | v rows).
@@ -141,6 +145,10 @@ int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, 
  * timer1_trainer.py:452-457, attn_implementation=flash_attention_2 in scripts/posttrain/train_rl.sh:33) need no V^T copy.  Same results as
  * tr1_attn_fwd up to the order of the fp32 accumulation. */
 int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
+/* tr1_attn_fwd_rows for 128-wide heads whose features 96..127 are ZERO in Q, K and V (the vision towers' head dim 80 in the padded layout of
+ * tr1_gemm_qkv_rope_vit_bf16): 12 + 12 instead of 16 + 16 MFMAs per wave and key tile; O columns 96..127 of every head are not written (the caller keeps them
+ * zero).  ref: VisionAttention.forward TF:379-396 / Qwen2.5-VL's windowed form, frozen towers (src/time_r1/rl/timer1_trainer.py:264-269). */
+int tr1_attn_fwd_rows_live96(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
 /* Split-KV decode over the layers of ONE decode step (same pre/lo/hi in every layer of model.generate's step, timer1_trainer.py:568-573): the
  * launch with plan_mode 1 publishes each query tile's relevant-tile list in `plan` (int32[tr1_attn_plan_ints()]), launches with plan_mode 2 start
  * from it instead of reducing the masks again; plan_mode 0 (plan may be NULL) is tr1_attn_fwd.  Results are bit-identical in all three modes. */
@@ -151,7 +159,10 @@ int tr1_attn_fwd_planned(const void* Q, int64_t q_ld, const void* K, int64_t k_l
 int tr1_attn_fwd_planned_frag(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* VT, int64_t vt_ld, void* Ofrag, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, int64_t nsplit, void* ws_f32, int64_t ws_floats, int64_t n_batch, int64_t kv_batch_slots, void* plan, int plan_mode, void* stream);
 /* Decode rows (M <= 32): C[M, N] = X @ W[N, K]^T (+ residual) with X fragment-major (layout above, K = n_heads * 128 <= 3584): every block keeps its whole
  * weight slice in flight (HBM -> LDS DMA) and owns its columns over the whole K - no split-K fixup (csrc/oproj.hip).  tr1_gemm_oproj_frag_ok: shape covered?
- * ref: o_proj of Qwen2VLAttention.forward (TF:553-556) inside model.generate (src/time_r1/rl/timer1_trainer.py:568-578). */
+ * Round 6: also K <= 9216 at M <= 16 when a block's columns (N / 256 rounded up to a divisor of N, <= 8) fit 152 KB of LDS over the whole K - the
+ * Qwen2-VL-2B down projection (1536 x 8960: 6 columns x 256 blocks), fed by tr1_norm_gemm_skinny(glu = 2).
+ * ref: o_proj of Qwen2VLAttention.forward (TF:553-556) and down_proj of Qwen2MLP.forward (TF:459-466) inside model.generate
+ * (src/time_r1/rl/timer1_trainer.py:568-578). */
 int tr1_gemm_oproj_frag(const void* Xfrag, const void* W, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t ldw, int64_t ldr, int64_t ldc, void* stream);
 int tr1_gemm_oproj_frag_ok(int64_t M, int64_t N, int64_t K);
 int64_t tr1_attn_plan_ints(int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_batch);
@@ -260,19 +271,11 @@ int tr1_sumsq_ranges_periodic(const void* g_f32, int64_t base, int64_t stride, i
 int tr1_zero_ranges_periodic(void* g_f32, int64_t base, int64_t stride, int64_t count, const int64_t* rel_ranges, int64_t n_ranges, void* stream);
 int tr1_sumsq_accum_bf16(const void* g_bf16, int64_t n, void* out_scalar, void* stream);
 
-/* ---- RCCL collectives over xGMI (rccl_{init, allreduce, reduce_scatter, allgather}) ------------------------------------------------ */
-/* The data-parallel exchange for a host that binds this library directly (time-r1_amd/dist.py reaches the same librccl through torch.distributed "nccl").
- * ref: `torchrun --nproc_per_node=8` + DeepSpeed ZeRO buckets (scripts/finetune/run_activitynet.sh:11, scripts/zero3.json:22-33) and
- * accelerator.gather_for_metrics (src/time_r1/rl/timer1_trainer.py:741-777).  One process per GPU, device selected before tr1_rccl_init; every collective
- * is asynchronous on `stream` and a SUM.  dtype: 0 = bf16 (gradient wire format), 1 = fp32, 2 = int32.  librccl.so is dlopen'ed on first use
- * (TR1_RCCL_LIB overrides the name).  Errors: 1000 = argument / load failure, 2000 + ncclResult_t otherwise. */
-int64_t tr1_rccl_version(void);
-int tr1_rccl_unique_id(void* id_out_128);                                   /* HOST pointer, 128 bytes; rank 0 creates it, the launcher distributes it */
-int tr1_rccl_init(const void* id_128, int64_t world, int64_t rank, void* comm_out);     /* comm_out: HOST slot receiving the communicator (one pointer) */
-int tr1_rccl_destroy(void* comm);
-int tr1_rccl_allreduce(void* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
-int tr1_rccl_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype, void* stream);
-int tr1_rccl_allgather(void* comm, const void* send, void* recv, int64_t send_count, int dtype, void* stream);
+/* ---- Collectives (rccl_{init, allreduce, reduce_scatter, allgather}) ------------------------------------------------------------------
+ * There is ONE exchange path: time-r1_amd/dist.py drives RCCL through torch.distributed's "nccl" backend (which IS librccl on ROCm): per-segment
+ * all-reduce (GradSync) or reduce-scatter + all-gather (ShardSync) of the bf16 wire arena, overlapped with the backward.  The round-4/5
+ * tr1_rccl_* entry points duplicated that binding without a caller in the product and were removed in round 6; a native host links librccl directly
+ * (ncclCommInitRank / ncclAllReduce / ncclReduceScatter / ncclAllGather on the stream it hands to the tr1_* kernels) - see INTEGRATION.md 2c. */
 
 #ifdef __cplusplus
 }

@@ -287,7 +287,7 @@ def test_gemm_qkv_rope_fused_epilogue(hip_ops, ref_ops, M, nh, nkv, K, row0):
 
 @pytest.mark.parametrize("M,H,K", [(1000, 16, 1280), (300, 16, 128), (5074, 32, 64)])
 def test_gemm_qkv_rope_vit_padded_heads(hip_ops, ref_ops, M, H, K):
-    """Vision q|k|v projection + bias + 2-D rotary embedding written as 128-wide zero-padded heads (csrc/gemm.hip EPI 7): d < 40 at column d, d + 40 at 64 + d.
+    """Vision q|k|v projection + bias + 2-D rotary embedding written as 128-wide zero-padded heads (csrc/gemm.hip EPI 7): d < 40 at column d, d + 40 at 48 + d (round 6: live features end at 96).
     Bit-identical to GEMM + rope_apply(head dim 80) scattered into that layout; pad columns untouched (zero)."""
     hd, half = 80, 40
     E = H * hd
@@ -304,8 +304,8 @@ def test_gemm_qkv_rope_vit_padded_heads(hip_ops, ref_ops, M, H, K):
         v = qkv[:, 2 * E:]
     for got, want, nm in ((q128, q, "q"), (k128, k, "k"), (v128, v, "v")):
         g3, w3 = got.view(M, H, 128), want.reshape(M, H, hd)
-        assert torch.equal(g3[:, :, :half], w3[:, :, :half]) and torch.equal(g3[:, :, 64:64 + half], w3[:, :, half:]), nm
-        assert float(g3[:, :, half:64].abs().max()) == 0.0 and float(g3[:, :, 64 + half:].abs().max()) == 0.0, nm + " pad columns"
+        assert torch.equal(g3[:, :, :half], w3[:, :, :half]) and torch.equal(g3[:, :, 48:48 + half], w3[:, :, half:]), nm
+        assert float(g3[:, :, half:48].abs().max()) == 0.0 and float(g3[:, :, 48 + half:].abs().max()) == 0.0, nm + " pad columns"
     qr = ref_ops.rope_apply(ref_ops.gemm_nt(x.float(), w.float(), bias=b.float())[:, :E], H, hd, cos, sin)
     close(q128.view(M, H, 128)[:, :, :half], qr.view(M, H, hd)[:, :, :half], 0.02 * math.sqrt(K) * 0.1 + 0.03, rtol=3e-2, what="q vs oracle")
 
@@ -400,6 +400,15 @@ def test_attention_fwd_bwd(hip_ops, ref_ops, name, nh, nkv, hd, m):
         close(lse_w, lse_r, 2e-3, rtol=1e-3, what=name + " lse (row-major V kernel)")
         close(o_w, o_h.float().cpu(), 0.02, what=name + " O rows vs V^T kernel")
         close(lse_w, lse_h.float().cpu(), 2e-3, rtol=1e-3, what=name + " lse rows vs V^T kernel")
+        # round 6: the live-96 launch (the vision towers' padded heads: features 96..127 of q / k / v are zero) computes the SAME bits in columns 0..95 of every
+        # head with three quarters of the MFMAs (skipped products are exact zeros) and leaves columns 96..127 of the output alone
+        z = lambda t, n: (t.view(-1, n, hd) * (torch.arange(hd) < 96).to(t.dtype)).reshape(t.shape[0], n * hd).cuda()
+        q6, k6, v6 = z(q, nh), z(k, nkv), z(v, nkv)
+        o_full, lse_full = hip_ops.attn_fwd(q6, k6, None, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, scale, v_rows=v6)
+        o_96 = torch.full((T, nh * hd), 7.0, dtype=BF16, device="cuda")
+        _, lse_96 = hip_ops.attn_fwd(q6, k6, None, pre.cuda(), lo.cuda(), hi.cuda(), nh, nkv, S, hd, scale, v_rows=v6, out=o_96, live96=True)
+        assert torch.equal(o_96.view(T, nh, hd)[:, :, :96], o_full.view(T, nh, hd)[:, :, :96]) and torch.equal(lse_96, lse_full), name + " live-96 launch"
+        assert bool((o_96.view(T, nh, hd)[:, :, 96:] == 7.0).all()), name + " live-96 launch wrote beyond column 96"
     # backward (uses the oracle's O / lse so that only the backward kernels are under test)
     dq_h, dk_h, dv_h = hip_ops.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o_r.to(BF16).cuda(), do.cuda(), lse_r.cuda(), pre.cuda(), lo.cuda(),
                                         hi.cuda(), nh, nkv, S, hd, scale)
@@ -741,6 +750,29 @@ def test_decode_o_projection_on_fragment_major_attention_rows(hip_ops, B, G, nh,
         c = hip_ops.gemm_oproj_frag(of, w, M, residual=res)
         ref = o_ref.double() @ w.double().t() + (res.double() if res is not None else 0.0)
         close(c, ref.float().cpu(), 0.02, rtol=0.02, what="o projection on fragment-major rows, rep %d" % rep)
+
+
+@pytest.mark.parametrize("M,H,I", [(16, 1536, 8960), (9, 1536, 8960), (16, 2048, 5632), (1, 1536, 8960)])
+def test_decode_down_projection_on_the_fragment_major_swiglu_output(hip_ops, M, H, I):
+    """Round 6 (Qwen2-VL-2B shapes): tr1_norm_gemm_skinny(glu = 2) writes silu(gate) * up fragment-major ([I / 32][16 rows][32 columns]) and the down projection runs on
+    csrc/oproj.hip's long-K form (<= 8 columns per block, the block's weight slice over the WHOLE K in flight, no split-K fixup).  The fragment-major values are the bits of the
+    row-major launch; the projection agrees with a float64 product and with the split-K + fixup kernel it replaces (another summation order: bf16 rounding apart)."""
+    x = rnd(M, H, seed=1).cuda()
+    lnw = (1.0 + 0.1 * rnd(H, seed=2).float()).to(BF16).cuda()
+    wgu = rnd(2 * I, H, seed=3, scale=1.0 / math.sqrt(H)).cuda()
+    wd = rnd(H, I, seed=4, scale=1.0 / math.sqrt(I)).cuda()
+    res = rnd(M, H, seed=5).cuda()
+    assert hip_ops.L.raw("tr1_gemm_oproj_frag_ok")(M, H, I) and hip_ops.L.raw("tr1_norm_gemm_glu_frag_ok")(M, I, H)
+    a_row = hip_ops.norm_gemm(x, lnw, 1e-6, wgu, glu=True)
+    for rep in range(3):      # (the first launch of a fresh process once read LDS stages before their DMA had landed: repeat)
+        a_frag = hip_ops.norm_gemm(x, lnw, 1e-6, wgu, glu=2)
+        back = a_frag.view(I // 32, 16, 32).permute(1, 0, 2).reshape(16, I)[:M]
+        assert torch.equal(back, a_row), "fragment-major SwiGLU output differs from the row-major launch (rep %d)" % rep
+        c = hip_ops.gemm_oproj_frag(a_frag, wd, M, residual=res)
+        ref = a_row.double() @ wd.double().t() + res.double()
+        close(c, ref.float().cpu(), 0.02, rtol=0.02, what="down projection on the fragment-major SwiGLU output, rep %d" % rep)
+    old = hip_ops.gemm_skinny_fixup(a_row, wd, residual=res)
+    close(c, old.cpu(), 0.05, rtol=0.03, what="long-K form vs split-K + fixup form")
 
 
 def test_attention_decode_plan_fallback_when_the_list_is_too_long_for_a_reader_block(hip_ops, ref_ops):

@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(NP * 128) void attn_bwd_dkdv32_kernel(AttnParams p,
 __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const float* __restrict__ lse2) {
     constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE;
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][K rows | V rows] + block mask summary
-    int* lds_meta = reinterpret_cast<int*>(dyn_lds + NB * BUF);      // [8][3]
+    int* lds_meta = reinterpret_cast<int*>(dyn_lds + NB * BUF);      // [8][6]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c32 = lane & 31, h = lane >> 5;
     const int kvh = blockIdx.y;
     const unsigned nR = (unsigned)p.T * (unsigned)p.group;
@@ -1213,8 +1213,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
     att_split_row(p, valid ? R : nR - 1, tq, hq);
     const int pre = valid ? p.pre[tq] : 0, lo = valid ? p.lo[tq] : 1, hi = valid ? p.hi[tq] : 0;
     const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + tq;
-    const float lse = valid ? lse2[si] : INFINITY;                    // log2-scaled; +inf (no visible key / padding row) -> P = 0
-    const float dlt = valid ? p.delta[si] : 0.f;
+    const bool fused_delta = p.lse2_out != nullptr;                   // wave-uniform (kernel argument)
+    float lse = INFINITY, dlt = 0.f;                                  // log2-scaled LSE; +inf (no visible key / padding row) -> P = 0
+    if (!fused_delta) { lse = valid ? lse2[si] : INFINITY; dlt = valid ? p.delta[si] : 0.f; }
     // wave summary of the masks: which tiles every row of the wave sees completely, which it sees at all
     int wmaxpre = valid ? pre : 0, wminpre = valid ? pre : 0x7fffffff;
     int wminlo = (valid && hi >= lo) ? lo : 0x7fffffff, wmaxhi = (valid && hi >= lo) ? hi : -1;
@@ -1231,7 +1232,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
     // (rows past nR - the padding of the last block - never force the masked path: they compute finite garbage that is not stored.  With an
     //  `all 32 rows valid` term in `full`, the ONE partially valid wave of the heaviest block took the per-element mask path on every tile:
     //  3 900 instead of 1 200 cycles of softmax, all other waves waiting for it at the barrier - wave timeline in DESIGN.md)
-    if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
+    if (lane == 0) {
+        lds_meta[wave * 6 + 0] = wmaxpre; lds_meta[wave * 6 + 1] = wminlo; lds_meta[wave * 6 + 2] = wmaxhi;
+        lds_meta[wave * 6 + 3] = wminpre; lds_meta[wave * 6 + 4] = wmaxlo; lds_meta[wave * 6 + 5] = wminhi;
+    }
     // stationary B fragments: Q / dO row of this lane, features ks*16 + h*8 .. +7
     bf16x8_t qf[D / 16], dof[D / 16];
     {
@@ -1240,6 +1244,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
         const bf16_t* drow = p.dO + (int64_t)tq * p.do_ld + hoff;
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) { qf[ks] = load_row_frag(qrow, ks * 16 + h * 8, D, valid); dof[ks] = load_row_frag(drow, ks * 16 + h * 8, D, valid); }
+        if (fused_delta) {
+            // what attn_delta_kernel computed for this row: delta = sum_d dO[d] O[d] (the lane's 64 features + its partner lane's), the log2-scaled LSE;
+            // both also go to global memory for the dK/dV kernel that follows on the stream
+            const bf16_t* orow = p.O + (int64_t)tq * p.o_ld + hoff;
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                const u32x4_t x = __builtin_bit_cast(u32x4_t, dof[ks]), y = __builtin_bit_cast(u32x4_t, load_row_frag(orow, ks * 16 + h * 8, D, valid));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += bflo(x[j]) * bflo(y[j]) + bfhi(x[j]) * bfhi(y[j]);
+            }
+            s += __shfl_xor(s, 32, 64);
+            const float l0 = valid ? p.lse[si] : NEG_INF;
+            lse = (l0 == NEG_INF) ? INFINITY : l0 * 1.4426950408889634f;
+            dlt = valid ? s : 0.f;
+            if (valid && h == 0) { p.delta[si] = dlt; p.lse2_out[si] = lse; }
+        }
     }
     f32x16_t acc[4];                                                  // dQ^T[feature block][C layout]
 #pragma unroll
@@ -1253,9 +1274,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
     __syncthreads();
     int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 3]); bminlo = min(bminlo, lds_meta[w * 3 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 3 + 2]); }
+    for (int w = 0; w < 8; ++w) { bmaxpre = max(bmaxpre, lds_meta[w * 6]); bminlo = min(bminlo, lds_meta[w * 6 + 1]); bmaxhi = max(bmaxhi, lds_meta[w * 6 + 2]); }
     const TileRange tr = att_tile_range(bmaxpre, bminlo, bmaxhi, p.n_slots);
     const int n_my = tr.n_rel;
+    if (p.qmeta_out && kvh == 0 && (wave & 1) == 0 && lane < 6) {
+        // the mask summary of 64-row tile (this wave's 32 rows + the next wave's): attn_qmeta_tile's six values (max pre, min lo, max hi, min pre, max lo, min hi)
+        const unsigned tile = Rw0 >> 6;
+        if (tile * 64u < nR) {
+            const int a = lds_meta[wave * 6 + lane], b = lds_meta[(wave + 1) * 6 + lane];
+            const bool is_max = lane == 0 || lane == 2 || lane == 4;
+            p.qmeta_out[tile * ATT_QMETA + lane] = is_max ? max(a, b) : min(a, b);
+        }
+    }
 
     // ---- DMA of one key tile (K rows + V rows): 4 instructions per wave, 32-bit byte offsets from uniform bases
     const unsigned lds_base = (unsigned)(uintptr_t)(att_lptr_t)dyn_lds;
@@ -1472,6 +1502,12 @@ static int dkdv_qsplit(int64_t T, int group, int n_kv, int64_t n_slots, int kb) 
     return (int)qs;
 }
 
+// both head-dim-128 kernels on the 32x32x16 forms (32-bit DMA byte offsets fit): the dQ kernel's prologue then also does attn_delta_kernel's work (round 6)
+static bool bwd32_both(const AttnParams& p) {
+    return p.d_real == 128 && (uint64_t)p.n_slots * (uint64_t)(p.k_ld > p.v_ld ? p.k_ld : p.v_ld) * 2ull < 0xffffffffull &&
+           (uint64_t)p.T * (uint64_t)(p.q_ld > p.do_ld ? p.q_ld : p.do_ld) * 2ull < 0xffffffffull;
+}
+
 template <int D>
 static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_floats, const float* lse2) {
     const int64_t nR = (int64_t)p.T * p.group;
@@ -1488,7 +1524,7 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
         attr_set = true;
     }
     // head dim 128: the 32x32x16-MFMA dQ kernel (round 3)
-    const size_t dyn_dq32 = 4 * (2 * 64 * 256) + 128;
+    const size_t dyn_dq32 = 4 * (2 * 64 * 256) + 256;
     static bool dq32_attr = false;
     if (D == 128 && !dq32_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq32); dq32_attr = true; }
     const bool use_dq32 = D == 128 && p.d_real == 128 && lse2 != nullptr &&
@@ -1593,6 +1629,11 @@ static int attn_bwd_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_l
     const int n_qtiles = (int)((T * p.group + 63) / 64);
     float* lse2 = (float*)delta + T * n_heads;                                   // second half of the delta scratch: log2-scaled LSE
     const unsigned delta_blocks = (unsigned)((T * n_heads + 15) / 16);          // >= 4 * n_qtiles (n_heads >= group)
+    static int fuse_delta = -1;                                                  // TR1_BWD_FUSE_DELTA=0: the separate attn_delta_kernel launch (A/B measurements)
+    if (fuse_delta < 0) { const char* e = getenv("TR1_BWD_FUSE_DELTA"); fuse_delta = e ? atoi(e) : 1; }
+    if (fuse_delta && d_pad == 128 && bwd32_both(p)) {
+        p.O = (bf16_t*)const_cast<void*>(O); p.o_ld = o_ld; p.lse2_out = lse2; p.qmeta_out = (int*)qmeta_ws;      // delta, lse2 and qmeta come out of the dQ kernel's prologue
+    } else
     hipLaunchKernelGGL(attn_delta_kernel, dim3(delta_blocks > (unsigned)n_qtiles ? delta_blocks : (unsigned)n_qtiles), dim3(256), 0, s,
                        (const bf16_t*)dO, do_ld, (const bf16_t*)O, o_ld, (float*)delta, (int)T, (int)n_heads, (int)head_dim, p.pre, p.lo, p.hi,
                        (int*)qmeta_ws, p.group, n_qtiles, (const float*)lse, lse2);

@@ -55,6 +55,10 @@ struct AttnParams {
     // backward only: when set, dQ and dK leave the kernels already multiplied by the TRANSPOSED rotary matrix (the backward of M-RoPE, TF:212-222):
     // fp32 cos / sin tables [T, d / 2]; row t of dQ and slot t of dK use row t
     const float* rope_cos; const float* rope_sin;
+    // backward at head dim 128 (round 6): the dQ kernel's prologue also produces what attn_delta_kernel did - delta = rowsum(dO o O) and the log2-scaled LSE
+    // of its own rows (it holds the dO row in registers already) and the per-64-row mask summary `qmeta` the dK/dV kernel skips tiles with - so that launch is gone.
+    // lse2_out / qmeta_out: where to store them (null: the separate kernel ran and `delta` / lse2 / `qmeta` are inputs)
+    float* lse2_out; int* qmeta_out;
 };
 
 #define ATT_KV 64          // keys per tile

@@ -44,8 +44,13 @@ extern "C" int probe_fwd_set_ptr(void* ptr) { return (int)hipMemcpyToSymbol(HIP_
 #ifndef FWD_LAZY_MAX
 #define FWD_LAZY_MAX 6      // log2 units; 0 = rescale whenever a row's maximum moves (round-3 behaviour)
 #endif
+// KS = k-steps (16 features each) of the S product that can be non-zero, NDB = KS / 2 = 32-feature blocks of O that are computed and stored.  KS = 8: head dim 128.
+// KS = 6 (round 6, the vision towers' head dim 80 on 128-wide zero-padded heads, features d < 40 at d and d + 40 at 48 + d): features 96..127 of Q / K / V are zero
+// by construction, so 12 + 12 of the 16 + 16 MFMAs of a tile (and the matching LDS fragment reads) carry everything; O columns 96..127 are not written.
+template <int KS>
 __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
-    constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE;
+    constexpr int D = 128, NB = 4, TILE = 64 * 256, BUF = 2 * TILE, NDB = KS / 2;
+    static_assert(KS == 8 || KS == 6, "k-steps");
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];  // [NB][K rows | V rows] + block mask summary
     int* lds_meta = reinterpret_cast<int*>(dyn_lds + NB * BUF);      // [8][3]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c32 = lane & 31, h = lane >> 5;
@@ -87,20 +92,20 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     //  `all 32 rows valid` term in `full`, the ONE partially valid wave of the heaviest block took the per-element mask path on every tile:
     //  3 900 instead of 1 200 cycles of softmax, all other waves waiting for it at the barrier - wave timeline in DESIGN.md)
     if (lane == 0) { lds_meta[wave * 3 + 0] = wmaxpre; lds_meta[wave * 3 + 1] = wminlo; lds_meta[wave * 3 + 2] = wmaxhi; }
-    bf16x8_t qf[D / 16];                                              // Q row of this lane, features ks*16 + h*8 .. +7 (B operand)
+    bf16x8_t qf[KS];                                                  // Q row of this lane, features ks*16 + h*8 .. +7 (B operand)
     {
         const bf16_t* qrow = p.Q + (int64_t)tq * p.q_ld + (int64_t)(kvh * p.group + hq) * D;
 #pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) qf[ks] = load_row_frag(qrow, ks * 16 + h * 8, D, valid);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = load_row_frag(qrow, ks * 16 + h * 8, D, valid);
     }
-    f32x16_t acc[4];                                                  // O^T[feature block][C layout]
+    f32x16_t acc[NDB];                                                // O^T[feature block][C layout]
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
     float m = NEG_INF, l = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) asm volatile("" ::"v"(qf[ks]));        // hipcc places the wait for the Q loads here (see attn_bwd.hip)
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));            // hipcc places the wait for the Q loads here (see attn_bwd.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int bmaxpre = 0, bminlo = 0x7fffffff, bmaxhi = -1;
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
 #pragma unroll
                 for (int ks = 0; ks < AH; ++ks) { k0[ks] = LDS_B128(xa ^ (ks * 32)); k1[ks] = LDS_B128((xa ^ (ks * 32)) + 8192); }
 #pragma unroll
-                for (int ks = 0; ks < D / 16; ++ks) {
-                    if (ks + AH < D / 16) { k0[(ks + AH) % (AH + 1)] = LDS_B128(xa ^ ((ks + AH) * 32)); k1[(ks + AH) % (AH + 1)] = LDS_B128((xa ^ ((ks + AH) * 32)) + 8192); }
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + AH < KS) { k0[(ks + AH) % (AH + 1)] = LDS_B128(xa ^ ((ks + AH) * 32)); k1[(ks + AH) % (AH + 1)] = LDS_B128((xa ^ ((ks + AH) * 32)) + 8192); }
 #if !(TR1_ABL & 4)
                     cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0[ks % (AH + 1)], qf[ks], cs[0], 0, 0, 0);
                     cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1[ks % (AH + 1)], qf[ks], cs[1], 0, 0, 0);
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             l = l * alpha + rs; m = m_new;
             if (!__all(alpha == 1.0f)) {      // exact: the running maximum did not move for any row of the wave -> no rescale needed
 #pragma unroll
-                for (int db = 0; db < 4; ++db)
+                for (int db = 0; db < NDB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
             }
@@ -245,17 +250,17 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             const unsigned ya = kb_ + TILE + t_lane;
             constexpr int TH = FWD_TH;
             bf16x8_t a[TH + 1];
-#define P2_LD(n) make_frag(LDS_TR16((ya ^ (((n) & 3) * 64)) + ((n) >> 2) * 4096), LDS_TR16((ya ^ (((n) & 3) * 64 + 32)) + ((n) >> 2) * 4096 + 2048))
+#define P2_LD(n) make_frag(LDS_TR16((ya ^ (((n) % NDB) * 64)) + ((n) / NDB) * 4096), LDS_TR16((ya ^ (((n) % NDB) * 64 + 32)) + ((n) / NDB) * 4096 + 2048))
 #pragma unroll
             for (int n = 0; n < TH; ++n) a[n] = P2_LD(n);
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {                            // n = chunk (16 keys) * 4 + feature block
-                if (n + TH < 16) a[(n + TH) % (TH + 1)] = P2_LD(n + TH);
-                const bf16x8_t f = pack8(cs[n >> 3], ((n >> 2) & 1) * 8);
+            for (int n = 0; n < 4 * NDB; ++n) {                       // n = chunk (16 keys) * NDB + feature block
+                if (n + TH < 4 * NDB) a[(n + TH) % (TH + 1)] = P2_LD(n + TH);
+                const bf16x8_t f = pack8(cs[(n / NDB) >> 1], ((n / NDB) & 1) * 8);
 #if !(TR1_ABL & 2)
-                acc[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n % (TH + 1)], f, acc[n & 3], 0, 0, 0);
+                acc[n % NDB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n % (TH + 1)], f, acc[n % NDB], 0, 0, 0);
 #else
-                acc[n & 3][n] += bf2f((bf16_t)a[n % (TH + 1)][0]) * bf2f((bf16_t)f[0]);
+                acc[n % NDB][n] += bf2f((bf16_t)a[n % (TH + 1)][0]) * bf2f((bf16_t)f[0]);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
         bf16_t* row = p.O + (int64_t)t2 * p.o_ld + (int64_t)(kvh * p.group + hq2) * D;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const u32x2_t w = {pack2bf(acc[db][4 * i] * inv, acc[db][4 * i + 1] * inv), pack2bf(acc[db][4 * i + 2] * inv, acc[db][4 * i + 3] * inv)};
@@ -626,9 +631,9 @@ int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s) {
 }
 
 // Q/O: [T, n_heads*128]; K, V: [n_slots, n_kv*128] row-major (any leading dims that are multiples of 8); lse (optional): fp32 [n_heads, T].
-extern "C" int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse,
-                                 const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots,
-                                 int64_t head_dim, float scale, void* stream) {
+static int attn_fwd_rows_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse,
+                              const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots,
+                              int64_t head_dim, float scale, int live96, void* stream) {
     AttnParams p; memset(&p, 0, sizeof(p));
     TR1_CHECK_ARG(head_dim == 128, "attention forward (row-major K / V form): head dim must be 128");
     TR1_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "attention: n_heads must be a multiple of n_kv");
@@ -651,7 +656,27 @@ extern "C" int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int
     }
     const size_t dyn = 4 * (2 * 64 * 256) + 128 + FWD_PROBE_LDS;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); attr = true; }
-    hipLaunchKernelGGL(attn_fwd32_kernel, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd32_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd32_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr = true;
+    }
+    if (live96) hipLaunchKernelGGL(attn_fwd32_kernel<6>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd32_kernel<8>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
     TR1_LAUNCH_CHECK();
+}
+
+extern "C" int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse,
+                                 const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots,
+                                 int64_t head_dim, float scale, void* stream) {
+    return attn_fwd_rows_impl(Q, q_ld, K, k_ld, V, v_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, 0, stream);
+}
+
+// The same launch for 128-wide heads whose features 96..127 are ZERO in Q, K and V (the vision towers' head dim 80 padded as d -> d, d + 40 -> 48 + d by
+// tr1_gemm_qkv_rope_vit_bf16): 24 instead of 32 MFMAs per wave and key tile.  O columns 96..127 of every head are NOT written (the caller keeps them zero).
+// ref: VisionAttention.forward TF:379-396 (Qwen2-VL) / the windowed form of Qwen2.5-VL, frozen towers (src/time_r1/rl/timer1_trainer.py:264-269).
+extern "C" int tr1_attn_fwd_rows_live96(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse,
+                                        const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots,
+                                        int64_t head_dim, float scale, void* stream) {
+    return attn_fwd_rows_impl(Q, q_ld, K, k_ld, V, v_ld, O, o_ld, lse, pre, lo, hi, T, n_heads, n_kv, n_slots, head_dim, scale, 1, stream);
 }

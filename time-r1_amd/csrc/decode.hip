@@ -51,7 +51,7 @@ static int64_t decode_ws_bytes(const int64_t* d) {
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     const int64_t fix = tr1_gemm_skinny_fixup_workspace_floats(R, hid, d[D_INTER]);
     const int64_t plan = tr1_attn_plan_ints(T, d[D_HEADS], d[D_KV], d[D_BATCH]);
-    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) + al(((R + 15) / 16 * 16) * qd * 2) + al(R * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
+    return al(R * hid * 2) * 2 + al(R * (qd + 2 * kvd) * 2) + al(R * qd * 2) + al(((R + 15) / 16 * 16) * qd * 2) + al(((R + 15) / 16 * 16) * d[D_INTER] * 2) + al(att * 4) + al(fix * 4) + al(plan * 4) + 4096;
 }
 
 extern "C" int64_t tr1_decode_step_workspace_bytes(const int64_t* dims) { return decode_ws_bytes(dims); }
@@ -71,7 +71,7 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     Carve c{(char*)work, (size_t)work_bytes};
     void* hA = c.take(R * hid * 2); void* hB = c.take(R * hid * 2);
     void* qkv = c.take(R * qkvd * 2); void* q = c.take(R * qd * 2); void* o = c.take(((R + 15) / 16 * 16) * qd * 2);
-    void* a = c.take(R * inter * 2); void* att = c.take(att_floats * 4);
+    void* a = c.take(((R + 15) / 16 * 16) * inter * 2); void* att = c.take(att_floats * 4);
     // down_proj (N = hidden, K = intermediate): split-K with in-kernel fixup pays from 16 rows up (tools/microbench.py fixup:
     // 37.9 -> 34.9 us at M = 16, 54 -> 45 us at M = 32); its ticket counters live in `work`, which the caller zero-fills ONCE
     const int64_t fix_floats = tr1_gemm_skinny_fixup_workspace_floats(R, hid, inter);
@@ -82,6 +82,11 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
     const bool planned = nsplit > 1 && L > 1;
     const bool down_fixup = !(qm & QM_DOWN) && R >= 16 && inter >= 8192;
     const bool down_fixup8 = w8 == 2 && (qm & QM_DOWN) && R <= 16 && inter >= 8192 && inter % 512 == 0 && hid % 64 == 0;      // fp8 MFMA: LDS-streamed split-K form
+    // round 6 (2B shapes): down projection with its whole weight slice in flight (csrc/oproj.hip long-K form) on the fragment-major SwiGLU output of the gate/up launch
+    static int down_frag_on = -1;
+    if (down_frag_on < 0) { const char* e = getenv("TR1_DOWN_FRAG"); down_frag_on = e ? atoi(e) : 1; }
+    const bool down_frag = down_frag_on && !(qm & (QM_DOWN | QM_GU)) && R <= 16 && inter > 3584 && tr1_gemm_oproj_frag_ok(R, hid, inter) &&
+                           tr1_norm_gemm_glu_frag_ok(R, inter, hid);
     TR1_CHECK_ARG(c.ok, "decode_step: workspace too small (tr1_decode_step_workspace_bytes)");
     const void* const* lp = (const void* const*)layer_ptrs;
     const int stride = w8 ? 13 : 9;
@@ -120,11 +125,12 @@ static int decode_step_impl(int w8, const void* layer_ptrs, const int64_t* dims,
         {
             ProfScope ps(2, stream);
             if (qm & QM_GU) CK(gemm8(h2, w[4], w[5], w[11], nullptr, nullptr, a, R, inter, hid, hid, hid, inter, 0, eps, 1, stream));
-            else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, 1, stream));
+            else CK(tr1_norm_gemm_skinny(h2, w[4], w[5], nullptr, a, R, inter, hid, hid, hid, inter, eps, down_frag ? 2 : 1, stream));
         }
         ProfScope ps3(3, stream);
         if (w8 == 2 && down_fixup8) CK(tr1_gemm_skinny_fixup_w8a8(a, w[6], w[12], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else if (qm & QM_DOWN) CK(gemm8(a, nullptr, w[6], w[12], nullptr, h2, h, R, hid, inter, inter, inter, hid, hid, eps, 0, stream));
+        else if (down_frag) CK(tr1_gemm_oproj_frag(a, w[6], h2, h, R, hid, inter, inter, hid, hid, stream));         // h = a Wd^T + h2
         else if (down_fixup) CK(tr1_gemm_skinny_fixup(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, fix, fix_floats, stream));
         else CK(tr1_gemm_nt_bf16(a, w[6], h, nullptr, h2, R, hid, inter, inter, inter, hid, hid, 0, 0, stream));  // h = a Wd^T + h2
     }

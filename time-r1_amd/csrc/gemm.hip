@@ -549,7 +549,7 @@ TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ 
         if (ep.p0) { dst_ga = reinterpret_cast<bf16_t*>(ep.p0) + col_a; dst_gb = dst_ga + I; ld_g = ep.ld0; }
     } else if (EPI == 7) {
         // Qwen2-VL / 2.5-VL vision attention (TF:225-248 apply_rotary_pos_emb_vision, head dim 80): section = q | k | v, the lane's 8 pair columns d0..d0+7
-        // (< 40) of one head and their partners d0 + 40.  Outputs go to 128-wide PADDED heads: d -> head*128 + d, d + 40 -> head*128 + 64 + d, so the head-dim-128
+        // (< 40) of one head and their partners d0 + 40.  Outputs go to 128-wide PADDED heads: d -> head*128 + d, d + 40 -> head*128 + 48 + d (64 + d when half > 48), so the head-dim-128
         // attention kernels (32x32x16 MFMA, K / V row-major) take the tower; the pad columns are zero-filled once by the caller.
         const int tps = ep.i0 >> 7, tile = (int)(n0 >> 8);
         const int sec = tile / tps, pair0 = (tile - sec * tps) * 128 + wn * 32 + c4 * 8;
@@ -562,7 +562,7 @@ TR1_DEV void store_acc256_pairs(const f32x4_t (&acc)[RT][4], char* __restrict__ 
         else if (sec == 1) { dst_a = reinterpret_cast<bf16_t*>(ep.p0); ld_o = ep.ld0; }
         else { dst_a = reinterpret_cast<bf16_t*>(ep.p1); ld_o = ep.ld1; }
         dst_a += head * 128 + d0;
-        dst_b = dst_a + 64;
+        dst_b = dst_a + (ep.i1 <= 48 ? 48 : 64);       // round 6: halves of <= 48 features sit 48 apart - the head's live features then end at 96 (tr1_attn_fwd_rows_live96)
         col_a = ncol;
     } else {
         const int d = (wn & 1) * 32 + c4 * 8;
@@ -1369,7 +1369,9 @@ template <int NST, int R, int NRED = 2, int MG = 1, int MODE = 0>
 __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ lnw, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ C, int M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                                                            int64_t ldc, float eps, int64_t up_off, const bf16_t* __restrict__ bias = nullptr,
-                                                           QkvEpi qe = QkvEpi{}) {
+                                                           QkvEpi qe = QkvEpi{}, int c_frag = 0) {
+    // c_frag (MODE 0, MG = 1; round 6): the SwiGLU output leaves FRAGMENT-MAJOR - element (m, n) at (n / 32) * 512 + m * 32 + n % 32, the layout
+    // tr1_gemm_oproj_frag reads (one contiguous KiB per MFMA operand fragment) - for the all-stages-in-flight down projection of the 2B shapes
     constexpr bool QKV = MODE == 1, PLAIN = MODE == 2;
     constexpr int STAGE = 4096;                                            // bytes per stage: gate 2 KiB + up 2 KiB
     constexpr int REDW = MG * 2 * 16 * 17;                                 // floats of one wave's partial: MG row groups x (gate | up)
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
             } else {
             const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(v2 * rstd));
             const int64_t n = (p0 + pi) * 16 + nn;
-            if (mgi * 16 + mm < M && n < N) C[(int64_t)(mgi * 16 + mm) * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
+            if (mgi * 16 + mm < M && n < N) C[c_frag ? (n >> 5) * 512 + mm * 32 + (n & 31) : (int64_t)(mgi * 16 + mm) * ldc + n] = f2bf(bf2f(f2bf(silu_f32(gt))) * up);
             }
         }
         if (NRED == 1) TR1_BARRIER();                                   // single reduction buffer: everybody has read it before the next pair writes
@@ -1613,6 +1615,12 @@ __global__ __launch_bounds__(512) void norm_glu_lds_kernel(const bf16_t* __restr
 // TR1_NG32_CFG: A/B hook for the 17..32-row rmsnorm + projection kernels (plain and fused-QKV take the SAME form so they stay bit-identical).
 // Default 1 = 8 waves x UNROLL 2 (fused QKV at 32 rows: 19.7 -> 18.4 us; 144 blocks for 256 CUs, so the extra waves are what adds loads in flight)
 static int ng32_cfg() { static int c = -1; if (c < 0) { c = 1; } return c; }
+
+// 1 when tr1_norm_gemm_skinny(..., glu = 2) can write the SwiGLU output fragment-major (the LDS-streamed <= 16-row form; N % 32: whole 32-column fragments)
+extern "C" int tr1_norm_gemm_glu_frag_ok(int64_t M, int64_t N, int64_t K) {
+    const int64_t nst = K / 512;
+    return M >= 1 && M <= 16 && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3) && N % 32 == 0;
+}
 
 extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* W, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                                     int64_t ldx, int64_t ldw, int64_t ldc, float eps, int glu, void* stream) {
@@ -1674,6 +1682,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
 #undef HL_LAUNCH
         TR1_LAUNCH_CHECK();
     }
+    TR1_CHECK_ARG(glu != 2 || tr1_norm_gemm_glu_frag_ok(M, N, K), "norm_gemm_skinny: glu = 2 (fragment-major SwiGLU output) needs M <= 16 and the LDS-streamed form (tr1_norm_gemm_glu_frag_ok)");
     if (glu && M <= 32 && glu_lds && K % 512 == 0 && (nst == 7 || nst == 4 || nst == 3) && N % 16 == 0) {   // hidden 3584 / 2048 / 1536
         // <= 16 rows: ring of 3 + double reduction buffer (a ring of 4 with a single buffer and a second barrier per pair measured the same).
         // 17..32 rows (config 4 decodes 2 x 16 rollouts): two row groups per wave against the SAME LDS stage, ring of 3, single reduction
@@ -1697,7 +1706,7 @@ extern "C" int tr1_norm_gemm_skinny(const void* x, const void* lnw, const void* 
 #define GLU_LAUNCH(NSTV)                                                                                                                        \
     do {                                                                                                                                        \
         if (M <= 16) hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 2, 1>), dim3(grid), dim3(512), dyn1, s, (const bf16_t*)x, (const bf16_t*)lnw, \
-                                        (const bf16_t*)W, (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);                                   \
+                                        (const bf16_t*)W, (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N, (const bf16_t*)nullptr, QkvEpi{}, glu == 2 ? 1 : 0); \
         else hipLaunchKernelGGL((norm_glu_lds_kernel<NSTV, RING, 1, 2>), dim3(grid), dim3(512), dyn2, s, (const bf16_t*)x, (const bf16_t*)lnw,         \
                                 (const bf16_t*)W, (bf16_t*)out, (int)M, N, K, ldx, ldw, ldc, eps, N);                                           \
     } while (0)

@@ -248,11 +248,17 @@ class HipOps:
         return (dgu, None) if want_t else dgu
 
     def norm_gemm(self, x, lnw, eps, w, bias=None, glu=False):
-        """Decode rows: rmsnorm(x; lnw) @ w^T (+bias), or with glu=True silu(gate)*up of the [2I, K] weight - one launch."""
+        """Decode rows: rmsnorm(x; lnw) @ w^T (+bias), or with glu=True silu(gate)*up of the [2I, K] weight - one launch.  glu=2 (M <= 16): the same
+        values FRAGMENT-MAJOR ([I / 32][16 rows][32 columns], the operand layout of gemm_oproj_frag) as a flat [16 * I] tensor."""
         self._chk(x, lnw, w, bias)
         M, K = x.shape
         N = w.shape[0] // 2 if glu else w.shape[0]
         assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and lnw.numel() == K
+        if int(glu) == 2:
+            assert self.L.raw("tr1_norm_gemm_glu_frag_ok")(M, N, K)
+            out = self.zeros(16 * N)
+            self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), 2, self._s())
+            return out
         out = self.empty(M, N)
         self.L.call("tr1_norm_gemm_skinny", _p(x), _p(lnw), _p(w), _p(bias), _p(out), M, N, K, x.stride(0), w.stride(0), N, float(eps), int(glu), self._s())
         return out
@@ -576,11 +582,12 @@ class HipOps:
     FWD32 = True      # head dim 128, nsplit 1: the 32x32x16-MFMA forward over row-major K / V (class attribute: tests / tools may clear it)
 
     def attn_fwd(self, q, k, vt, pre, lo, hi, n_heads, n_kv, n_slots, head_dim, scale, nsplit=1, need_lse=True, out=None, n_batch=1,
-                 kv_batch_slots=0, plan=None, plan_mode=0, v_rows=None):
+                 kv_batch_slots=0, plan=None, plan_mode=0, v_rows=None, live96=False):
         """n_batch > 1: q/out/masks hold n_batch problems of T = rows/n_batch tokens each; problem b reads cache slots from b*kv_batch_slots.
         plan / plan_mode: split-KV decode only - mode 1 publishes the tile lists of these masks in `plan`, mode 2 reuses them (same masks).
         v_rows: V row-major [n_slots, n_kv*head_dim] (a view is fine).  With it, head dim 128 single-pass launches take the 32x32x16-MFMA
-        kernel, which reads K and V as stored; `vt` may then be None."""
+        kernel, which reads K and V as stored; `vt` may then be None.  live96 (with v_rows, head dim 128): features 96..127 of every head are zero in q / k / v
+        (the vision towers' padded heads) - the kernel skips them and leaves columns 96..127 of `out` untouched."""
         assert pre.dtype == I32 and lo.dtype == I32 and hi.dtype == I32
         rows = q.shape[0]
         assert rows % n_batch == 0
@@ -590,9 +597,10 @@ class HipOps:
         if v_rows is not None and self.attn_fwd_rows_ok(head_dim, nsplit, n_batch, n_slots=n_slots, ld=max(_ld(k), _ld(v_rows))):
             self._chk(q, k, v_rows)
             assert k.shape[0] >= n_slots and v_rows.shape[0] >= n_slots
-            self.L.call("tr1_attn_fwd_rows", _p(q), _ld(q), _p(k), _ld(k), _p(v_rows), _ld(v_rows), _p(o), _ld(o), _p(lse), _p(pre), _p(lo), _p(hi), T,
-                        n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
+            self.L.call("tr1_attn_fwd_rows_live96" if live96 else "tr1_attn_fwd_rows", _p(q), _ld(q), _p(k), _ld(k), _p(v_rows), _ld(v_rows), _p(o), _ld(o), _p(lse),
+                        _p(pre), _p(lo), _p(hi), T, n_heads, n_kv, n_slots, head_dim, float(scale), self._s())
             return o, lse
+        assert not live96, "live96 is a property of the row-major head-dim-128 launch"
         if vt is None and v_rows is not None:      # the row-major kernel does not take this launch (head dim, split-KV, > 4 GiB operands): V^T copy
             vt = self.pack_transpose(v_rows, n_kv, n_kv, head_dim)
         assert vt is not None, "attention: this shape needs the V^T operand"
