@@ -418,6 +418,42 @@ def test_attention_fwd_bwd(hip_ops, ref_ops, name, nh, nkv, hd, m):
     close(dv_h, dv_r, 0.03 * math.sqrt(nh // nkv) + 0.02, rtol=3e-2, what=name + " dV")
 
 
+FWD64_CASES = [
+    # name, n_heads, n_kv, P, G, C, continuation, q scale (large: the lazy running maximum rescales often - the kernel's cold path)
+    ("g7-kv4", 28, 4, 700, 8, 50, False, 1.0),
+    ("g7-kv4-continuation", 28, 4, 210, 4, 33, True, 1.0),
+    ("g6-kv2-hot-scores", 12, 2, 333, 8, 25, False, 6.0),
+    ("g2-kv3", 6, 3, 333, 3, 77, False, 1.0),
+    ("g1-kv16", 16, 16, 300, 2, 100, False, 1.0),
+    ("one-tile", 28, 4, 5, 2, 3, False, 1.0),
+    ("two-tokens", 28, 4, 1, 1, 1, False, 1.0),
+]
+
+
+@pytest.mark.parametrize("name,nh,nkv,P,G,C,cont,qs", FWD64_CASES, ids=[c[0] for c in FWD64_CASES])
+def test_attention_fwd64_bit_identical_to_fwd32(hip_ops, name, nh, nkv, P, G, C, cont, qs, monkeypatch):
+    """Round 6: attn_fwd64_kernel (64 query rows per wave, one wave per SIMD, softmax of tile t in the MFMA gaps of tiles t-1 / t+1; csrc/attn_fwd64.hip) is the
+    default head-dim-128 forward.  It keeps attn_fwd32_kernel's 32-row softmax groups, lazy-maximum decisions and summation orders, so O and the LSE must
+    agree with that kernel BIT FOR BIT (the 32-row kernel is held to the oracle by the tests above and below; TR1_FWD64 is read per call)."""
+    hd = 128
+    qd, kvd = nh * hd, nkv * hd
+    S = P + G * C
+    pre, lo, hi = masks_prefix_shared(P, G, C)
+    qkv = rnd(S, qd + 2 * kvd, seed=21).cuda()
+    qkv[:, :qd] *= qs
+    q_all, k_view, v_view = qkv[:, :qd], qkv[:, qd:qd + kvd], qkv[:, qd + kvd:]
+    r0 = P if cont else 0
+    args = (q_all[r0:], k_view, None, pre[r0:].cuda(), lo[r0:].cuda(), hi[r0:].cuda(), nh, nkv, S, hd, hd ** -0.5)
+    monkeypatch.setenv("TR1_FWD64", "0")
+    o32, l32 = hip_ops.attn_fwd(*args, v_rows=v_view)
+    monkeypatch.setenv("TR1_FWD64", "1")
+    o64, l64 = hip_ops.attn_fwd(*args, v_rows=v_view)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(o64.float()).any())
+    assert torch.equal(o32.view(torch.int16), o64.view(torch.int16)), name + " O"
+    assert torch.equal(l32.view(torch.int32), l64.view(torch.int32)), name + " lse"
+
+
 ROWS_CASES = [
     # name, n_heads, n_kv, P, G, C, continuation (q = completion rows only, T < n_slots)
     ("g7-kv4-packed", 28, 4, 210, 4, 33, False),          # Qwen2-VL-7B head layout; 342 * 7 packed rows: not a multiple of 256

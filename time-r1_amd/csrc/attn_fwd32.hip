@@ -630,6 +630,7 @@ int tr1_launch_attn_dec32(AttnParams& p, dim3 grid, hipStream_t s) {
     return 1;
 }
 
+int tr1_launch_attn_fwd64(AttnParams& p, unsigned blocks, hipStream_t s);      // attn_fwd64.hip
 // Q/O: [T, n_heads*128]; K, V: [n_slots, n_kv*128] row-major (any leading dims that are multiples of 8); lse (optional): fp32 [n_heads, T].
 static int attn_fwd_rows_impl(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse,
                               const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots,
@@ -661,7 +662,11 @@ static int attn_fwd_rows_impl(const void* Q, int64_t q_ld, const void* K, int64_
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd32_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         attr = true;
     }
+    // head dim 128, all 128 features live: the 64-rows-per-wave kernel (attn_fwd64.hip; TR1_FWD64=0 selects the 32-row kernel for A/B runs and the bit-identity test -
+    // read per call, so a test can switch inside one process)
+    const char* f64 = getenv("TR1_FWD64");
     if (live96) hipLaunchKernelGGL(attn_fwd32_kernel<6>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
+    else if (!f64 || f64[0] != '0') tr1_launch_attn_fwd64(p, blocks, (hipStream_t)stream);
     else hipLaunchKernelGGL(attn_fwd32_kernel<8>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
     TR1_LAUNCH_CHECK();
 }
