@@ -366,14 +366,14 @@ def cpu_baseline(args, budget_note=True):
             "seconds_per_sample_est": est}
 
 
-def cpu_config1(n_prompts=1):
+def cpu_config1(n_prompts=1, dtype="fp32"):
     """BASELINE.json configs[0] timed for real on the host cores (no extrapolation): Qwen2-VL-2B architecture at FULL depth, 8 frames of
     360x640 (grid 4x26x46, 1196 video tokens), G = 4, C = 64, beta = 0.04, fp32, the CPU oracle ops (kind "port").  One micro-step per
     prompt: preprocessing, vision tower, prefill + 64 decode steps, policy and reference log-probs, loss, backward; the optimizer step is
     timed once.  `python bench.py --cpu-config1 [--cpu-config1-prompts N]` prints this leg only (about 1 minute per prompt on 128 cores)."""
     from oracle.ref_ops import RefOps  # noqa: checker/baseline only
     cfg = PRESETS["qwen2-vl-2b"]()
-    ops = RefOps(act_dtype=torch.float32)
+    ops = RefOps(act_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)      # bf16: activations / weights rounded to bf16 like the GPU path (the reference's --bf16 run on CPU)
     G, C, grid = 4, 64, GRIDS[8]
     t_all = time.time()
     params = ModelParams(cfg, ops, init="none")
@@ -409,10 +409,10 @@ def cpu_config1(n_prompts=1):
     per = sum(ph.values()) / n_prompts + t_opt / 2.0          # gradient_accumulation_steps = 2: half an optimizer step per micro-step
     return {"value": 1.0 / per, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "generated_tokens_per_sec": toks / ph["rollout"],
-            "sample": "BASELINE configs[0] measured, not extrapolated: Qwen2-VL-2B full depth, 8 frames (grid %s), G=4, C=64, beta=0.04, fp32 CPU oracle ops, "
+            "sample": "BASELINE configs[0] measured, not extrapolated: Qwen2-VL-2B full depth, 8 frames (grid %s), G=4, C=64, beta=0.04, %s CPU oracle ops, "
                       "%d prompt(s); seconds per prompt by phase %s, optimizer step %.1f s (amortised over GA=2); %.0f s of CPU work in total"
-                      % (str(grid), n_prompts, {k: round(x / n_prompts, 1) for k, x in ph.items()}, t_opt, time.time() - t_all),
-            "seconds_per_sample": per}
+                      % (str(grid), dtype, n_prompts, {k: round(x / n_prompts, 1) for k, x in ph.items()}, t_opt, time.time() - t_all),
+            "seconds_per_sample": per, "dtype": dtype}
 
 
 def parse_args(argv=None):
@@ -431,6 +431,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-config1", action="store_true", help="only time BASELINE configs[0] (2B, 8 frames, G=4, C=64) on the host cores with the CPU oracle and print it")
     ap.add_argument("--cpu-config1-prompts", type=int, default=1)
+    ap.add_argument("--cpu-config1-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-op-by-op", action="store_true", help="time the decode GEMMs from Python torch events around op-by-op launches (rounds 1-2 method)")
     ap.add_argument("--no-peak-probe", action="store_true")
@@ -481,7 +482,7 @@ def resolve_launch(args, env, device_count):
 def main(argv=None):
     args = parse_args(argv)
     if args.cpu_config1:
-        print(json.dumps({"metric": "grpo_samples_per_sec", "config": {"workload": "BASELINE configs[0], CPU only"}, "cpu_baseline": cpu_config1(args.cpu_config1_prompts)}))
+        print(json.dumps({"metric": "grpo_samples_per_sec", "config": {"workload": "BASELINE configs[0], CPU only"}, "cpu_baseline": cpu_config1(args.cpu_config1_prompts, args.cpu_config1_dtype)}))
         return
     mode, cmd = resolve_launch(args, os.environ, torch.cuda.device_count())
     if mode == "spawn":
