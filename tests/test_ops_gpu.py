@@ -454,26 +454,6 @@ def test_attention_fwd64_bit_identical_to_fwd32(hip_ops, name, nh, nkv, P, G, C,
     assert torch.equal(l32.view(torch.int32), l64.view(torch.int32)), name + " lse"
 
 
-@pytest.mark.parametrize("name,nh,nkv,P,G,C,cont,qs", FWD64_CASES, ids=[c[0] for c in FWD64_CASES])
-def test_attention_bwd_dq64_bit_identical_to_dq32(hip_ops, name, nh, nkv, P, G, C, cont, qs, monkeypatch):
-    """Round 6: attn_bwd_dq64_kernel (csrc/attn_bwd_dq64.hip: 64 query rows per wave, the P / dS chain of a 32-key half tile in the MFMA gaps of its neighbours) is the
-    default head-dim-128 dQ kernel.  Same per-element arithmetic and accumulation order as attn_bwd_dq32_kernel (held to the oracle by test_attention_fwd_bwd): dQ
-    must agree BIT FOR BIT, and so must dK / dV - the dK/dV kernel reads the delta / log2-LSE / mask summary that the dQ kernel's prologue writes."""
-    hd = 128
-    S = P + G * C
-    pre, lo, hi = [t.cuda() for t in masks_prefix_shared(P, G, C)]
-    q, k, v, do = (rnd(S, nh * hd, seed=31).cuda() * qs).to(BF16), rnd(S, nkv * hd, seed=32).cuda(), rnd(S, nkv * hd, seed=33).cuda(), (rnd(S, nh * hd, seed=34).cuda() * 0.1).to(BF16)
-    o, lse = hip_ops.attn_fwd(q, k, None, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5, v_rows=v)
-    res = {}
-    for form in ("0", "1"):
-        monkeypatch.setenv("TR1_DQ64", form)
-        res[form] = [t.clone() for t in hip_ops.attn_bwd(q, k, v, o, do, lse, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5)]
-        torch.cuda.synchronize()
-    for what, a, b in zip(("dQ", "dK", "dV"), res["0"], res["1"]):
-        assert not bool(torch.isnan(b.float()).any()), name + " " + what
-        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), name + " " + what
-
-
 ROWS_CASES = [
     # name, n_heads, n_kv, P, G, C, continuation (q = completion rows only, T < n_slots)
     ("g7-kv4-packed", 28, 4, 210, 4, 33, False),          # Qwen2-VL-7B head layout; 342 * 7 packed rows: not a multiple of 256

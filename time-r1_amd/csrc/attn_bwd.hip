@@ -1508,8 +1508,6 @@ static bool bwd32_both(const AttnParams& p) {
            (uint64_t)p.T * (uint64_t)(p.q_ld > p.do_ld ? p.q_ld : p.do_ld) * 2ull < 0xffffffffull;
 }
 
-int tr1_launch_attn_bwd_dq64(const AttnParams& p, unsigned blocks_x, hipStream_t s, const float* lse2);      // attn_bwd_dq64.hip
-
 template <int D>
 static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_floats, const float* lse2) {
     const int64_t nR = (int64_t)p.T * p.group;
@@ -1531,11 +1529,7 @@ static int launch_bwd(const AttnParams& p, hipStream_t s, float* ws, int64_t ws_
     if (D == 128 && !dq32_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_dq32); dq32_attr = true; }
     const bool use_dq32 = D == 128 && p.d_real == 128 && lse2 != nullptr &&
                           (uint64_t)p.n_slots * (uint64_t)(p.k_ld > p.v_ld ? p.k_ld : p.v_ld) * 2ull < 0xffffffffull;      // 32-bit DMA byte offsets
-    // (round 6) the 64-rows-per-wave form of the same kernel (attn_bwd_dq64.hip, bit-identical results); TR1_DQ64=0 selects the 32-row kernel for A/B runs and the
-    // bit-identity test - read per call, so a test can switch inside one process
-    const char* dq64 = getenv("TR1_DQ64");
-    if (use_dq32 && (!dq64 || dq64[0] != '0')) tr1_launch_attn_bwd_dq64(p, (unsigned)((nR + 255) / 256), s, lse2);
-    else if (use_dq32) hipLaunchKernelGGL(attn_bwd_dq32_kernel, dim3((unsigned)((nR + 255) / 256), p.n_kv), dim3(512), dyn_dq32, s, p, lse2);
+    if (use_dq32) hipLaunchKernelGGL(attn_bwd_dq32_kernel, dim3((unsigned)((nR + 255) / 256), p.n_kv), dim3(512), dyn_dq32, s, p, lse2);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3((unsigned)((nR + 127) / 128), p.n_kv), dim3(256), dyn_dq, s, p);
     // head dim 128 beyond the 32-bit DMA offsets of the 32x32x16 kernel: the LDS-DMA staged 16x16x32 form, 8 waves x 16 keys
     constexpr int DMA_NB = 4;

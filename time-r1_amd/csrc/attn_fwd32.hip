@@ -662,11 +662,14 @@ static int attn_fwd_rows_impl(const void* Q, int64_t q_ld, const void* K, int64_
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd32_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         attr = true;
     }
-    // head dim 128, all 128 features live: the 64-rows-per-wave kernel (attn_fwd64.hip; TR1_FWD64=0 selects the 32-row kernel for A/B runs and the bit-identity test -
-    // read per call, so a test can switch inside one process)
+    // head dim 128, all 128 features live, long key ranges: the 64-rows-per-wave kernel (attn_fwd64.hip, bit-identical results).  Its software pipeline pays one
+    // extra body per block for fill / drain, so it wins from ~30 key tiles per block on (tools/sweep_fwd64.py, profiles/r06_sweep_fwd64.txt: -8 % at 3 072 prompt
+    // tokens, -3 % at 2 048, +1 % at 1 536, +12 % at 256) and loses on the vision towers' 13-tile segments (live-96 form built and measured: 195 against 173 us).
+    // TR1_FWD64 = 1 / 0 forces / forbids it (A/B runs, the bit-identity test) - read per call, so a test can switch inside one process.
     const char* f64 = getenv("TR1_FWD64");
-    if (live96) hipLaunchKernelGGL(attn_fwd32_kernel<6>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
-    else if (!f64 || f64[0] != '0') tr1_launch_attn_fwd64(p, blocks, (hipStream_t)stream);
+    const bool use64 = !live96 && (f64 ? f64[0] != '0' : n_slots >= 3072);
+    if (use64) tr1_launch_attn_fwd64(p, blocks, (hipStream_t)stream);
+    else if (live96) hipLaunchKernelGGL(attn_fwd32_kernel<6>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd32_kernel<8>, dim3(blocks), dim3(512), dyn, (hipStream_t)stream, p);
     TR1_LAUNCH_CHECK();
 }
