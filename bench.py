@@ -669,7 +669,7 @@ def main(argv=None):
         try:
             fp8_run = bool(args.rollout_fp8 or args.rollout_fp8_w8a16)
             # (round 5: the fp8 sampling policy has a PMC pass of its own - its decode kernels stream other bytes than the bf16 family's)
-            cands = ("r05_pmc_traffic_fp8.json",) if fp8_run else ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            cands = ("r06_pmc_traffic_fp8.json", "r05_pmc_traffic_fp8.json") if fp8_run else ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
             pmc_name = [f for f in cands if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             # guard: the counters are only quoted while the kernels they were collected on are the kernels that just ran - the PMC pass records

@@ -143,7 +143,9 @@ int64_t tr1_attn_fwd_workspace_floats(int64_t T, int64_t n_heads, int64_t n_kv, 
 /* The same attention (nsplit = 1, one problem, head_dim = 128) with K AND V row-major ([n_slots, n_kv*128], any leading dims % 8 == 0): the
  * 32x32x16-MFMA kernel of round 3 transposes V in its LDS reads, so the LLM's training / prefill / reference-policy forwards (TF:521-556 via
  * timer1_trainer.py:452-457, attn_implementation=flash_attention_2 in scripts/posttrain/train_rl.sh:33) need no V^T copy.  Same results as
- * tr1_attn_fwd up to the order of the fp32 accumulation. */
+ * tr1_attn_fwd up to the order of the fp32 accumulation.  From 3 072 key slots on the launch takes the 64-rows-per-wave kernel of round 6
+ * (csrc/attn_fwd64.hip: one wave per SIMD, the softmax of tile t in the MFMA gaps of tiles t-1 / t+1) - bit-identical O and LSE; the
+ * environment variable TR1_FWD64 = 1 / 0, read per call, forces / forbids it. */
 int tr1_attn_fwd_rows(const void* Q, int64_t q_ld, const void* K, int64_t k_ld, const void* V, int64_t v_ld, void* O, int64_t o_ld, void* lse, const void* pre, const void* lo, const void* hi, int64_t T, int64_t n_heads, int64_t n_kv, int64_t n_slots, int64_t head_dim, float scale, void* stream);
 /* tr1_attn_fwd_rows for 128-wide heads whose features 96..127 are ZERO in Q, K and V (the vision towers' head dim 80 in the padded layout of
  * tr1_gemm_qkv_rope_vit_bf16): 12 + 12 instead of 16 + 16 MFMAs per wave and key tile; O columns 96..127 of every head are not written (the caller keeps them
