@@ -433,7 +433,7 @@ FWD64_CASES = [
 @pytest.mark.parametrize("name,nh,nkv,P,G,C,cont,qs", FWD64_CASES, ids=[c[0] for c in FWD64_CASES])
 def test_attention_fwd64_bit_identical_to_fwd32(hip_ops, name, nh, nkv, P, G, C, cont, qs, monkeypatch):
     """Round 6: attn_fwd64_kernel (64 query rows per wave, one wave per SIMD, softmax of tile t in the MFMA gaps of tiles t-1 / t+1; csrc/attn_fwd64.hip) is the
-    default head-dim-128 forward.  It keeps attn_fwd32_kernel's 32-row softmax groups, lazy-maximum decisions and summation orders, so O and the LSE must
+    head-dim-128 forward from 3 072 key slots on (TR1_FWD64=1 forces it at any size).  It keeps attn_fwd32_kernel's 32-row softmax groups, lazy-maximum decisions and summation orders, so O and the LSE must
     agree with that kernel BIT FOR BIT (the 32-row kernel is held to the oracle by the tests above and below; TR1_FWD64 is read per call)."""
     hd = 128
     qd, kvd = nh * hd, nkv * hd
@@ -448,6 +448,37 @@ def test_attention_fwd64_bit_identical_to_fwd32(hip_ops, name, nh, nkv, P, G, C,
     o32, l32 = hip_ops.attn_fwd(*args, v_rows=v_view)
     monkeypatch.setenv("TR1_FWD64", "1")
     o64, l64 = hip_ops.attn_fwd(*args, v_rows=v_view)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(o64.float()).any())
+    assert torch.equal(o32.view(torch.int16), o64.view(torch.int16)), name + " O"
+    assert torch.equal(l32.view(torch.int32), l64.view(torch.int32)), name + " lse"
+
+
+FWD64_MASK_CASES = [
+    ("segments", 4, 4, lambda: masks_segments([70, 3, 130, 64, 200])),          # group 1, per-segment intervals (what a forced launch on a vision-style mask sees)
+    ("prefix-only-rows", 4, 2, lambda: masks_prefix_only(90, 45)),               # rows whose second interval is empty or one key wide
+    ("causal-tiny", 2, 2, lambda: masks_causal(9)),
+    ("causal-g7-ragged", 28, 4, lambda: masks_causal(333)),                      # 333 slots: the last tile is partial, 2 331 packed rows: the last block too
+    ("default-dispatch-3100-slots", 28, 4, lambda: masks_prefix_shared(2900, 2, 100)),   # TR1_FWD64 unset: the launch picks the 64-row kernel by itself
+]
+
+
+@pytest.mark.parametrize("name,nh,nkv,mk", FWD64_MASK_CASES, ids=[c[0] for c in FWD64_MASK_CASES])
+def test_attention_fwd64_bit_identical_other_masks(hip_ops, name, nh, nkv, mk, monkeypatch):
+    """The 64-row forward on the other mask families of the path (segments, prefix-only rows, plain causal, ragged sizes) and through the launch's own
+    key-range rule: bit-identical O and LSE against the 32-row kernel, which the tests above hold to the oracle."""
+    hd = 128
+    pre, lo, hi = [t.cuda() for t in mk()]
+    S = pre.numel()
+    q, k, v = rnd(S, nh * hd, seed=41).cuda(), rnd(S, nkv * hd, seed=42).cuda(), rnd(S, nkv * hd, seed=43).cuda()
+    args = (q, k, None, pre, lo, hi, nh, nkv, S, hd, hd ** -0.5)
+    monkeypatch.setenv("TR1_FWD64", "0")
+    o32, l32 = hip_ops.attn_fwd(*args, v_rows=v)
+    if name.startswith("default-dispatch"):
+        monkeypatch.delenv("TR1_FWD64")
+    else:
+        monkeypatch.setenv("TR1_FWD64", "1")
+    o64, l64 = hip_ops.attn_fwd(*args, v_rows=v)
     torch.cuda.synchronize()
     assert not bool(torch.isnan(o64.float()).any())
     assert torch.equal(o32.view(torch.int16), o64.view(torch.int16)), name + " O"
