@@ -922,118 +922,6 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Round 6 (experimental, TR1_GEMM4W=1): the 256 x 256 x 64 NT tile on FOUR waves, one per SIMD, each with a 128 x 128 output (8 x 8 MFMA tiles = all 256
-// accumulator registers) and the 512-register file of a lone wave.  Per 32-k step a wave reads 8 A + 8 B fragments for 64 MFMAs (0.25 fragment reads per MFMA
-// against 0.375 of the 8-wave form); the k loop is software-pipelined inside the wave in HALF K-tiles: phase 0 of tile t issues the MFMAs of k-step 0 while the
-// fragments of k-step 1 are read, [vmcnt(0) + barrier: tile t+1 - requested one tile ago - has landed for everybody, tile t's buffer is all in registers],
-// phase 1 issues k-step 1 while the 16 DMA instructions of tile t+2 go out (into tile t's buffer) and the k-step-0 fragments of tile t+1 come in.
-// One barrier per K-tile; DMA by inline asm behind that one counted wait (32-bit offsets from scalar bases).  Same LDS image / swizzle / B-row permutation /
-// epilogue as the 8-wave forms (store_acc256_lds on the wave's two 64-column halves), so results are identical to gemm_nt8p_kernel<.., 8>.
-template <bool OUT_F32, bool ACCUM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv,
-                                                        const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
-                                                        int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                                                        int64_t ldr, int tiles_m, int tiles_n) {
-    constexpr int OPB = 256 * BK * 2, SLOT = 2 * OPB;                  // 32 KiB per operand tile, slot = [A | B]
-    extern __shared__ __attribute__((aligned(1024))) char smem4[];    // [2 slots]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = tiles_m * tiles_n;
-    int wgid;
-    {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
-    const int GROUP_M = 4;
-    const int group = wgid / (GROUP_M * tiles_n);
-    const int first_m = group * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int in_group = wgid - group * GROUP_M * tiles_n;
-    const int tm = first_m + in_group % gsz;
-    const int tn = in_group / gsz;
-    const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
-
-    f32x4_t acc0[8][4], acc1[8][4];                                   // the wave's two 64-column halves
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc0[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+a"(acc0[i][j])); asm volatile("" : "+a"(acc1[i][j]));      // loop-carried tiles start in the accumulator file
-        }
-    const int nk = (int)(K / BK);
-    const int u = lane & 15, g = lane >> 4;
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem4;
-    const unsigned a_off = (unsigned)((wm * 128 + u) * 128 + ((g ^ ((u >> 1) & 7)) << 4));
-    const unsigned b_off = (unsigned)(OPB + (wn * 128 + (u >> 2) * 16 + (u & 3)) * 128 + ((g ^ (((u >> 2) << 1) | ((u >> 1) & 1))) << 4));
-    // DMA: instruction d of a wave covers tile rows (wave*8 + d)*8 .. +7; per-lane byte offsets hoisted, the k position lives in the scalar base
-    unsigned aoffs[8], boffs[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        const int row = (wave * 8 + d) * 8 + (lane >> 3);
-        int64_t ga = m0 + row; if (ga >= M) ga = M - 1;
-        int64_t gb = n0 + row; if (gb >= N) gb = N - 1;
-        aoffs[d] = (unsigned)(ga * lda * 2 + ((((lane & 7) ^ keyA(row))) << 4));
-        boffs[d] = (unsigned)(gb * ldb * 2 + ((((lane & 7) ^ keyB(row))) << 4));
-    }
-#define G4_DMA(voff_, sbase, m0v) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff_), "s"(sbase) : "memory", "m0")
-    auto dma_one = [&](int d, int t) {                                // d < 8: A instruction d of K-tile t (clamped), else B instruction d - 8
-        const int tc = t < nk ? t : nk - 1;
-        const unsigned dst = lds_base + (unsigned)(t & 1) * SLOT + (unsigned)(wave * 8 + (d & 7)) * 1024u;
-        if (d < 8) G4_DMA(aoffs[d], reinterpret_cast<const char*>(A) + (int64_t)tc * (BK * 2), dst);
-        else G4_DMA(boffs[d - 8], reinterpret_cast<const char*>(B) + (int64_t)tc * (BK * 2), dst + OPB);
-    };
-#pragma unroll
-    for (int d = 0; d < 16; ++d) dma_one(d, 0);
-#pragma unroll
-    for (int d = 0; d < 16; ++d) dma_one(d, 1);
-    typedef const __attribute__((address_space(3))) bf16x8_t* lds_b128_t;
-#define G4_LDS(addr) (*(lds_b128_t)(uintptr_t)(addr))
-    struct Frags { bf16x8_t a[8], b[2][4]; };
-    Frags f0, f1;
-    // fragment n (0..15) of k-step ks of the tile in slot `sl`: n < 8 -> A tile row block n, else B fragment (half (n-8)/4, j = (n-8)%4)
-    auto load_frag = [&](Frags& f, int n, unsigned sl, int ks) {
-        if (n < 8) f.a[n] = G4_LDS(sl + ((a_off + n * 2048) ^ (ks * 64)));
-        else f.b[(n - 8) >> 2][(n - 8) & 3] = G4_LDS(sl + ((b_off + ((n - 8) >> 2) * 8192 + ((n - 8) & 3) * 512) ^ (ks * 64)));
-    };
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // tile 0
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int n = 0; n < 16; ++n) load_frag(f0, n, lds_base, 0);
-    // one phase: 64 MFMAs on fragments `fc`; between them the 16 fragment reads into `fn` and (phase 1) the 16 DMA instructions of tile t+2
-    auto phase = [&](const Frags& fc, Frags& fn, unsigned nsl, int nks, bool dma, int t) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {                                // q = 4 MFMAs: half s = q >> 3, row block i = q & 7
-            const int sh = q >> 3, i = q & 7;
-            load_frag(fn, q, nsl, nks);
-            if (dma) dma_one(q, t + 2);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (sh == 0) acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc.b[0][j], fc.a[i], acc0[i][j], 0, 0, 0);
-                else acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc.b[1][j], fc.a[i], acc1[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    for (int t = 0; t < nk; ++t) {
-        const unsigned cur = lds_base + (unsigned)(t & 1) * SLOT, nxt = lds_base + (unsigned)((t + 1) & 1) * SLOT;
-        phase(f0, f1, cur, 1, false, t);                              // k-step 0 of tile t; read k-step 1 of tile t
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile t+1 (requested a tile ago) has landed; this wave is done reading tile t's buffer
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        phase(f1, f0, nxt, 0, true, t);                               // k-step 1 of tile t; request tile t+2 into tile t's buffer; read k-step 0 of tile t+1
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // (the clamped requests of the last tiles)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#undef G4_DMA
-#undef G4_LDS
-    store_acc256_lds<OUT_F32, ACCUM, 8, 0>(acc0, smem4 + wave * (4 * 4096), Cv, bias, residual, M, N, ldc, ldr, m0 + wm * 128, n0 + wn * 128, lane);
-    store_acc256_lds<OUT_F32, ACCUM, 8, 0>(acc1, smem4 + wave * (4 * 4096), Cv, bias, residual, M, N, ldc, ldr, m0 + wm * 128, n0 + wn * 128 + 64, lane);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Skinny GEMM for the decode regime (M <= 64 rows, one new token per rollout row): out[M,N] = x[M,K] * W[N,K]^T.
 // HBM-bound weight streaming: every W element is read exactly once, straight from global memory into the MFMA A
 // fragment (no LDS: the operand is not shared between waves).  A block owns 16 output columns; its 4 waves split K
@@ -1982,24 +1870,6 @@ extern "C" int tr1_gemm_nt_bf16(const void* A, const void* B, void* C, const voi
                 const double c = cost(r * 32, BN2, 256, eff[r - 7]);
                 if (c < best) { best = c; rt = r; }
             }
-        }
-        const char* g4 = getenv("TR1_GEMM4W");
-        if (g4 && g4[0] == '1' && M >= 512 && N >= 256 && (uint64_t)M * (uint64_t)lda * 2ull < 0xffffffffull && (uint64_t)N * (uint64_t)ldb * 2ull < 0xffffffffull) {
-            const int64_t t4m = (M + 255) / 256, t4n = (N + 255) / 256;
-            const size_t dyn4 = 2 * 2 * 256 * BK * 2;
-            static bool attr4 = false;
-            if (!attr4) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt4w_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn4);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt4w_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn4);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt4w_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn4);
-                attr4 = true;
-            }
-            dim3 grid4((unsigned)(t4m * t4n));
-#define LAUNCH4(OF, AC) hipLaunchKernelGGL((gemm_nt4w_kernel<OF, AC>), grid4, dim3(256), dyn4, s, (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, \
-                                           (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, (int)t4m, (int)t4n)
-            if (out_f32) { if (accumulate) LAUNCH4(true, true); else LAUNCH4(true, false); } else LAUNCH4(false, false);
-#undef LAUNCH4
-            TR1_LAUNCH_CHECK();
         }
         if (rt) {
             const int bmx = rt * 32;
