@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // spill the hot path's registers for the whole loop (137 spilled VGPRs, scratch traffic inside the tile loop)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
+                if (!__all(alpha[b] == 1.0f))                         // (per 32-row q-block: the other one's accumulators are left alone - multiplying by 1 is the identity)
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
 #pragma unroll
