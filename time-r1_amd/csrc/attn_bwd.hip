@@ -1212,6 +1212,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
     int tq, hq;
     att_split_row(p, valid ? R : nR - 1, tq, hq);
     const int pre = valid ? p.pre[tq] : 0, lo = valid ? p.lo[tq] : 1, hi = valid ? p.hi[tq] : 0;
+    const int hi_c = hi < p.n_slots ? hi : p.n_slots - 1;             // the two visible intervals clamped to the cache's slots (see attn_fwd32_kernel)
+    const int pre_e = pre < p.n_slots ? pre : p.n_slots, lo_e = hi_c >= lo ? lo : 0x7fffffff, hi_d = hi_c >= lo ? hi_c - lo : 0;
     const int64_t si = (int64_t)(kvh * p.group + hq) * p.T + tq;
     const bool fused_delta = p.lse2_out != nullptr;                   // wave-uniform (kernel argument)
     float lse = INFINITY, dlt = 0.f;                                  // log2-scaled LSE; +inf (no visible key / padding row) -> P = 0
@@ -1360,11 +1362,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dq32_kernel(AttnParams p, const 
                         cs[r] = pv * (cp[r] - dlt);
                     }
                 } else {
+                    // (round 6) the interval mask as vector instructions only (two compares + two selects on the clamped intervals, see attn_fwd32_kernel): a masked
+                    // score becomes -inf, so P = exp2(-inf) = +0 - the value the select on the lane masks produced
+                    const int base = kv0 + kb * 32 + 4 * h;
+                    const unsigned mA = (unsigned)(base - lo_e), mD = (unsigned)hi_d;
+                    const int mB = pre_e - base;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre, lo, hi);
-                        const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(cs[r], p.scale_log2, -lse)) : 0.f;
+                        const int c = (r & 3) + 8 * (r >> 2);
+                        const float sv = cs[r];
+                        float x = (mA + (unsigned)c <= mD) ? sv : NEG_INF;
+                        asm volatile("" : "+v"(x));
+                        x = (c < mB) ? sv : x;
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x, p.scale_log2, -lse));
                         cs[r] = pv * (cp[r] - dlt);
                     }
                 }

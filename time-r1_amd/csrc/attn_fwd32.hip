@@ -76,6 +76,9 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
     int tq, hq;
     att_split_row(p, valid ? R : nR - 1, tq, hq);
     const int pre = valid ? p.pre[tq] : 0, lo = valid ? p.lo[tq] : 1, hi = valid ? p.hi[tq] : 0;
+    // the row's two visible intervals clamped to the cache's slots: visible(kv) = kv < pre_e | (unsigned)(kv - lo_e) <= hi_d  (lo_e = INT_MAX: no second interval)
+    const int hi_c = hi < p.n_slots ? hi : p.n_slots - 1;
+    const int pre_e = pre < p.n_slots ? pre : p.n_slots, lo_e = hi_c >= lo ? lo : 0x7fffffff, hi_d = hi_c >= lo ? hi_c - lo : 0;
     int wmaxpre = valid ? pre : 0, wminpre = valid ? pre : 0x7fffffff;
     int wminlo = (valid && hi >= lo) ? lo : 0x7fffffff, wmaxhi = (valid && hi >= lo) ? hi : -1;
     int wmaxlo = valid ? (hi >= lo ? lo : 0x7fffffff) : -1, wminhi = valid ? (hi >= lo ? hi : -1) : 0x7fffffff;
@@ -193,13 +196,22 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
             //  only rewrites cs in place, so both paths share ONE copy of the code below and no register copies appear at the join; the max runs
             //  as two independent v_max3 chains; scale / subtract and the row sum are packed-fp32 instructions, two values each)
             if (!full) {
+                // (round 6) vector instructions only - two compares + two selects per score on the clamped intervals [0, pre_e) and [lo_e, lo_e + hi_d]: the lane-mask form
+                // (v_cmp -> s_and / s_or on the masks -> v_cndmask) put scalar instructions that wait for vector results between the selects (attn_fwd64.hip measured
+                // 4 600 against 2 600 cycles per masked tile); same values
+                const int base = kv0 + 4 * h;
+                const unsigned mA = (unsigned)(base - lo_e), mD = (unsigned)hi_d;
+                const int mB = pre_e - base;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre, lo, hi);
-                        cs[kb][r] = ok ? cs[kb][r] : NEG_INF;
+                        const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+                        const float sv = cs[kb][r];
+                        float x = (mA + (unsigned)c <= mD) ? sv : NEG_INF;
+                        asm volatile("" : "+v"(x));
+                        x = (c < mB) ? sv : x;
+                        cs[kb][r] = x;
                     }
             }
             float mxa = NEG_INF, mxb = NEG_INF;
