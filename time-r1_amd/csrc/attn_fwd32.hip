@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { mxa = att_max3(mxa, cs[0][r], cs[0][r + 1]); mxb = att_max3(mxb, cs[1][r], cs[1][r + 1]); }
             float mx = fmaxf(mxa, mxb);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            { float mx0_, mx1_; att_halves(mx, mx0_, mx1_); mx = fmaxf(mx0_, mx1_); }
             // Lazy running maximum: when no row of the wave would raise its maximum by more than FWD_LAZY_MAX (log2 units), the OLD maximum stays the
             // reference point of this tile - alpha == 1 for every row, so the 64 accumulator multiplies per lane are skipped and P = exp2(s - m_old) <= 2^6;
             // l, the accumulators and the LSE (m + log2 l) stay mutually consistent because all three use the same reference.  With the exact test
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512) void attn_fwd32_kernel(AttnParams p) {
                     rs2 += e;
                 }
             float rs = rs2[0] + rs2[1];
-            rs += __shfl_xor(rs, 32, 64);
+            { float rs0_, rs1_; att_halves(rs, rs0_, rs1_); rs = rs0_ + rs1_; }
             l = l * alpha + rs; m = m_new;
             if (!__all(alpha == 1.0f)) {      // exact: the running maximum did not move for any row of the wave -> no rescale needed
 #pragma unroll
@@ -488,6 +488,8 @@ __global__ __launch_bounds__(512) void attn_dec32_kernel(AttnParams p) {
         pre = mk[0]; lo = mk[64]; hi = mk[128];
     }
     if (!valid) { pre = 0; lo = 1; hi = 0; }
+    const int hi_c = hi < p.n_slots ? hi : p.n_slots - 1;             // the row's two visible intervals clamped to the cache's slots
+    const int pre_e = pre < p.n_slots ? pre : p.n_slots, lo_e = hi_c >= lo ? lo : 0x7fffffff, hi_d = hi_c >= lo ? hi_c - lo : 0;
     int landed = spec_hit ? 1 : (n_my < NB ? n_my : NB);             // tiles whose DMA (this wave's share) is known complete
     const int first_batch = n_my < NB ? n_my : NB;                    // tiles requested before the loop
 
@@ -556,15 +558,21 @@ __global__ __launch_bounds__(512) void attn_dec32_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cs[r]);
         } else {
+            // (round 6) vector-only interval mask (two compares + two selects on the clamped intervals; see attn_fwd32_kernel): every suffix tile of a decode step takes this path
+            const int base = kv0 + 4 * h;
+            const unsigned mA = (unsigned)(base - lo_e), mD = (unsigned)hi_d;
+            const int mB = pre_e - base;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool ok = (kv < p.n_slots) & att_visible_nb(kv, pre, lo, hi);
-                const float v = ok ? cs[r] : NEG_INF;
+                const int c = (r & 3) + 8 * (r >> 2);
+                const float sv = cs[r];
+                float v = (mA + (unsigned)c <= mD) ? sv : NEG_INF;
+                asm volatile("" : "+v"(v));
+                v = (c < mB) ? sv : v;
                 cs[r] = v; mx = fmaxf(mx, v);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        { float mx0_, mx1_; att_halves(mx, mx0_, mx1_); mx = fmaxf(mx0_, mx1_); }
         const float m_new = fmaxf(m, mx * p.scale_log2);
         const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m - m_safe);
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(512) void attn_dec32_kernel(AttnParams p) {
             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[r], p.scale_log2, -m_safe));
             cs[r] = e; rs += e;
         }
-        rs += __shfl_xor(rs, 32, 64);
+        { float rs0_, rs1_; att_halves(rs, rs0_, rs1_); rs = rs0_ + rs1_; }
         l = l * alpha + rs; m = m_new;
         if (!__all(alpha == 1.0f)) {
 #pragma unroll
