@@ -323,14 +323,8 @@ typedef __attribute__((address_space(3))) void* att_lptr_t;
 TR1_DEV int skey(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 // max of three without the canonicalising v_max x, x that fmaxf() costs per operand (no NaN can reach the score tiles: -inf masks, finite inputs)
 TR1_DEV float att_max3(float a, float b, float c) { float o; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c)); return o; }
-// both halves of a wave meet: x -> (the value of lane & 31 in the lower half, the value of lane & 31 in the upper half), in every lane.  v_permlane32_swap is a vector
-// instruction; __shfl_xor(x, 32) is a ds_bpermute whose lgkmcnt(0) wait also drains every LDS fragment read in flight (round 6, attn_fwd64.hip's timeline: four of
-// those per tile cost 600 of 4 000 cycles).  fmaxf(a, b) / a + b give what fmaxf(x, shfl) / x + shfl gave, bit for bit (both are commutative).  Assembly: the
-// builtin's second result is mis-assigned by this hipcc; the leading nops are the VALU-write -> permlane read wait states.
-TR1_DEV void att_halves(float x, float& a, float& b) {
-    a = x; b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
+// both halves of a wave meet (tr1_common.h: v_permlane32_swap instead of the ds_bpermute behind __shfl_xor(x, 32)): fmaxf(a, b) / a + b give what fmaxf(x, shfl) / x + shfl gave
+TR1_DEV void att_halves(float x, float& a, float& b) { tr1_halves32(x, a, b); }
 // registers b .. b+7 of a 32x32 accumulator -> one bf16 MFMA operand fragment (k-slot j of lane half h = accumulator row 16(b/8) + (j&3) + 8(j>>2) + 4h)
 TR1_DEV bf16x8_t pack8(const f32x16_t& c, int b) {
     u32x4_t w = {pack2bf(c[b], c[b + 1]), pack2bf(c[b + 2], c[b + 3]), pack2bf(c[b + 4], c[b + 5]), pack2bf(c[b + 6], c[b + 7])};

@@ -422,8 +422,8 @@ __global__ __launch_bounds__(128) void attn_combine128_kernel(AttnParams p, int6
         }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        a0[j] += __shfl_xor(a0[j], 16, 64); a1[j] += __shfl_xor(a1[j], 16, 64);
-        a0[j] += __shfl_xor(a0[j], 32, 64); a1[j] += __shfl_xor(a1[j], 32, 64);
+        a0[j] = tr1_sum_xor16(a0[j]); a1[j] = tr1_sum_xor16(a1[j]);      // (vector-unit exchanges, same partners and order as the shuffles they replace: tr1_common.h)
+        a0[j] = tr1_sum_xor32(a0[j]); a1[j] = tr1_sum_xor32(a1[j]);
     }
     if (sg != 0) return;
     int t, hq;

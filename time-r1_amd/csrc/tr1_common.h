@@ -27,14 +27,27 @@ TR1_DEV unsigned pack2bf(float lo, float hi) {
 TR1_DEV float bflo(unsigned w) { return __uint_as_float(w << 16); }
 TR1_DEV float bfhi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- cross-lane exchanges without the LDS (round 6).  __shfl_xor lowers to ds_bpermute_b32: an LDS round trip plus an lgkmcnt(0) wait that also drains every LDS read
+// in flight; a 6-step wave reduction is six DEPENDENT round trips (~500 cycles in the latency-bound decode kernels).  gfx950 exchanges the halves (v_permlane32_swap)
+// and the odd / even 16-lane rows (v_permlane16_swap) of a wave in the vector unit, and DPP row rotations cover the steps inside a row.  The reductions below take
+// the SAME partners in the SAME order as the xor butterfly 32, 16, 8, 4, 2, 1 they replace: after step k the values have period k inside a row, so the lane that a
+// rotation by k/2 reads holds exactly what lane ^ (k/2) holds - and a + b, max(a, b) do not care which side the partner is on: bit-identical results.
+// (Assembly for the swaps: the builtin's second result is mis-assigned by this hipcc; the leading nops are the VALU-write -> permlane-read wait states.)
+TR1_DEV void tr1_halves32(float x, float& a, float& b) { a = x; b = x; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }   // a = lane & 31 of the lower half, b = of the upper half
+TR1_DEV void tr1_halves16(float x, float& a, float& b) { a = x; b = x; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }   // a = the even row of each row pair, b = the odd row
+template <int N> TR1_DEV float tr1_row_ror(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false)); }
+TR1_DEV float tr1_sum_xor32(float v) { float a, b; tr1_halves32(v, a, b); return a + b; }      // == v + __shfl_xor(v, 32, 64)
+TR1_DEV float tr1_sum_xor16(float v) { float a, b; tr1_halves16(v, a, b); return a + b; }      // == v + __shfl_xor(v, 16, 64)
 TR1_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = tr1_sum_xor32(v); v = tr1_sum_xor16(v);
+    v += tr1_row_ror<8>(v); v += tr1_row_ror<4>(v); v += tr1_row_ror<2>(v); v += tr1_row_ror<1>(v);
     return v;
 }
 TR1_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    float a, b;
+    tr1_halves32(v, a, b); v = fmaxf(a, b);
+    tr1_halves16(v, a, b); v = fmaxf(a, b);
+    v = fmaxf(v, tr1_row_ror<8>(v)); v = fmaxf(v, tr1_row_ror<4>(v)); v = fmaxf(v, tr1_row_ror<2>(v)); v = fmaxf(v, tr1_row_ror<1>(v));
     return v;
 }
 
